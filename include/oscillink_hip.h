@@ -1,0 +1,149 @@
+/* oscillink_hip.h -- C ABI of liboscillink_hip.so: the MI355X (gfx950) implementation of the
+ * Oscillink lattice "settle" hot path.
+ *
+ * The reference (Maverick0351a/Oscillink v0.1.13) is pure Python + NumPy and has NO native/FFI
+ * boundary: its boundary is the Python class `OscillinkLattice` (oscillink/core/lattice.py) calling
+ * the NumPy functions in oscillink/core/{graph,solver,receipts}.py.  Every entry point below
+ * replaces one of those Python seams 1:1 (file:line cited per function; paths are relative to the
+ * reference checkout).  The Python mirror of the class that binds these symbols with ctypes is
+ * `oscillink_amd/lattice.py`; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; all host arrays are row-major, contiguous, caller-owned; fp32 / int32 / int64.
+ *   - every call returns 0 on success or a negative OSC_E_* code; osc_last_error() gives the text.
+ *   - a handle owns one HIP stream and all its device memory; handles are independent and a handle
+ *     must not be used from two threads at once (the reference's cloud runs one lattice per request
+ *     thread: cloud/app/main.py:1030-1061).  No process-global mutable state except the last-error
+ *     string of failed osc_create calls (thread-local).
+ *   - there is NO CPU fallback: without a usable gfx950 device osc_create fails with OSC_E_NODEVICE.
+ */
+#ifndef OSCILLINK_HIP_H
+#define OSCILLINK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct osc_lattice* osc_handle;
+
+enum {
+  OSC_OK = 0,
+  OSC_E_INVALID = -1,     /* bad argument (the Python layer maps this to ValueError)            */
+  OSC_E_NODEVICE = -2,    /* no HIP device / wrong architecture                                  */
+  OSC_E_HIP = -3,         /* a HIP runtime call failed                                           */
+  OSC_E_STATE = -4,       /* call order problem (e.g. deltaH before any U* solve)                */
+  OSC_E_UNSUPPORTED = -5, /* valid request this build cannot serve (e.g. kneighbors > 128)       */
+  OSC_E_COMM = -6         /* RCCL failure                                                        */
+};
+
+/* precond argument of osc_settle (lattice.py:164,186): "jacobi" -> 1, anything else -> 0 */
+enum { OSC_PRECOND_NONE = 0, OSC_PRECOND_JACOBI = 1 };
+
+/* ---- library / device ---------------------------------------------------------------------- */
+const char* osc_version(void);
+int osc_device_count(int32_t* n);                       /* never initialises a device context     */
+int osc_device_name(int32_t device, char* out, int32_t cap);
+int osc_device_synchronize(int32_t device);
+const char* osc_last_error(osc_handle h);               /* h may be NULL: error of the last failed osc_create on this thread */
+
+/* ---- construction: OscillinkLattice.__init__ (lattice.py:33-110) ---------------------------- */
+/* Copies Y (N x D) to the device, sets U = Y, B = 1, psi = 0, lams = (1.0, 0.5, 4.0).
+ * build_graph != 0: builds the mutual-kNN graph on the device -- graph.py:8-66 (mutual_knn_adj),
+ * :69-83 (row_sum_cap), :86-93 (normalized_laplacian).  k is clamped to [1, N-1] (lattice.py:60).
+ * deterministic != 0 -> ties ordered (similarity desc, index asc) (graph.py:46-49); the
+ * non-deterministic reference path leaves ties unspecified (graph.py:59) and this build uses the
+ * same total order for it.  seed < 0 means None; seed >= 0 is accepted and, like the reference's
+ * jitter (graph.py:54-58, magnitude 1e-8 < fp32 resolution of the similarities), only ever affects
+ * exact ties, which the total order already resolves.
+ * build_graph == 0: no graph yet; call osc_set_csr (from_state / parity tests). */
+int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, int32_t deterministic,
+               int64_t seed, int32_t device, int32_t build_graph, osc_handle* out);
+int osc_destroy(osc_handle h);
+
+/* rebuild_graph (lattice.py:760-801) */
+int osc_rebuild_graph(osc_handle h, int32_t k, float row_cap, int32_t deterministic, int64_t seed);
+
+/* nnz = stored directed edges (== count of A > 0), max_deg = widest row, build_ms = device build time */
+int osc_graph_stats(osc_handle h, int64_t* nnz, int32_t* max_deg, double* build_ms);
+
+/* CSR view of the graph for `.A`, `.L_sym`, `_signature()` (lattice.py:729-744) and export_state
+ * (:582-624).  rowptr has N+1 entries; col/a/w have nnz entries, columns ascending within a row;
+ * a = capped adjacency A_ij (> 0), w = A_ij / (sqrt_deg_i sqrt_deg_j); sqrt_deg has N entries.
+ * Any output pointer may be NULL. */
+int osc_get_csr(osc_handle h, int64_t* rowptr, int32_t* col, float* a, float* w, float* sqrt_deg);
+
+/* Inject a (symmetric, zero-diagonal, already capped) adjacency as CSR; recomputes sqrt_deg and W
+ * exactly as normalized_laplacian (graph.py:86-93).  Mirrors from_state's `lat.A = A;
+ * lat.L_sym, lat.sqrt_deg = normalized_laplacian(lat.A)` (lattice.py:709-713). */
+int osc_set_csr(osc_handle h, const int64_t* rowptr, const int32_t* col, const float* a);
+
+/* raw per-row top-k lists of the last device graph build (idx/val: N x k_eff, unsorted within a row;
+ * val is the similarity clipped at 0) -- graph.py:59-62.  Test/diagnostic aid. */
+int osc_get_knn_lists(osc_handle h, int32_t* idx, float* val, int32_t* k_eff);
+
+/* ---- state setters -------------------------------------------------------------------------- */
+/* set_query / set_gates (lattice.py:114-127): psi has D entries; gates (N entries) may be NULL */
+int osc_set_query(osc_handle h, const float* psi, const float* gates_or_null);
+/* add_chain + build_path_laplacian (lattice.py:129-149, graph.py:96-111); weights may be NULL (all 1) */
+int osc_set_chain(osc_handle h, const int32_t* chain, const float* weights_or_null, int32_t len, float lamP);
+int osc_clear_chain(osc_handle h);                      /* lattice.py:151-157 */
+int osc_set_lams(osc_handle h, float lamG, float lamC, float lamQ);
+int osc_get_U(osc_handle h, float* out);                /* N x D */
+int osc_set_U(osc_handle h, const float* U_or_null);    /* NULL -> U = Y (device copy) */
+
+/* ---- solves --------------------------------------------------------------------------------- */
+/* settle (lattice.py:159-230) + cg_solve (solver.py:6-37): one implicit-Euler step
+ * (I + dt M) U+ = U + dt (lamG Y + lamQ B 1 psi^T), Jacobi diagonal 1 + dt (lamG + lamQ B + [lamP]),
+ * x0 = Y (warm_start == 0) | U | (1-w) Y + w U with w = clamp(inertia, 0, 1) (lattice.py:751-758).
+ * Stop test: max over columns of ||r_c||_2 <= tol, checked before the beta/p update.  Never fails on
+ * non-convergence: iters = max_iters and res is the last residual (lattice.py:206-212).
+ * ms = host wall time of x0 selection + CG, device-synchronised (the reference's t_ms). */
+int osc_settle(osc_handle h, float dt, int32_t max_iters, float tol, int32_t precond, int32_t warm_start,
+               float inertia, int32_t* iters, float* res, double* ms);
+/* solve_Ustar (lattice.py:232-290): M U* = lamG Y + lamQ B 1 psi^T from x0 = Y, Jacobi lamG + lamQ B + [lamP].
+ * U* stays resident on the device for osc_deltaH / receipts; Ustar_out (N x D) may be NULL. */
+int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out, int32_t* iters, float* res,
+                    double* ms);
+/* residual after every iteration of the last solve (solver.py:29), n <= cap entries written */
+int osc_residual_history(osc_handle h, float* out, int32_t cap, int32_t* n);
+
+/* screened diffusion solve used by compute_diffusion_gates(method="cg")
+ * (preprocess/diffusion.py:130-151): (L_sym + gamma I) h = s, x0 = 0, Jacobi diag(L)+gamma = 1+gamma. */
+int osc_cg_single_rhs(osc_handle h, float gamma, const float* s, float tol, int32_t max_iters, float* h_out,
+                      int32_t* iters, float* res);
+/* cosine of every anchor row with psi (diffusion.py:104-107): out[i] = <Y_i/(|Y_i|+1e-12), psi/(|psi|+1e-12)> */
+int osc_cosine_to(osc_handle h, const float* psi, float* out);
+
+/* ---- receipts ------------------------------------------------------------------------------- */
+/* deltaH_trace (receipts.py:10-25) on the resident U and U* */
+int osc_deltaH(osc_handle h, double* dH);
+/* per_node_components (receipts.py:28-60): three arrays of N entries (any may be NULL) */
+int osc_receipt_components(osc_handle h, float* coh_drop, float* anchor_pen, float* query_term);
+/* null_points (receipts.py:63-83), sparse restatement: per row the first argmax edge, reported iff
+ * residual > 0 and z > z_th.  Output arrays hold N entries; *count rows are written in row order. */
+int osc_null_points(osc_handle h, float z_th, int32_t* i_out, int32_t* j_out, float* z_out, float* r_out,
+                    int32_t* count);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Per-kernel HIP-event timing on the handle's own stream.  which: 0 = operator apply (SpMM, the
+ * CG matvec), 1 = fused x/r update, 2 = p update, 3 = kNN GEMM+top-k.  Returns launches and the
+ * summed device time since the last reset.  Enabling adds two event records per launch. */
+int osc_profile_enable(osc_handle h, int32_t on);
+int osc_profile_reset(osc_handle h);
+int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* total_ms);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---------------------------------------- */
+/* Column-sharded CG: every rank holds the whole graph and the column slab [c0, c1) of the N x D state;
+ * alpha/beta are per column (solver.py:22-36) so the only exchange per iteration is one
+ * all-reduce(max) of the stop-test residual.  id is an ncclUniqueId (128 bytes) made by rank 0
+ * with osc_comm_unique_id and distributed by the caller. */
+int osc_comm_unique_id(char id_out[128]);
+int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world);
+int osc_comm_shard(osc_handle h, int32_t* c0, int32_t* c1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSCILLINK_HIP_H */

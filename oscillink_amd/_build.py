@@ -1,0 +1,55 @@
+"""Builds liboscillink_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "liboscillink_hip.so")
+SOURCES = ["osc_api.hip", "cg_kernels.hip", "knn_kernels.hip", "receipt_kernels.hip"]
+HEADERS = ["common.hpp", "knn.hpp", "receipts.hpp", os.path.join("..", "..", "include", "oscillink_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source and link the shared library. Returns the library path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    objs = []
+    for s in SOURCES:
+        o = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+        if verbose and out.strip():
+            print(out, file=sys.stderr)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl",
+            "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,118 @@
+"""ctypes binding of liboscillink_hip.so (include/oscillink_hip.h).
+
+The library is the product's only compute path: if it is missing or no gfx950 device is present the
+calls below raise -- there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboscillink_hip.so")
+
+OSC_OK, OSC_E_INVALID, OSC_E_NODEVICE, OSC_E_HIP, OSC_E_STATE, OSC_E_UNSUPPORTED, OSC_E_COMM = 0, -1, -2, -3, -4, -5, -6
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_f64p = C.POINTER(C.c_double)
+Handle = C.c_void_p
+
+# name -> (restype, argtypes): exactly the declarations of include/oscillink_hip.h
+SIGNATURES = {
+    "osc_version": (C.c_char_p, []),
+    "osc_device_count": (C.c_int, [c_i32p]),
+    "osc_device_name": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
+    "osc_device_synchronize": (C.c_int, [C.c_int32]),
+    "osc_last_error": (C.c_char_p, [Handle]),
+    "osc_create": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int64, C.c_int32,
+                             C.c_int32, C.POINTER(Handle)]),
+    "osc_destroy": (C.c_int, [Handle]),
+    "osc_rebuild_graph": (C.c_int, [Handle, C.c_int32, C.c_float, C.c_int32, C.c_int64]),
+    "osc_graph_stats": (C.c_int, [Handle, c_i64p, c_i32p, c_f64p]),
+    "osc_get_csr": (C.c_int, [Handle, c_i64p, c_i32p, c_f32p, c_f32p, c_f32p]),
+    "osc_set_csr": (C.c_int, [Handle, c_i64p, c_i32p, c_f32p]),
+    "osc_get_knn_lists": (C.c_int, [Handle, c_i32p, c_f32p, c_i32p]),
+    "osc_set_query": (C.c_int, [Handle, c_f32p, c_f32p]),
+    "osc_set_chain": (C.c_int, [Handle, c_i32p, c_f32p, C.c_int32, C.c_float]),
+    "osc_clear_chain": (C.c_int, [Handle]),
+    "osc_set_lams": (C.c_int, [Handle, C.c_float, C.c_float, C.c_float]),
+    "osc_get_U": (C.c_int, [Handle, c_f32p]),
+    "osc_set_U": (C.c_int, [Handle, c_f32p]),
+    "osc_settle": (C.c_int, [Handle, C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_float, c_i32p, c_f32p,
+                             c_f64p]),
+    "osc_solve_ustar": (C.c_int, [Handle, C.c_float, C.c_int32, c_f32p, c_i32p, c_f32p, c_f64p]),
+    "osc_residual_history": (C.c_int, [Handle, c_f32p, C.c_int32, c_i32p]),
+    "osc_cg_single_rhs": (C.c_int, [Handle, C.c_float, c_f32p, C.c_float, C.c_int32, c_f32p, c_i32p, c_f32p]),
+    "osc_cosine_to": (C.c_int, [Handle, c_f32p, c_f32p]),
+    "osc_deltaH": (C.c_int, [Handle, c_f64p]),
+    "osc_receipt_components": (C.c_int, [Handle, c_f32p, c_f32p, c_f32p]),
+    "osc_null_points": (C.c_int, [Handle, C.c_float, c_i32p, c_i32p, c_f32p, c_f32p, c_i32p]),
+    "osc_profile_enable": (C.c_int, [Handle, C.c_int32]),
+    "osc_profile_reset": (C.c_int, [Handle]),
+    "osc_profile_get": (C.c_int, [Handle, C.c_int32, c_i64p, c_f64p]),
+    "osc_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "osc_comm_init": (C.c_int, [Handle, C.c_char_p, C.c_int32, C.c_int32]),
+    "osc_comm_shard": (C.c_int, [Handle, c_i32p, c_i32p]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    """A call into liboscillink_hip.so failed (HIP error, no device, call-order problem)."""
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises NativeError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} is missing: build it with `python -m oscillink_amd._build` (hipcc, gfx950). "
+                "oscillink_amd has no CPU fallback."
+            )
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    lib().osc_device_count(C.byref(n))
+    return int(n.value)
+
+
+def f32(a: np.ndarray):
+    return a.ctypes.data_as(c_f32p)
+
+
+def i32(a: np.ndarray):
+    return a.ctypes.data_as(c_i32p)
+
+
+def i64(a: np.ndarray):
+    return a.ctypes.data_as(c_i64p)
+
+
+def check(rc: int, handle=None, what: str = "") -> None:
+    """Map a status code to the exception the reference's Python surface would raise."""
+    if rc == OSC_OK:
+        return
+    msg = lib().osc_last_error(handle)
+    text = (msg.decode("utf-8", "replace") if msg else "") or what
+    if rc == OSC_E_INVALID:
+        raise ValueError(text)
+    if rc == OSC_E_UNSUPPORTED:
+        raise NotImplementedError(text)
+    raise NativeError(f"{what or 'native call'} failed ({rc}): {text}")

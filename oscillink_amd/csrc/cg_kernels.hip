@@ -1,0 +1,467 @@
+// CG hot loop of the lattice settle path, hand-written for gfx950 (wave64, HBM-bound).
+//
+//   k_spmm      : operator apply  out = (cs_i) x_i - cW sum_j W_ij x_j - cP sum_j Wp_ij x_j   (lattice.py:173-182, 247-255)
+//                 fused with the per-column dot product the CG needs next (solver.py:21,25) and, in INIT mode,
+//                 with the right-hand side, residual, Jacobi scaling and first search direction (solver.py:19-22).
+//   k_update_xr : x += alpha p ; r -= alpha Ap ; column sums of r.r and r.z   (solver.py:27-29, 32-33)
+//   k_update_p  : p = z + beta p with z = r / (Md + 1e-12) recomputed          (solver.py:32, 35)
+//   k_reduce_*  : deterministic second stage of the column reductions -> alpha, beta, residual
+//
+// Layout: every N x D array is row-major with pitch ld (multiple of 4 floats) so one wave reads a row as
+// 16-byte-per-lane coalesced segments.  LPR lanes cover one row's column window (LPR*4*NCH floats); a wave
+// carries 64/LPR rows.  Neighbour ids/weights are read one entry per lane and broadcast with v_readlane
+// (LPR == 64: wave-uniform row base -> scalar address + lane offset) or ds_bpermute (LPR < 64).
+// Column sums never use atomics: each block keeps per-lane partials in registers over its grid-stride rows,
+// folds its 4 waves through LDS and writes one row of part[grid][ld]; a small second kernel finishes in fp64.
+#include "common.hpp"
+
+namespace osc {
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
+  return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+__device__ __forceinline__ float4 mulacc4(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+
+template <int LPR>
+__device__ __forceinline__ int bcast_i(int v, int sub, int t) {
+  if constexpr (LPR == 64) {
+    return __builtin_amdgcn_readlane(v, t);
+  } else {
+    return __shfl(v, sub * LPR + t, 64);
+  }
+}
+template <int LPR>
+__device__ __forceinline__ float bcast_f(float v, int sub, int t) {
+  return __int_as_float(bcast_i<LPR>(__float_as_int(v), sub, t));
+}
+
+// fold per-lane column partials of the 4 waves of a block and write one row of part[grid][ld]
+template <int LPR, int NCH>
+__device__ __forceinline__ void block_fold(float4 (&dot)[NCH], float* red /*[4][CPW]*/, float* part, int32_t ld,
+                                           int32_t c0, int32_t c1) {
+  constexpr int CPW = NCH * LPR * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, lr = lane % LPR;
+  if constexpr (LPR < 64) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        dot[ch].x += __shfl_xor(dot[ch].x, o, 64);
+        dot[ch].y += __shfl_xor(dot[ch].y, o, 64);
+        dot[ch].z += __shfl_xor(dot[ch].z, o, 64);
+        dot[ch].w += __shfl_xor(dot[ch].w, o, 64);
+      }
+    }
+  }
+  __syncthreads();  // red may still be read by a previous fold
+  if (sub == 0) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) st4(red + wave * CPW + (ch * LPR + lr) * 4, dot[ch]);
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < CPW; idx += 256) {
+    const int col = c0 + idx;
+    if (col < c1) part[(size_t)blockIdx.x * ld + col] = (red[idx] + red[CPW + idx]) + (red[2 * CPW + idx] + red[3 * CPW + idx]);
+  }
+}
+
+template <int NCH>
+struct Unroll {
+  static constexpr int U = NCH <= 3 ? 4 : (NCH <= 6 ? 2 : 1);
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int NCH, int MODE>
+__global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
+  constexpr int RPW = 64 / LPR;
+  constexpr int CPW = NCH * LPR * 4;
+  constexpr int U = Unroll<NCH>::U;
+  __shared__ __attribute__((aligned(16))) float red[4 * CPW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, lr = lane % LPR;
+  const int32_t ld = a.ld;
+  int coff[NCH];
+  bool cok[NCH];
+  float4 psi4[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    coff[ch] = a.c0 + (ch * LPR + lr) * 4;
+    cok[ch] = coff[ch] < a.c1;
+    psi4[ch] = f4(0.f);
+    if (MODE == SPMM_INIT && cok[ch]) psi4[ch] = ld4(a.psi + coff[ch]);
+  }
+  float4 dot[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) dot[ch] = f4(0.f);
+
+  const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t rb = ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
+    int row = (int)rb + sub;
+    const bool rok = row < a.N;
+    if (!rok) row = (int)a.N - 1;
+    if constexpr (LPR == 64) row = __builtin_amdgcn_readfirstlane(row);
+    int deg = rok ? a.g.deg[row] : 0;
+    if constexpr (LPR == 64) deg = __builtin_amdgcn_readfirstlane(deg);
+    int maxdeg = deg;
+    if constexpr (LPR < 64) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o, 64));
+    }
+    const float* xrow = a.X + (size_t)row * ld;
+    float4 xs[NCH], acc[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      xs[ch] = cok[ch] ? ld4(xrow + coff[ch]) : f4(0.f);
+      acc[ch] = f4(0.f);
+    }
+    const int32_t* crow = a.g.col + (size_t)row * a.g.width;
+    const float* wrow = a.g.w + (size_t)row * a.g.width;
+    for (int e0 = 0; e0 < maxdeg; e0 += LPR) {
+      const int e = e0 + lr;
+      int cj = row;
+      float wj = 0.f;
+      if (e < deg) {
+        cj = crow[e];
+        wj = wrow[e];
+      }
+      const int cnt = min(LPR, maxdeg - e0);
+      for (int t = 0; t < cnt; t += U) {
+        float4 v[U][NCH];
+        float wv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = bcast_i<LPR>(cj, sub, t + u);  // t+u <= LPR-1: cnt <= LPR and LPR % U == 0
+          wv[u] = bcast_f<LPR>(wj, sub, t + u);
+          const float* xj = a.X + (size_t)j * ld;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) v[u][ch] = cok[ch] ? ld4(xj + coff[ch]) : f4(0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fma4(wv[u], v[u][ch], acc[ch]);
+      }
+    }
+    // chain prior rows (a handful): second tiny ELL addressed through path_slot
+    float4 accp[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) accp[ch] = f4(0.f);
+    if (a.g.path_slot != nullptr) {
+      const int ps = rok ? a.g.path_slot[row] : -1;
+      if (ps >= 0) {
+        const int pd = a.g.pdeg[ps];
+        for (int e = 0; e < pd; ++e) {
+          const int j = a.g.pcol[(size_t)ps * a.g.pwidth + e];
+          const float w = a.g.pw[(size_t)ps * a.g.pwidth + e];
+          const float* xj = a.X + (size_t)j * ld;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch)
+            if (cok[ch]) accp[ch] = fma4(w, ld4(xj + coff[ch]), accp[ch]);
+        }
+      }
+    }
+    if (rok) {
+      const float Bi = a.B[row];
+      const float cs = fmaf(a.op.cs_B, Bi, a.op.cs_const);
+      float invMd = 1.f;
+      if (MODE == SPMM_INIT && a.op.precond) invMd = 1.f / (fmaf(a.op.md_B, Bi, a.op.md_const) + 1e-12f);
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        if (!cok[ch]) continue;
+        float4 o;
+        o.x = cs * xs[ch].x - a.op.cW * acc[ch].x - a.op.cP * accp[ch].x;
+        o.y = cs * xs[ch].y - a.op.cW * acc[ch].y - a.op.cP * accp[ch].y;
+        o.z = cs * xs[ch].z - a.op.cW * acc[ch].z - a.op.cP * accp[ch].z;
+        o.w = cs * xs[ch].w - a.op.cW * acc[ch].w - a.op.cP * accp[ch].w;
+        const size_t off = (size_t)row * ld + coff[ch];
+        if (MODE == SPMM_AP) {
+          st4(a.OUT + off, o);
+          dot[ch] = mulacc4(xs[ch], o, dot[ch]);
+        } else if (MODE == SPMM_DOT) {
+          dot[ch] = mulacc4(xs[ch], o, dot[ch]);
+        } else {  // INIT: r = b - A x0 ; z = r / (Md + eps) ; p = z ; rz = sum r.z   (solver.py:19-22)
+          const float4 u = ld4(a.U + off), y = ld4(a.Y + off);
+          const float qb = a.op.rbB * Bi;
+          float4 r, z;
+          r.x = (a.op.rbU * u.x + a.op.rbY * y.x + qb * psi4[ch].x) - o.x;
+          r.y = (a.op.rbU * u.y + a.op.rbY * y.y + qb * psi4[ch].y) - o.y;
+          r.z = (a.op.rbU * u.z + a.op.rbY * y.z + qb * psi4[ch].z) - o.z;
+          r.w = (a.op.rbU * u.w + a.op.rbY * y.w + qb * psi4[ch].w) - o.w;
+          z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
+          st4(a.OUT + off, xs[ch]);
+          st4(a.R + off, r);
+          st4(a.P + off, z);
+          dot[ch] = mulacc4(r, z, dot[ch]);
+        }
+      }
+    }
+  }
+  block_fold<LPR, NCH>(dot, red, a.part, ld, a.c0, a.c1);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
+  constexpr int RPW = 64 / LPR;
+  constexpr int CPW = NCH * LPR * 4;
+  __shared__ __attribute__((aligned(16))) float red[4 * CPW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, lr = lane % LPR;
+  const int32_t ld = a.ld;
+  int coff[NCH];
+  bool cok[NCH];
+  float4 al[NCH], rr[NCH], rz[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    coff[ch] = a.c0 + (ch * LPR + lr) * 4;
+    cok[ch] = coff[ch] < a.c1;
+    al[ch] = cok[ch] ? ld4(a.alpha + coff[ch]) : f4(0.f);
+    rr[ch] = f4(0.f);
+    rz[ch] = f4(0.f);
+  }
+  const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t rb = ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
+    const int row = (int)rb + sub;
+    if (row >= a.N) continue;
+    float invMd = 1.f;
+    if (a.op.precond) invMd = 1.f / (fmaf(a.op.md_B, a.B[row], a.op.md_const) + 1e-12f);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (!cok[ch]) continue;
+      const size_t off = (size_t)row * ld + coff[ch];
+      float4 x = ld4(a.X + off), p = ld4(a.P + off), r = ld4(a.R + off);
+      const float4 ap = ld4(a.AP + off);
+      x.x = fmaf(p.x, al[ch].x, x.x); x.y = fmaf(p.y, al[ch].y, x.y);
+      x.z = fmaf(p.z, al[ch].z, x.z); x.w = fmaf(p.w, al[ch].w, x.w);
+      r.x = fmaf(-ap.x, al[ch].x, r.x); r.y = fmaf(-ap.y, al[ch].y, r.y);
+      r.z = fmaf(-ap.z, al[ch].z, r.z); r.w = fmaf(-ap.w, al[ch].w, r.w);
+      st4(a.X + off, x);
+      st4(a.R + off, r);
+      rr[ch] = mulacc4(r, r, rr[ch]);
+      const float4 z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
+      rz[ch] = mulacc4(r, z, rz[ch]);
+    }
+  }
+  block_fold<LPR, NCH>(rr, red, a.part_rr, ld, a.c0, a.c1);
+  block_fold<LPR, NCH>(rz, red, a.part_rz, ld, a.c0, a.c1);
+}
+
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void k_update_p(const UpdateArgs a) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, lr = lane % LPR;
+  const int32_t ld = a.ld;
+  int coff[NCH];
+  bool cok[NCH];
+  float4 be[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    coff[ch] = a.c0 + (ch * LPR + lr) * 4;
+    cok[ch] = coff[ch] < a.c1;
+    be[ch] = cok[ch] ? ld4(a.beta + coff[ch]) : f4(0.f);
+  }
+  const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t rb = ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
+    const int row = (int)rb + sub;
+    if (row >= a.N) continue;
+    float invMd = 1.f;
+    if (a.op.precond) invMd = 1.f / (fmaf(a.op.md_B, a.B[row], a.op.md_const) + 1e-12f);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (!cok[ch]) continue;
+      const size_t off = (size_t)row * ld + coff[ch];
+      const float4 r = ld4(a.R + off);
+      float4 p = ld4(a.P + off);
+      p.x = fmaf(p.x, be[ch].x, r.x * invMd); p.y = fmaf(p.y, be[ch].y, r.y * invMd);
+      p.z = fmaf(p.z, be[ch].z, r.z * invMd); p.w = fmaf(p.w, be[ch].w, r.w * invMd);
+      st4(a.P + off, p);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// second stage of the column reductions: 64 columns per block, 16 row-groups, fp64 accumulation
+template <int NIN>
+__device__ __forceinline__ bool reduce_cols(const float* p0, const float* p1, int nb, int32_t ld, int32_t c0,
+                                            int32_t c1, double (&tot)[NIN], int& col) {
+  __shared__ double sh[NIN][16][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  col = c0 + blockIdx.x * 64 + cl;
+  const bool ok = col < c1;
+  double s[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) s[i] = 0.0;
+  if (ok) {
+    for (int b = g; b < nb; b += 16) {
+      s[0] += (double)p0[(size_t)b * ld + col];
+      if (NIN > 1) s[NIN - 1] += (double)p1[(size_t)b * ld + col];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) sh[i][g][cl] = s[i];
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += sh[i][k][cl];
+      tot[i] = t;
+    }
+  }
+  return ok && g == 0;
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_init(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1,
+                                                      double* rz) {
+  double t[1];
+  int col;
+  if (reduce_cols<1>(part, nullptr, nb, ld, c0, c1, t, col)) rz[col] = t[0];
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_alpha(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1,
+                                                       const double* rz, float* alpha) {
+  double t[1];
+  int col;
+  if (reduce_cols<1>(part, nullptr, nb, ld, c0, c1, t, col))
+    alpha[col] = (float)(rz[col] / (t[0] + 1e-18));  // solver.py:25-26
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_beta(const float* part_rr, const float* part_rz, int nb, int32_t ld,
+                                                      int32_t c0, int32_t c1, double* rz, float* beta,
+                                                      uint32_t* res_bits) {
+  double t[2];
+  int col;
+  const bool w = reduce_cols<2>(part_rr, part_rz, nb, ld, c0, c1, t, col);
+  float resc = 0.f;
+  if (w) {
+    resc = (float)sqrt(t[0]);                            // ||r_c||_2        (solver.py:29)
+    beta[col] = (float)(t[1] / (rz[col] + 1e-18));       // solver.py:33-34
+    rz[col] = t[1];
+  }
+  if ((threadIdx.x >> 6) == 0) {  // wave 0 holds the 64 column residuals of this block
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) resc = fmaxf(resc, __shfl_xor(resc, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(res_bits, __float_as_uint(resc));  // non-negative floats order as uints
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1,
+                                                     double* out_cols) {
+  double t[1];
+  int col;
+  if (reduce_cols<1>(part, nullptr, nb, ld, c0, c1, t, col)) out_cols[col] = t[0];
+}
+
+__global__ __launch_bounds__(256) void k_axpby(float* out, const float* a, float ca, const float* b, float cb,
+                                               int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 x = ld4(a + i * 4), y = ld4(b + i * 4);
+    st4(out + i * 4, make_float4(ca * x.x + cb * y.x, ca * x.y + cb * y.y, ca * x.z + cb * y.z, ca * x.w + cb * y.w));
+  }
+}
+
+// ---- dispatch -------------------------------------------------------------------------------
+struct Shape {
+  int lpr, nch;
+};
+inline Shape pick_shape(int ncols) {
+  if (ncols <= 64) return {16, 1};
+  if (ncols <= 128) return {32, 1};
+  int nch = (ncols + 255) / 256;
+  if (nch == 5) nch = 6;
+  if (nch == 7) nch = 8;
+  if (nch > 8) throw std::runtime_error("column window wider than 2048; split it");
+  return {64, nch};
+}
+
+#define OSC_SHAPE_SWITCH(sh, CALL)                                   \
+  do {                                                               \
+    if ((sh).lpr == 16) { CALL(16, 1); }                             \
+    else if ((sh).lpr == 32) { CALL(32, 1); }                        \
+    else switch ((sh).nch) {                                         \
+      case 1: CALL(64, 1); break;                                    \
+      case 2: CALL(64, 2); break;                                    \
+      case 3: CALL(64, 3); break;                                    \
+      case 4: CALL(64, 4); break;                                    \
+      case 6: CALL(64, 6); break;                                    \
+      default: CALL(64, 8); break;                                   \
+    }                                                                \
+  } while (0)
+
+}  // namespace
+
+int spmm_grid(int64_t N, int32_t ncols) {
+  const Shape sh = pick_shape(ncols);
+  const int rpw = 64 / sh.lpr;
+  const int64_t need = (N + 4 * rpw - 1) / (4 * rpw);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(need, 1024));
+}
+
+void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s) {
+  const Shape sh = pick_shape(a.c1 - a.c0);
+#define CALL(L, C)                                                                                   \
+  do {                                                                                               \
+    if (mode == SPMM_AP) hipLaunchKernelGGL((k_spmm<L, C, SPMM_AP>), dim3(grid), dim3(256), 0, s, a); \
+    else if (mode == SPMM_INIT) hipLaunchKernelGGL((k_spmm<L, C, SPMM_INIT>), dim3(grid), dim3(256), 0, s, a); \
+    else hipLaunchKernelGGL((k_spmm<L, C, SPMM_DOT>), dim3(grid), dim3(256), 0, s, a);               \
+  } while (0)
+  OSC_SHAPE_SWITCH(sh, CALL);
+#undef CALL
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_update_xr(const UpdateArgs& a, int grid, hipStream_t s) {
+  const Shape sh = pick_shape(a.c1 - a.c0);
+#define CALL(L, C) hipLaunchKernelGGL((k_update_xr<L, C>), dim3(grid), dim3(256), 0, s, a)
+  OSC_SHAPE_SWITCH(sh, CALL);
+#undef CALL
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_update_p(const UpdateArgs& a, int grid, hipStream_t s) {
+  const Shape sh = pick_shape(a.c1 - a.c0);
+#define CALL(L, C) hipLaunchKernelGGL((k_update_p<L, C>), dim3(grid), dim3(256), 0, s, a)
+  OSC_SHAPE_SWITCH(sh, CALL);
+#undef CALL
+  HIP_CHECK(hipGetLastError());
+}
+
+static inline int red_grid(int32_t c0, int32_t c1) { return (c1 - c0 + 63) / 64; }
+
+void launch_reduce_init(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* rz, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_init, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part, nb, ld, c0, c1, rz);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_reduce_alpha(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, const double* rz, float* alpha,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_alpha, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part, nb, ld, c0, c1, rz, alpha);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_reduce_beta(const float* part_rr, const float* part_rz, int nb, int32_t ld, int32_t c0, int32_t c1,
+                        double* rz, float* beta, uint32_t* res_bits_slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_beta, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part_rr, part_rz, nb, ld, c0, c1, rz,
+                     beta, res_bits_slot);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_sum, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part, nb, ld, c0, c1, out_cols);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_axpby(float* out, const float* a, float ca, const float* b, float cb, int64_t n, hipStream_t s) {
+  const int64_t n4 = n / 4;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n4 + 255) / 256, 2048));
+  hipLaunchKernelGGL(k_axpby, dim3(grid), dim3(256), 0, s, out, a, ca, b, cb, n4);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace osc

@@ -1,0 +1,124 @@
+// Shared declarations for liboscillink_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace osc {
+
+struct HipError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+  if (e != hipSuccess) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    throw HipError(buf);
+  }
+}
+#define HIP_CHECK(x) ::osc::hip_check((x), #x, __FILE__, __LINE__)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    if (count == n && p) return;
+    release();
+    if (count) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    n = count;
+  }
+  void swap(DevBuf& o) {
+    std::swap(p, o.p);
+    std::swap(n, o.n);
+  }
+};
+
+// ---- operator description ------------------------------------------------------------------
+// out_i = (cs_const + cs_B * B_i) x_i - cW * sum_j W_ij x_j - cP * sum_j Wp_ij x_j
+// Jacobi diagonal  Md_i = md_const + md_B * B_i   (lattice.py:187-192, 257-259: lamC is NOT in it)
+// rhs              b_i  = rbU U_i + rbY Y_i + rbB B_i psi
+struct OpParams {
+  float cs_const, cs_B, cW, cP;
+  float md_const, md_B;
+  int precond;
+  float rbU, rbY, rbB;
+};
+
+// ELL view of the lattice graph (degree <= width; columns ascending within a row)
+struct GraphView {
+  const int32_t* col;   // [N][width]
+  const float* w;       // [N][width]   normalised weights W_ij
+  const int32_t* deg;   // [N]
+  int32_t width;
+  // chain prior: path_slot[i] = -1 or row index into the (tiny) path ELL
+  const int32_t* path_slot;  // nullptr when no chain / lamP == 0
+  const int32_t* pcol;       // [P][pwidth]
+  const float* pw;           // [P][pwidth]  normalised path weights
+  const int32_t* pdeg;       // [P]
+  int32_t pwidth;
+};
+
+enum SpmmMode { SPMM_AP = 0, SPMM_INIT = 1, SPMM_DOT = 2 };
+
+struct SpmmArgs {
+  GraphView g;
+  OpParams op;
+  const float* X;     // operand (gathered)
+  float* OUT;         // AP: A x ; INIT: x copy (x0)     (may alias nothing else)
+  float* R;           // INIT: residual out
+  float* P;           // INIT: search direction out
+  const float* U;     // INIT rhs
+  const float* Y;     // INIT rhs
+  const float* B;     // [N]
+  const float* psi;   // [ld]
+  float* part;        // [grid][ld] column partial sums of the mode's dot product
+  int64_t N;
+  int32_t ld;         // row pitch in floats (multiple of 4)
+  int32_t c0, c1;     // column window [c0, c1), multiples of 4
+};
+
+struct UpdateArgs {
+  float* X;
+  float* R;
+  float* P;
+  const float* AP;
+  const float* B;
+  const float* alpha;  // [ld]
+  const float* beta;   // [ld]
+  float* part_rr;      // [grid][ld]
+  float* part_rz;      // [grid][ld]
+  OpParams op;
+  int64_t N;
+  int32_t ld, c0, c1;
+};
+
+// launchers implemented in cg_kernels.hip
+int spmm_grid(int64_t N, int32_t ncols);
+void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s);
+void launch_update_xr(const UpdateArgs& a, int grid, hipStream_t s);
+void launch_update_p(const UpdateArgs& a, int grid, hipStream_t s);
+// column reductions over `nb` partial rows
+void launch_reduce_init(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* rz, hipStream_t s);
+void launch_reduce_alpha(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, const double* rz,
+                         float* alpha, hipStream_t s);
+void launch_reduce_beta(const float* part_rr, const float* part_rz, int nb, int32_t ld, int32_t c0, int32_t c1,
+                        double* rz, float* beta, uint32_t* res_bits_slot, hipStream_t s);
+void launch_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols,
+                       hipStream_t s);
+void launch_axpby(float* out, const float* a, float ca, const float* b, float cb, int64_t n, hipStream_t s);
+
+}  // namespace osc

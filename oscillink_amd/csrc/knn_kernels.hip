@@ -1,0 +1,461 @@
+// Mutual-kNN lattice build on gfx950 (graph.py:8-93), never materialising the N x N similarity matrix.
+//
+//   k_normalize_rows : Yn = Y / (||Y_i|| + 1e-12)                      (graph.py:35)       HBM-bound, 1 pass
+//   k_knn_topk<E>    : S = Yn Yn^T in exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) tiles, LDS-staged,
+//                      fused with a register-resident running top-k per query row (graph.py:36-37, 59)
+//   k_knn_merge      : merges the per-column-split candidate lists into the final (sim desc, idx asc)
+//                      top-k (graph.py:46-49), clips at 0 (graph.py:62)
+//   k_mutual_ell     : mutual test + max-symmetrise (graph.py:64-65) -> ELL rows with ascending columns
+//   k_row_scale / k_apply_cap / k_sqrt_deg / k_normalize_w : row_sum_cap + normalized_laplacian (graph.py:69-93)
+//
+// MFMA tiling (wave64): a block = 4 waves owns 128 query rows; wave w computes rows 32w..32w+31 against a
+// 128-column tile as four 32x32 accumulators (64 acc VGPRs).  With D[i][j] = sum_k A[i][k] B[k][j] and
+// B[k][j] = Yn[col j][k], both operands are "row of Yn, element k": lane l supplies element k = l>>5 of row
+// l&31.  The 32-deep K tile sits in LDS as [128 rows][36 floats] (pad 4 -> ds_read_b128 conflict-free);
+// lane half h reads k = 8s+4h..8s+4h+3 with one ds_read_b128 and feeds component u to MFMA (s,u), so each
+// MFMA pairs k = 8s+u with k = 8s+4+u.  The summation order is the same for S_ij and S_ji, hence the
+// similarity matrix is bitwise symmetric, as the mutual test needs.
+//
+// Running top-k: after the 32x32x2 MFMA chain lane l holds column (l&31) of rows (g&3)+8(g>>2)+4(l>>5),
+// g = 0..15.  So one query row lives in one register across the 32 lanes of a half-wave; its candidate list
+// lives the same way (E entries per lane, capacity 32E >= k).  A (t,g) slice is compared against the row's
+// threshold with one v_cmp + ballot; only on a hit does the half-wave run the exact (value desc, index asc)
+// replace-worst step.  Expected hits per row are O(k log(N/k)), so the MFMA pipe stays the bound.
+#include "common.hpp"
+#include "knn.hpp"
+
+namespace osc {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr float NEG = -3.0e38f;
+constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// a is a worse list entry than b  <=>  smaller similarity, or equal similarity and larger index
+__device__ __forceinline__ bool worse(float av, int ai, float bv, int bi) { return av < bv || (av == bv && ai > bi); }
+
+__global__ __launch_bounds__(256) void k_normalize_rows(const float* Y, int32_t ldy, float* Yn, int32_t ldn, int64_t N,
+                                                        int32_t D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* y = Y + row * ldy;
+  float ss = 0.f;
+  for (int c = lane; c < D; c += 64) ss = fmaf(y[c], y[c], ss);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float inv = 1.f / (sqrtf(ss) + 1e-12f);
+  float* yn = Yn + row * ldn;
+  for (int c = lane; c < ldn; c += 64) yn[c] = c < D ? y[c] * inv : 0.f;
+}
+
+// out[i] = <Yn_i, q>  (cosine to a pre-normalised query; diffusion.py:104-107)
+__global__ __launch_bounds__(256) void k_rows_dot(const float* Yn, int32_t ldn, const float* q, float* out, int64_t N,
+                                                  int32_t D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* y = Yn + row * ldn;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s = fmaf(y[c], q[c], s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[row] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// work item = (row block of 128, column split s of S).  cand_*: [N][S][32E]
+template <int E>
+__device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k, int32_t S,
+                                              int32_t cols_per_split, float* cand_val, int32_t* cand_idx) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * BM * LDT];
+  float* As = lds;
+  float* Bs = lds + BM * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int rblk = blockIdx.x / S, split = blockIdx.x % S;
+  const int row0 = rblk * BM;
+  const int cbeg = split * cols_per_split;
+  const int cend = min(N, cbeg + cols_per_split);
+  const int nkt = ldn / BK;
+
+  // candidate lists: row R(g,h) of this wave lives in lv[g][*] across the 32 lanes of half h
+  float lv[16][E];
+  int li[16][E];
+  float thr[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    thr[g] = NEG;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const bool live = (l31 + 32 * e) < k;
+      lv[g][e] = live ? NEG : 3.0e38f;  // dead slots can never be the worst entry
+      li[g][e] = 0x7fffffff;
+    }
+  }
+
+  // staging: 128 rows x 32 floats per operand tile = 1024 float4; thread owns 4 of each
+  int srow[4], sc4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = tid + 256 * q;
+    srow[q] = f >> 3;
+    sc4[q] = (f & 7) * 4;
+  }
+  const float* a_ptr[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a_ptr[q] = Yn + (size_t)min(row0 + srow[q], N - 1) * ldn + sc4[q];
+
+  const int wrow_base = row0 + 32 * wave;  // global row of this wave's local row 0
+
+  for (int ct = cbeg; ct < cend; ct += BN) {
+    const float* b_ptr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b_ptr[q] = Yn + (size_t)min(ct + srow[q], N - 1) * ldn + sc4[q];
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+
+    float4 ra[4], rb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ra[q] = ld4(a_ptr[q]);
+      rb[q] = ld4(b_ptr[q]);
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+      __syncthreads();  // previous tile fully consumed
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<float4*>(As + srow[q] * LDT + sc4[q]) = ra[q];
+        *reinterpret_cast<float4*>(Bs + srow[q] * LDT + sc4[q]) = rb[q];
+      }
+      __syncthreads();
+      if (kt + 1 < nkt) {  // issue next tile's global loads; they land under the MFMAs below
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ra[q] = ld4(a_ptr[q] + (kt + 1) * BK);
+          rb[q] = ld4(b_ptr[q] + (kt + 1) * BK);
+        }
+      }
+      const float* ap = As + (32 * wave + l31) * LDT + 4 * h;
+      const float* bp = Bs + l31 * LDT + 4 * h;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4 av = ld4(ap + 8 * s);
+        float4 bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t] = ld4(bp + 32 * t * LDT + 8 * s);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[t].y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- running top-k update for this 32 x 128 slice -------------------------------------
+    const bool need_mask = (ct + BN > cend) || (ct < wrow_base + 32 && ct + BN > wrow_base);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int grow = wrow_base + (g & 3) + 8 * (g >> 2) + 4 * h;  // global query row of this half
+      bool touched = false;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float c = acc[t][g];
+        const int ccol = ct + 32 * t + l31;
+        if (need_mask && (ccol >= cend || ccol == grow)) c = NEG;  // graph.py:37 (diag = -inf) and the ragged tail
+        bool pred = (c >= thr[g]) && (c > NEG);
+        unsigned long long m = __ballot(pred);
+        while (m) {
+          touched = true;
+          const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
+          const bool has = mh != 0u;
+          const int srcl = has ? (__ffs(mh) - 1) : 0;
+          const float cv = __shfl(c, srcl + 32 * h, 64);
+          const int cc = ct + 32 * t + srcl;
+          // worst entry of this half's list for row g
+          float wv = lv[g][0];
+          int wi = li[g][0];
+#pragma unroll
+          for (int e = 1; e < E; ++e)
+            if (worse(lv[g][e], li[g][e], wv, wi)) {
+              wv = lv[g][e];
+              wi = li[g][e];
+            }
+          int wl = lane;
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) {
+            const float ov = __shfl_xor(wv, o, 64);
+            const int oi = __shfl_xor(wi, o, 64);
+            const int ol = __shfl_xor(wl, o, 64);
+            if (worse(ov, oi, wv, wi) || (ov == wv && oi == wi && ol < wl)) {
+              wv = ov;
+              wi = oi;
+              wl = ol;
+            }
+          }
+          const bool repl = has && (cv > wv || (cv == wv && cc < wi));
+          if (repl && lane == wl) {
+            bool done = false;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              if (!done && lv[g][e] == wv && li[g][e] == wi) {
+                lv[g][e] = cv;
+                li[g][e] = cc;
+                done = true;
+              }
+            }
+          }
+          if (has && l31 == srcl) pred = false;
+          m = __ballot(pred);
+        }
+      }
+      if (touched) {  // refresh the filter threshold = current worst similarity (NEG while the list is not full)
+        float wv = lv[g][0];
+#pragma unroll
+        for (int e = 1; e < E; ++e) wv = fminf(wv, lv[g][e]);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) wv = fminf(wv, __shfl_xor(wv, o, 64));
+        thr[g] = wv;
+      }
+    }
+  }
+
+  // ---- write this item's candidate lists ---------------------------------------------------
+  constexpr int KC = 32 * E;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int grow = wrow_base + (g & 3) + 8 * (g >> 2) + 4 * h;
+    if (grow < N) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const size_t o = ((size_t)grow * S + split) * KC + l31 + 32 * e;
+        cand_val[o] = lv[g][e];
+        cand_idx[o] = li[g][e];
+      }
+    }
+  }
+}
+
+template <int E>
+__global__ __launch_bounds__(256, 2) void k_knn_topk(const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k,
+                                                     int32_t S, int32_t cols_per_split, float* cand_val,
+                                                     int32_t* cand_idx) {
+  knn_topk_body<E>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx);
+}
+// k in (64, 128]: 128 list registers per lane -> one wave per SIMD with the whole 512-entry register file
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_knn_topk_wide(
+    const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k, int32_t S, int32_t cols_per_split, float* cand_val,
+    int32_t* cand_idx) {
+  knn_topk_body<4>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx);
+}
+
+// one wave per row: rank-select the k best of the S*KC candidates -> sorted (sim desc, idx asc), clipped at 0
+__global__ __launch_bounds__(256) void k_knn_merge(const float* cand_val, const int32_t* cand_idx, int32_t ncand,
+                                                   int32_t N, int32_t k, float* out_val, int32_t* out_idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* sv = reinterpret_cast<float*>(smem) + (size_t)wave * ncand;
+  int32_t* si = reinterpret_cast<int32_t*>(smem + (size_t)4 * ncand * sizeof(float)) + (size_t)wave * ncand;
+  const int row = blockIdx.x * 4 + wave;
+  if (row < N) {
+    for (int c = lane; c < ncand; c += 64) {
+      sv[c] = cand_val[(size_t)row * ncand + c];
+      si[c] = cand_idx[(size_t)row * ncand + c];
+    }
+  }
+  __syncthreads();
+  if (row >= N) return;
+  for (int c = lane; c < ncand; c += 64) {
+    const float v = sv[c];
+    const int i = si[c];
+    if (!(v > NEG && v < 3.0e38f)) continue;  // empty or dead slot
+    int rank = 0;
+    for (int d = 0; d < ncand; ++d) {
+      const float dv = sv[d];
+      const int di = si[d];
+      if (dv < 3.0e38f && (dv > v || (dv == v && di < i))) ++rank;
+    }
+    if (rank < k) {
+      out_val[(size_t)row * k + rank] = fmaxf(v, 0.f);  // graph.py:62
+      out_idx[(size_t)row * k + rank] = i;
+    }
+  }
+}
+
+// one wave per row: keep (i,j) iff j in topk(i), i in topk(j), both sims > 0; weight = max (graph.py:64-65)
+__global__ __launch_bounds__(256) void k_mutual_ell(const float* kval, const int32_t* kidx, int32_t N, int32_t k,
+                                                    int32_t width, int32_t* ell_col, float* ell_a, int32_t* deg) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  int total = 0;
+  // k <= 128: two passes of 64 entries; ranks computed against all kept entries of both passes
+  int jcol[2];
+  float jw[2];
+  bool keep[2];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int e = lane + 64 * ps;
+    keep[ps] = false;
+    jcol[ps] = 0x7fffffff;
+    jw[ps] = 0.f;
+    if (e < k) {
+      const int j = kidx[(size_t)row * k + e];
+      const float v = kval[(size_t)row * k + e];
+      if (v > 0.f && j >= 0 && j < N) {
+        float back = 0.f;
+        for (int q = 0; q < k; ++q)
+          if (kidx[(size_t)j * k + q] == row) back = kval[(size_t)j * k + q];
+        if (back > 0.f) {
+          keep[ps] = true;
+          jcol[ps] = j;
+          jw[ps] = fmaxf(v, back);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    int rank = 0;
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      for (int l = 0; l < 64; ++l) {
+        const int oc = __shfl(jcol[qs], l, 64);
+        rank += (oc < jcol[ps]) ? 1 : 0;
+      }
+    }
+    if (keep[ps]) {
+      ell_col[(size_t)row * width + rank] = jcol[ps];
+      ell_a[(size_t)row * width + rank] = jw[ps];
+    }
+    total += __popcll(__ballot(keep[ps]));
+  }
+  if (lane == 0) deg[row] = total;
+}
+
+// ---- row_sum_cap / normalized_laplacian on the ELL graph (thread per row; rows are <= a few hundred bytes) ----
+__global__ void k_row_scale(const float* ell_a, const int32_t* deg, int32_t width, int32_t N, float cap, float* scale) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  float s = 0.f;
+  for (int e = 0; e < deg[row]; ++e) s += ell_a[(size_t)row * width + e];
+  scale[row] = fminf(1.0f, cap / (s + 1e-12f));  // graph.py:77-78
+}
+__global__ void k_apply_cap(float* ell_a, const int32_t* ell_col, const int32_t* deg, int32_t width, int32_t N,
+                            const float* scale) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  const float si = scale[row];
+  for (int e = 0; e < deg[row]; ++e) {
+    const size_t o = (size_t)row * width + e;
+    const float a2 = ell_a[o] * sqrtf(si * scale[ell_col[o]]);  // graph.py:80-81
+    ell_a[o] = 0.5f * (a2 + a2);                                 // graph.py:83 (symmetric input: identity)
+  }
+}
+__global__ void k_sqrt_deg(const float* ell_a, const int32_t* deg, int32_t width, int32_t N, float* sqrt_deg) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  float d = 0.f;
+  for (int e = 0; e < deg[row]; ++e) d += ell_a[(size_t)row * width + e];
+  sqrt_deg[row] = sqrtf(fmaxf(d, 1e-12f));  // graph.py:87-88
+}
+__global__ void k_normalize_w(const float* ell_a, const int32_t* ell_col, const int32_t* deg, int32_t width, int32_t N,
+                              const float* sqrt_deg, float* ell_w) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  const float di = 1.0f / sqrt_deg[row];
+  for (int e = 0; e < deg[row]; ++e) {
+    const size_t o = (size_t)row * width + e;
+    ell_w[o] = (ell_a[o] * di) * (1.0f / sqrt_deg[ell_col[o]]);  // graph.py:89-90
+  }
+}
+
+}  // namespace
+
+// ---- launchers --------------------------------------------------------------------------------
+void launch_normalize_rows(const float* Y, int32_t ldy, float* Yn, int32_t ldn, int64_t N, int32_t D, hipStream_t s) {
+  hipLaunchKernelGGL(k_normalize_rows, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Y, ldy, Yn, ldn, N, D);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_rows_dot(const float* Yn, int32_t ldn, const float* q, float* out, int64_t N, int32_t D, hipStream_t s) {
+  hipLaunchKernelGGL(k_rows_dot, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Yn, ldn, q, out, N, D);
+  HIP_CHECK(hipGetLastError());
+}
+
+KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots) {
+  KnnPlan p;
+  p.E = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
+  p.KC = 32 * p.E;
+  p.row_blocks = (N + BM - 1) / BM;
+  const int col_tiles = (N + BN - 1) / BN;
+  // choose the column split count S: enough work items to balance `slots` resident blocks, while keeping
+  // the per-item list warm-up (k log) small.
+  int best_S = 1;
+  double best_cost = 1e300;
+  for (int S = 1; S <= std::min(col_tiles, 16); ++S) {
+    const int tiles_per = (col_tiles + S - 1) / S;
+    const int S_eff = (col_tiles + tiles_per - 1) / tiles_per;
+    if (S_eff != S) continue;
+    const long items = (long)p.row_blocks * S;
+    const long rounds = (items + slots - 1) / slots;
+    const double cost = (double)rounds * tiles_per * (1.0 + 0.012 * S);  // imbalance x (1 + warm-up overhead)
+    if (cost < best_cost) {
+      best_cost = cost;
+      best_S = S;
+    }
+  }
+  p.S = best_S;
+  p.cols_per_split = ((col_tiles + p.S - 1) / p.S) * BN;
+  return p;
+}
+
+void launch_knn_topk(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t N, int32_t k, float* cand_val,
+                     int32_t* cand_idx, hipStream_t s) {
+  const dim3 grid((unsigned)(p.row_blocks * p.S)), block(256);
+  if (p.E == 1)
+    hipLaunchKernelGGL(k_knn_topk<1>, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx);
+  else if (p.E == 2)
+    hipLaunchKernelGGL(k_knn_topk<2>, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx);
+  else
+    hipLaunchKernelGGL(k_knn_topk_wide, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* cand_idx, int32_t N, int32_t k,
+                      float* out_val, int32_t* out_idx, hipStream_t s) {
+  const int ncand = p.S * p.KC;
+  const size_t shmem = (size_t)4 * ncand * (sizeof(float) + sizeof(int32_t));
+  hipLaunchKernelGGL(k_knn_merge, dim3((unsigned)((N + 3) / 4)), dim3(256), shmem, s, cand_val, cand_idx, ncand, N, k,
+                     out_val, out_idx);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_mutual_ell(const float* kval, const int32_t* kidx, int32_t N, int32_t k, int32_t width, int32_t* ell_col,
+                       float* ell_a, int32_t* deg, hipStream_t s) {
+  hipLaunchKernelGGL(k_mutual_ell, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, kval, kidx, N, k, width, ell_col,
+                     ell_a, deg);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_cap_and_normalize(float* ell_a, float* ell_w, const int32_t* ell_col, const int32_t* deg, int32_t width,
+                              int32_t N, float cap, int apply_cap, float* scale_tmp, float* sqrt_deg, hipStream_t s) {
+  const dim3 grid((unsigned)((N + 255) / 256)), block(256);
+  if (apply_cap) {
+    hipLaunchKernelGGL(k_row_scale, grid, block, 0, s, ell_a, deg, width, N, cap, scale_tmp);
+    hipLaunchKernelGGL(k_apply_cap, grid, block, 0, s, ell_a, ell_col, deg, width, N, scale_tmp);
+  }
+  hipLaunchKernelGGL(k_sqrt_deg, grid, block, 0, s, ell_a, deg, width, N, sqrt_deg);
+  hipLaunchKernelGGL(k_normalize_w, grid, block, 0, s, ell_a, ell_col, deg, width, N, sqrt_deg, ell_w);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace osc

@@ -1,0 +1,1055 @@
+// C ABI of liboscillink_hip.so (include/oscillink_hip.h): handle management, lattice build orchestration,
+// the CG driver and receipts.  All device work of a handle goes to the handle's own HIP stream.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "../../include/oscillink_hip.h"
+#include "common.hpp"
+#include "knn.hpp"
+#include "receipts.hpp"
+
+using namespace osc;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ProfSlot {
+  hipEvent_t a, b;
+  int which;
+};
+
+struct Invalid : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct StateError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct Unsupported : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct CommError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct osc_lattice {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t N = 0;
+  int32_t D = 0, ld = 0;
+  // state (N x ld, row-major)
+  DevBuf<float> Y, U, X, R, P, AP, Ustar;
+  bool have_ustar = false;
+  DevBuf<float> B, psi;
+  float lamG = 1.0f, lamC = 0.5f, lamQ = 4.0f;
+  // graph (ELL)
+  int32_t k_eff = 0;
+  float row_cap = 1.0f;
+  int deterministic = 0;
+  int64_t seed = -1;
+  bool have_graph = false;
+  int32_t width = 0;
+  DevBuf<int32_t> ell_col, deg;
+  DevBuf<float> ell_a, ell_w, sqrt_deg;
+  DevBuf<float> knn_val;
+  DevBuf<int32_t> knn_idx;
+  int32_t knn_k = 0;
+  double build_ms = 0.0;
+  int64_t nnz = 0;
+  int32_t max_deg = 0;
+  // chain prior
+  bool chain_present = false;
+  float lamP = 0.0f;
+  int32_t prows = 0, pwidth = 0;
+  DevBuf<int32_t> path_slot, pcol, pdeg;
+  DevBuf<float> pw;
+  // CG scratch
+  int grid_cap = 1024;
+  DevBuf<float> part0, part1, alpha, beta;
+  DevBuf<double> rz, colsum;
+  DevBuf<uint32_t> res_bits;
+  std::vector<float> history;
+  // column shard (multi-GPU, column-sharded CG); single GPU: [0, ld)
+  int32_t c0 = 0, c1 = 0;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  DevBuf<float> comm_buf;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfSlot> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  int64_t prof_count[4] = {0, 0, 0, 0};
+  double prof_ms[4] = {0, 0, 0, 0};
+  std::string err;
+
+  ~osc_lattice() {
+    for (auto& s : prof_pending) {
+      (void)hipEventDestroy(s.a);
+      (void)hipEventDestroy(s.b);
+    }
+    for (auto e : prof_pool) (void)hipEventDestroy(e);
+    if (comm) (void)ncclCommDestroy(comm);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+using L = osc_lattice;
+
+hipEvent_t prof_event(L& h) {
+  if (!h.prof_pool.empty()) {
+    hipEvent_t e = h.prof_pool.back();
+    h.prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
+void prof_drain(L& h) {
+  for (auto& s : h.prof_pending) {
+    HIP_CHECK(hipEventSynchronize(s.b));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));
+    h.prof_count[s.which] += 1;
+    h.prof_ms[s.which] += ms;
+    h.prof_pool.push_back(s.a);
+    h.prof_pool.push_back(s.b);
+  }
+  h.prof_pending.clear();
+}
+struct ProfScope {
+  L& h;
+  ProfSlot s{};
+  bool on;
+  ProfScope(L& h_, int which) : h(h_), on(h_.prof_on) {
+    if (on) {
+      s.which = which;
+      s.a = prof_event(h);
+      s.b = prof_event(h);
+      HIP_CHECK(hipEventRecord(s.a, h.stream));
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      (void)hipEventRecord(s.b, h.stream);
+      h.prof_pending.push_back(s);
+      if (h.prof_pending.size() > 8192) prof_drain(h);
+    }
+  }
+};
+
+void use_device(L& h) { HIP_CHECK(hipSetDevice(h.device)); }
+void sync(L& h) { HIP_CHECK(hipStreamSynchronize(h.stream)); }
+
+void upload_rows(L& h, float* dst, const float* src) {  // N x D host -> N x ld device
+  HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)h.ld * 4, src, (size_t)h.D * 4, (size_t)h.D * 4, (size_t)h.N,
+                             hipMemcpyHostToDevice, h.stream));
+}
+void download_rows(L& h, float* dst, const float* src) {
+  HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)h.D * 4, src, (size_t)h.ld * 4, (size_t)h.D * 4, (size_t)h.N,
+                             hipMemcpyDeviceToHost, h.stream));
+}
+
+void ensure_cg_scratch(L& h, int max_iters) {
+  const size_t pn = (size_t)h.grid_cap * h.ld;
+  h.part0.alloc(pn);
+  h.part1.alloc(pn);
+  h.alpha.alloc(h.ld);
+  h.beta.alloc(h.ld);
+  h.rz.alloc(h.ld);
+  h.colsum.alloc(h.ld);
+  if (h.res_bits.n < (size_t)max_iters + 2) h.res_bits.alloc((size_t)max_iters + 2);
+}
+
+GraphView graph_view(L& h, bool with_path) {
+  GraphView g{};
+  g.col = h.ell_col.p;
+  g.w = h.ell_w.p;
+  g.deg = h.deg.p;
+  g.width = h.width;
+  if (with_path) {
+    g.path_slot = h.path_slot.p;
+    g.pcol = h.pcol.p;
+    g.pw = h.pw.p;
+    g.pdeg = h.pdeg.p;
+    g.pwidth = h.pwidth;
+  }
+  return g;
+}
+
+// ---- graph build --------------------------------------------------------------------------------
+void graph_counts(L& h) {
+  std::vector<int32_t> d((size_t)h.N);
+  HIP_CHECK(hipMemcpyAsync(d.data(), h.deg.p, (size_t)h.N * 4, hipMemcpyDeviceToHost, h.stream));
+  sync(h);
+  int64_t nnz = 0;
+  int32_t mx = 0;
+  for (auto v : d) {
+    nnz += v;
+    mx = std::max(mx, v);
+  }
+  h.nnz = nnz;
+  h.max_deg = mx;
+}
+
+void alloc_ell(L& h, int32_t width) {
+  h.width = std::max<int32_t>(1, width);
+  const size_t n = (size_t)h.N * h.width;
+  h.ell_col.alloc(n);
+  h.ell_a.alloc(n);
+  h.ell_w.alloc(n);
+  h.deg.alloc((size_t)h.N);
+  h.sqrt_deg.alloc((size_t)h.N);
+  HIP_CHECK(hipMemsetAsync(h.ell_col.p, 0, n * 4, h.stream));
+  HIP_CHECK(hipMemsetAsync(h.ell_a.p, 0, n * 4, h.stream));
+  HIP_CHECK(hipMemsetAsync(h.ell_w.p, 0, n * 4, h.stream));
+  HIP_CHECK(hipMemsetAsync(h.deg.p, 0, (size_t)h.N * 4, h.stream));
+}
+
+void build_graph(L& h) {
+  const double t0 = now_ms();
+  const int32_t N = (int32_t)h.N;
+  h.k_eff = std::min<int32_t>(h.k_eff, std::max<int32_t>(1, N - 1));  // lattice.py:60
+  h.have_ustar = false;
+  if (N <= 1) {  // graph.py:30-32
+    alloc_ell(h, 1);
+    const float one_em6 = 1e-6f;  // sqrt(max(0, 1e-12))
+    std::vector<float> sd((size_t)h.N, one_em6);
+    HIP_CHECK(hipMemcpyAsync(h.sqrt_deg.p, sd.data(), sd.size() * 4, hipMemcpyHostToDevice, h.stream));
+    sync(h);
+    h.knn_k = 0;
+    h.have_graph = true;
+    h.nnz = 0;
+    h.max_deg = 0;
+    h.build_ms = now_ms() - t0;
+    return;
+  }
+  const int32_t k = h.k_eff;
+  if (k > 128) throw Unsupported("kneighbors > 128 is not supported by the device kNN build");
+  const int32_t ldn = ((h.D + 31) / 32) * 32;
+  DevBuf<float> Yn;
+  Yn.alloc((size_t)h.N * ldn);
+  launch_normalize_rows(h.Y.p, h.ld, Yn.p, ldn, h.N, h.D, h.stream);
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, h.device));
+  const int slots = prop.multiProcessorCount * (k <= 64 ? 2 : 1);
+  const KnnPlan plan = knn_plan(N, k, slots);
+  DevBuf<float> cand_val;
+  DevBuf<int32_t> cand_idx;
+  const size_t ncand = (size_t)h.N * plan.S * plan.KC;
+  cand_val.alloc(ncand);
+  cand_idx.alloc(ncand);
+  {
+    ProfScope ps(h, 3);
+    launch_knn_topk(plan, Yn.p, ldn, N, k, cand_val.p, cand_idx.p, h.stream);
+  }
+  h.knn_val.alloc((size_t)h.N * k);
+  h.knn_idx.alloc((size_t)h.N * k);
+  h.knn_k = k;
+  HIP_CHECK(hipMemsetAsync(h.knn_val.p, 0, (size_t)h.N * k * 4, h.stream));
+  HIP_CHECK(hipMemsetAsync(h.knn_idx.p, 0xFF, (size_t)h.N * k * 4, h.stream));
+  launch_knn_merge(plan, cand_val.p, cand_idx.p, N, k, h.knn_val.p, h.knn_idx.p, h.stream);
+  alloc_ell(h, k);
+  launch_mutual_ell(h.knn_val.p, h.knn_idx.p, N, k, h.width, h.ell_col.p, h.ell_a.p, h.deg.p, h.stream);
+  DevBuf<float> scale;
+  scale.alloc((size_t)h.N);
+  launch_cap_and_normalize(h.ell_a.p, h.ell_w.p, h.ell_col.p, h.deg.p, h.width, N, h.row_cap, 1, scale.p,
+                           h.sqrt_deg.p, h.stream);
+  graph_counts(h);  // synchronises
+  h.have_graph = true;
+  h.build_ms = now_ms() - t0;
+}
+
+// ---- operators ------------------------------------------------------------------------------------
+bool path_active(const L& h) { return h.chain_present && h.lamP > 0.0f; }
+
+OpParams settle_op(const L& h, float dt, int precond) {
+  OpParams o{};
+  const float lp_op = path_active(h) ? h.lamP : 0.0f;
+  o.cs_const = 1.0f + dt * (h.lamG + h.lamC + lp_op);  // X + dt (lamG X + lamC (X - W X) + lamP (X - Wp X))
+  o.cs_B = dt * h.lamQ;
+  o.cW = dt * h.lamC;
+  o.cP = dt * lp_op;
+  o.md_const = 1.0f + dt * (h.lamG + (h.chain_present ? h.lamP : 0.0f));  // lattice.py:187-192
+  o.md_B = dt * h.lamQ;
+  o.precond = precond;
+  o.rbU = 1.0f;
+  o.rbY = dt * h.lamG;
+  o.rbB = dt * h.lamQ;
+  return o;
+}
+OpParams ustar_op(const L& h) {
+  OpParams o{};
+  const float lp_op = path_active(h) ? h.lamP : 0.0f;
+  o.cs_const = h.lamG + h.lamC + lp_op;
+  o.cs_B = h.lamQ;
+  o.cW = h.lamC;
+  o.cP = lp_op;
+  o.md_const = h.lamG + (h.chain_present ? h.lamP : 0.0f);  // lattice.py:257-259
+  o.md_B = h.lamQ;
+  o.precond = 1;
+  o.rbU = 0.0f;
+  o.rbY = h.lamG;
+  o.rbB = h.lamQ;
+  return o;
+}
+
+struct CgBuffers {  // the arrays one solve works on (all N x ld)
+  const float* x0;  // gathered in INIT
+  float* X;
+  float* R;
+  float* P;
+  float* AP;
+  const float* rhsU;
+  const float* rhsY;
+  const float* B;
+  const float* psi;
+  int32_t ld, c0, c1;
+};
+
+struct CgResult {
+  int iters;
+  float res;
+};
+
+// cg_solve (solver.py:6-37) on the device; returns after the stream is idle
+CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol) {
+  const int grid = std::min(h.grid_cap, spmm_grid(h.N, b.c1 - b.c0));
+  HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, ((size_t)max_iters + 2) * 4, h.stream));
+  SpmmArgs sa{};
+  sa.g = graph_view(h, with_path);
+  sa.op = op;
+  sa.B = b.B;
+  sa.psi = b.psi;
+  sa.N = h.N;
+  sa.ld = b.ld;
+  sa.c0 = b.c0;
+  sa.c1 = b.c1;
+  sa.part = h.part0.p;
+  // r = b - A x0 ; z ; p ; rz
+  sa.X = b.x0;
+  sa.OUT = b.X;
+  sa.R = b.R;
+  sa.P = b.P;
+  sa.U = b.rhsU;
+  sa.Y = b.rhsY;
+  {
+    ProfScope ps(h, 0);
+    launch_spmm(SPMM_INIT, sa, grid, h.stream);
+  }
+  launch_reduce_init(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.stream);
+  UpdateArgs ua{};
+  ua.X = b.X;
+  ua.R = b.R;
+  ua.P = b.P;
+  ua.AP = b.AP;
+  ua.B = b.B;
+  ua.alpha = h.alpha.p;
+  ua.beta = h.beta.p;
+  ua.part_rr = h.part0.p;
+  ua.part_rz = h.part1.p;
+  ua.op = op;
+  ua.N = h.N;
+  ua.ld = b.ld;
+  ua.c0 = b.c0;
+  ua.c1 = b.c1;
+  sa.X = b.P;
+  sa.OUT = b.AP;
+  h.history.clear();
+  CgResult out{max_iters, 0.f};
+  for (int it = 1; it <= max_iters; ++it) {
+    {
+      ProfScope ps(h, 0);
+      launch_spmm(SPMM_AP, sa, grid, h.stream);  // Ap and column sums of p.Ap
+    }
+    launch_reduce_alpha(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, h.stream);
+    {
+      ProfScope ps(h, 1);
+      launch_update_xr(ua, grid, h.stream);
+    }
+    launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, h.stream);
+    float res = 0.f;
+    if (h.comm) {  // column-sharded: the stop test is the max over all shards (solver.py:29)
+      if (ncclAllReduce(h.res_bits.p + it, h.res_bits.p + it, 1, ncclFloat, ncclMax, h.comm, h.stream) != ncclSuccess)
+        throw CommError("ncclAllReduce(max residual) failed");
+    }
+    HIP_CHECK(hipMemcpyAsync(&res, h.res_bits.p + it, 4, hipMemcpyDeviceToHost, h.stream));
+    sync(h);
+    h.history.push_back(res);
+    out.res = res;
+    if ((double)res <= (double)tol) {
+      out.iters = it;
+      break;
+    }
+    if (it < max_iters) {
+      ProfScope ps(h, 2);
+      launch_update_p(ua, grid, h.stream);
+    }
+  }
+  sync(h);
+  return out;
+}
+
+void require_graph(L& h) {
+  if (!h.have_graph) throw StateError("no lattice graph: build it (osc_create build_graph=1) or inject one (osc_set_csr)");
+}
+
+template <typename F>
+int guarded(osc_handle h, F&& f) {
+  if (!h) return OSC_E_INVALID;
+  try {
+    use_device(*h);
+    f(*h);
+    return OSC_OK;
+  } catch (const Invalid& e) {
+    h->err = e.what();
+    return OSC_E_INVALID;
+  } catch (const StateError& e) {
+    h->err = e.what();
+    return OSC_E_STATE;
+  } catch (const Unsupported& e) {
+    h->err = e.what();
+    return OSC_E_UNSUPPORTED;
+  } catch (const CommError& e) {
+    h->err = e.what();
+    return OSC_E_COMM;
+  } catch (const HipError& e) {
+    h->err = e.what();
+    return OSC_E_HIP;
+  } catch (const std::exception& e) {
+    h->err = e.what();
+    return OSC_E_HIP;
+  }
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* osc_version(void) { return "oscillink-hip 0.1.0 (gfx950)"; }
+
+int osc_device_count(int32_t* n) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  if (n) *n = c;
+  return OSC_OK;
+}
+
+int osc_device_name(int32_t device, char* out, int32_t cap) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return OSC_E_NODEVICE;
+  snprintf(out, (size_t)cap, "%s|%s|CUs=%d", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return OSC_OK;
+}
+
+int osc_device_synchronize(int32_t device) {
+  if (hipSetDevice(device) != hipSuccess) return OSC_E_NODEVICE;
+  return hipDeviceSynchronize() == hipSuccess ? OSC_OK : OSC_E_HIP;
+}
+
+const char* osc_last_error(osc_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, int32_t deterministic, int64_t seed,
+               int32_t device, int32_t build, osc_handle* out) {
+  if (!out) return OSC_E_INVALID;
+  *out = nullptr;
+  if (!Y || N < 1 || D < 1 || k < 1 || N >= (int64_t)1 << 31) {
+    g_create_error = "osc_create: need Y != NULL, 1 <= N < 2^31, D >= 1, k >= 1";
+    return OSC_E_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) {
+    g_create_error = "osc_create: no usable HIP device (this library has no CPU fallback)";
+    return OSC_E_NODEVICE;
+  }
+  std::unique_ptr<osc_lattice> h(new osc_lattice());
+  try {
+    h->device = device;
+    HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+      g_create_error = std::string("osc_create: device is ") + prop.gcnArchName + ", this build targets gfx950 only";
+      return OSC_E_NODEVICE;
+    }
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->N = N;
+    h->D = D;
+    h->ld = ((D + 3) / 4) * 4;
+    h->c0 = 0;
+    h->c1 = h->ld;
+    h->k_eff = (int32_t)std::min<int64_t>(k, std::max<int64_t>(1, N - 1));
+    h->row_cap = row_cap;
+    h->deterministic = deterministic;
+    h->seed = seed;
+    const size_t n = (size_t)N * h->ld;
+    for (DevBuf<float>* b : {&h->Y, &h->U, &h->X, &h->R, &h->P, &h->AP, &h->Ustar}) b->alloc(n);
+    HIP_CHECK(hipMemsetAsync(h->Y.p, 0, n * 4, h->stream));
+    upload_rows(*h, h->Y.p, Y);
+    HIP_CHECK(hipMemcpyAsync(h->U.p, h->Y.p, n * 4, hipMemcpyDeviceToDevice, h->stream));
+    for (DevBuf<float>* b : {&h->X, &h->R, &h->P, &h->AP, &h->Ustar}) HIP_CHECK(hipMemsetAsync(b->p, 0, n * 4, h->stream));
+    h->B.alloc((size_t)N);
+    std::vector<float> ones((size_t)N, 1.0f);
+    HIP_CHECK(hipMemcpyAsync(h->B.p, ones.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+    h->psi.alloc((size_t)h->ld);
+    HIP_CHECK(hipMemsetAsync(h->psi.p, 0, (size_t)h->ld * 4, h->stream));
+    sync(*h);
+    if (build) build_graph(*h);
+  } catch (const Unsupported& e) {
+    g_create_error = e.what();
+    return OSC_E_UNSUPPORTED;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    return OSC_E_HIP;
+  }
+  *out = h.release();
+  return OSC_OK;
+}
+
+int osc_destroy(osc_handle h) {
+  if (!h) return OSC_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  delete h;
+  return OSC_OK;
+}
+
+int osc_rebuild_graph(osc_handle h, int32_t k, float row_cap, int32_t deterministic, int64_t seed) {
+  return guarded(h, [&](L& l) {
+    if (k < 1) throw Invalid("kneighbors must be >= 1");
+    l.k_eff = (int32_t)std::min<int64_t>(k, std::max<int64_t>(1, l.N - 1));
+    l.row_cap = row_cap;
+    l.deterministic = deterministic;
+    l.seed = seed;
+    build_graph(l);
+  });
+}
+
+int osc_graph_stats(osc_handle h, int64_t* nnz, int32_t* max_deg, double* build_ms) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (nnz) *nnz = l.nnz;
+    if (max_deg) *max_deg = l.max_deg;
+    if (build_ms) *build_ms = l.build_ms;
+  });
+}
+
+int osc_get_csr(osc_handle h, int64_t* rowptr, int32_t* col, float* a, float* w, float* sqrt_deg) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    const size_t n = (size_t)l.N * l.width;
+    std::vector<int32_t> hc(n), hd((size_t)l.N);
+    std::vector<float> ha(n), hw(n);
+    HIP_CHECK(hipMemcpyAsync(hc.data(), l.ell_col.p, n * 4, hipMemcpyDeviceToHost, l.stream));
+    HIP_CHECK(hipMemcpyAsync(ha.data(), l.ell_a.p, n * 4, hipMemcpyDeviceToHost, l.stream));
+    HIP_CHECK(hipMemcpyAsync(hw.data(), l.ell_w.p, n * 4, hipMemcpyDeviceToHost, l.stream));
+    HIP_CHECK(hipMemcpyAsync(hd.data(), l.deg.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    if (sqrt_deg) HIP_CHECK(hipMemcpyAsync(sqrt_deg, l.sqrt_deg.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+    int64_t pos = 0;
+    for (int64_t i = 0; i < l.N; ++i) {
+      if (rowptr) rowptr[i] = pos;
+      for (int e = 0; e < hd[(size_t)i]; ++e) {
+        const size_t o = (size_t)i * l.width + e;
+        if (col) col[pos] = hc[o];
+        if (a) a[pos] = ha[o];
+        if (w) w[pos] = hw[o];
+        ++pos;
+      }
+    }
+    if (rowptr) rowptr[l.N] = pos;
+  });
+}
+
+int osc_set_csr(osc_handle h, const int64_t* rowptr, const int32_t* col, const float* a) {
+  return guarded(h, [&](L& l) {
+    if (!rowptr || rowptr[0] != 0) throw Invalid("osc_set_csr: rowptr[0] must be 0");
+    int64_t width = 1;
+    for (int64_t i = 0; i < l.N; ++i) {
+      if (rowptr[i + 1] < rowptr[i]) throw Invalid("osc_set_csr: rowptr must be non-decreasing");
+      width = std::max(width, rowptr[i + 1] - rowptr[i]);
+    }
+    const int64_t nnz = rowptr[l.N];
+    if (nnz > 0 && (!col || !a)) throw Invalid("osc_set_csr: col / a missing");
+    alloc_ell(l, (int32_t)width);
+    const size_t n = (size_t)l.N * l.width;
+    std::vector<int32_t> hc(n, 0), hd((size_t)l.N, 0);
+    std::vector<float> ha(n, 0.f);
+    for (int64_t i = 0; i < l.N; ++i) {
+      int cnt = 0;
+      for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+        if (col[p] < 0 || col[p] >= l.N) throw Invalid("osc_set_csr: column index out of range");
+        if (!(a[p] > 0.f)) continue;  // only strictly positive weights are edges (graph.py:64)
+        hc[(size_t)i * l.width + cnt] = col[p];
+        ha[(size_t)i * l.width + cnt] = a[p];
+        ++cnt;
+      }
+      hd[(size_t)i] = cnt;
+    }
+    HIP_CHECK(hipMemcpyAsync(l.ell_col.p, hc.data(), n * 4, hipMemcpyHostToDevice, l.stream));
+    HIP_CHECK(hipMemcpyAsync(l.ell_a.p, ha.data(), n * 4, hipMemcpyHostToDevice, l.stream));
+    HIP_CHECK(hipMemcpyAsync(l.deg.p, hd.data(), (size_t)l.N * 4, hipMemcpyHostToDevice, l.stream));
+    launch_cap_and_normalize(l.ell_a.p, l.ell_w.p, l.ell_col.p, l.deg.p, l.width, (int32_t)l.N, 0.f, 0, nullptr,
+                             l.sqrt_deg.p, l.stream);
+    graph_counts(l);
+    l.have_graph = true;
+    l.have_ustar = false;
+    l.knn_k = 0;
+  });
+}
+
+int osc_get_knn_lists(osc_handle h, int32_t* idx, float* val, int32_t* k_eff) {
+  return guarded(h, [&](L& l) {
+    if (k_eff) *k_eff = l.knn_k;
+    if (l.knn_k <= 0) return;
+    const size_t n = (size_t)l.N * l.knn_k;
+    if (idx) HIP_CHECK(hipMemcpyAsync(idx, l.knn_idx.p, n * 4, hipMemcpyDeviceToHost, l.stream));
+    if (val) HIP_CHECK(hipMemcpyAsync(val, l.knn_val.p, n * 4, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+  });
+}
+
+int osc_set_query(osc_handle h, const float* psi, const float* gates) {
+  return guarded(h, [&](L& l) {
+    if (psi) {
+      HIP_CHECK(hipMemsetAsync(l.psi.p, 0, (size_t)l.ld * 4, l.stream));
+      HIP_CHECK(hipMemcpyAsync(l.psi.p, psi, (size_t)l.D * 4, hipMemcpyHostToDevice, l.stream));
+    }
+    if (gates) HIP_CHECK(hipMemcpyAsync(l.B.p, gates, (size_t)l.N * 4, hipMemcpyHostToDevice, l.stream));
+    sync(l);
+    l.have_ustar = false;
+  });
+}
+
+int osc_set_chain(osc_handle h, const int32_t* chain, const float* weights, int32_t len, float lamP) {
+  return guarded(h, [&](L& l) {
+    if (lamP < 0) throw Invalid("lamP must be >= 0");
+    if (len < 2 || !chain) throw Invalid("chain must contain at least two indices");
+    for (int i = 0; i < len; ++i)
+      if (chain[i] < 0 || chain[i] >= l.N) throw Invalid("chain indices out of bounds");
+    // path adjacency, duplicate edges keep the max weight (graph.py:102-109)
+    std::map<std::pair<int32_t, int32_t>, float> adj;
+    for (int t = 0; t + 1 < len; ++t) {
+      const int32_t i = chain[t], j = chain[t + 1];
+      const float w = weights ? weights[t] : 1.0f;
+      auto put = [&](int32_t r, int32_t c) {
+        auto it = adj.find({r, c});
+        if (it == adj.end()) adj[{r, c}] = std::max(0.0f, w);
+        else it->second = std::max(it->second, w);
+      };
+      put(i, j);
+      put(j, i);
+    }
+    // normalized_laplacian(A_path) (graph.py:86-93): only rows that own an entry differ from identity
+    std::map<int32_t, float> dsum;
+    for (auto& kv : adj) dsum[kv.first.first] += kv.second;
+    std::map<int32_t, int32_t> slot;
+    for (auto& kv : dsum) slot.emplace(kv.first, (int32_t)slot.size());
+    std::map<int32_t, int32_t> cnt;
+    int32_t pwidth = 1;
+    for (auto& kv : adj) pwidth = std::max(pwidth, ++cnt[kv.first.first]);
+    const int32_t prows = (int32_t)slot.size();
+    std::vector<int32_t> hslot((size_t)l.N, -1), hcol((size_t)prows * pwidth, 0), hdeg((size_t)prows, 0);
+    std::vector<float> hw((size_t)prows * pwidth, 0.f);
+    auto sd = [&](int32_t r) {
+      auto it = dsum.find(r);
+      return std::sqrt(std::max(it == dsum.end() ? 0.0f : it->second, 1e-12f));
+    };
+    for (auto& kv : slot) hslot[(size_t)kv.first] = kv.second;
+    for (auto& kv : adj) {
+      const int32_t r = kv.first.first, c = kv.first.second, s = slot[r];
+      const int32_t e = hdeg[(size_t)s]++;
+      hcol[(size_t)s * pwidth + e] = c;
+      hw[(size_t)s * pwidth + e] = (kv.second * (1.0f / sd(r))) * (1.0f / sd(c));
+    }
+    l.path_slot.alloc((size_t)l.N);
+    l.pcol.alloc(hcol.size());
+    l.pw.alloc(hw.size());
+    l.pdeg.alloc(hdeg.size());
+    HIP_CHECK(hipMemcpyAsync(l.path_slot.p, hslot.data(), hslot.size() * 4, hipMemcpyHostToDevice, l.stream));
+    HIP_CHECK(hipMemcpyAsync(l.pcol.p, hcol.data(), hcol.size() * 4, hipMemcpyHostToDevice, l.stream));
+    HIP_CHECK(hipMemcpyAsync(l.pw.p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, l.stream));
+    HIP_CHECK(hipMemcpyAsync(l.pdeg.p, hdeg.data(), hdeg.size() * 4, hipMemcpyHostToDevice, l.stream));
+    sync(l);
+    l.prows = prows;
+    l.pwidth = pwidth;
+    l.chain_present = true;
+    l.lamP = lamP;
+    l.have_ustar = false;
+  });
+}
+
+int osc_clear_chain(osc_handle h) {
+  return guarded(h, [&](L& l) {
+    l.chain_present = false;
+    l.lamP = 0.0f;
+    l.have_ustar = false;
+  });
+}
+
+int osc_set_lams(osc_handle h, float lamG, float lamC, float lamQ) {
+  return guarded(h, [&](L& l) {
+    if (!(lamG > 0)) throw Invalid("lamG must be > 0 for SPD");
+    if (lamC < 0) throw Invalid("lamC must be >= 0");
+    if (lamQ < 0) throw Invalid("lamQ must be >= 0");
+    l.lamG = lamG;
+    l.lamC = lamC;
+    l.lamQ = lamQ;
+    l.have_ustar = false;
+  });
+}
+
+int osc_get_U(osc_handle h, float* out) {
+  return guarded(h, [&](L& l) {
+    if (!out) throw Invalid("osc_get_U: out is NULL");
+    download_rows(l, out, l.U.p);
+    sync(l);
+  });
+}
+
+int osc_set_U(osc_handle h, const float* U) {
+  return guarded(h, [&](L& l) {
+    if (U) upload_rows(l, l.U.p, U);
+    else HIP_CHECK(hipMemcpyAsync(l.U.p, l.Y.p, (size_t)l.N * l.ld * 4, hipMemcpyDeviceToDevice, l.stream));
+    sync(l);
+  });
+}
+
+int osc_settle(osc_handle h, float dt, int32_t max_iters, float tol, int32_t precond, int32_t warm_start, float inertia,
+               int32_t* iters, float* res, double* ms) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (max_iters < 1) throw Invalid("max_iters must be >= 1");
+    ensure_cg_scratch(l, max_iters);
+    const OpParams op = settle_op(l, dt, precond == OSC_PRECOND_JACOBI ? 1 : 0);
+    sync(l);
+    const double t0 = now_ms();
+    // x0 (lattice.py:751-758)
+    const float* x0 = l.U.p;
+    if (!warm_start) {
+      x0 = l.Y.p;
+    } else {
+      const float w = std::max(0.0f, std::min(1.0f, inertia));
+      if (w > 0.0f) {
+        launch_axpby(l.AP.p, l.Y.p, 1.0f - w, l.U.p, w, (int64_t)l.N * l.ld, l.stream);
+        x0 = l.AP.p;  // AP is free until the first operator apply overwrites it (INIT gathers x0 before that)
+      }
+    }
+    CgBuffers b{x0, l.X.p, l.R.p, l.P.p, l.AP.p, l.U.p, l.Y.p, l.B.p, l.psi.p, l.ld, l.c0, l.c1};
+    // when x0 aliases AP the INIT pass reads it completely before the first SPMM_AP launch writes AP: same stream
+    const CgResult r = run_cg(l, op, b, path_active(l), max_iters, tol);
+    l.U.swap(l.X);  // U <- U+ (lattice.py:206)
+    if (ms) *ms = now_ms() - t0;
+    if (iters) *iters = r.iters;
+    if (res) *res = r.res;
+  });
+}
+
+int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out, int32_t* iters, float* res,
+                    double* ms) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (max_iters < 1) throw Invalid("max_iters must be >= 1");
+    ensure_cg_scratch(l, max_iters);
+    const OpParams op = ustar_op(l);
+    sync(l);
+    const double t0 = now_ms();
+    CgBuffers b{l.Y.p, l.X.p, l.R.p, l.P.p, l.AP.p, l.U.p, l.Y.p, l.B.p, l.psi.p, l.ld, l.c0, l.c1};
+    const CgResult r = run_cg(l, op, b, path_active(l), max_iters, tol);
+    l.Ustar.swap(l.X);
+    l.have_ustar = true;
+    if (ms) *ms = now_ms() - t0;
+    if (iters) *iters = r.iters;
+    if (res) *res = r.res;
+    if (Ustar_out) {
+      download_rows(l, Ustar_out, l.Ustar.p);
+      sync(l);
+    }
+  });
+}
+
+int osc_residual_history(osc_handle h, float* out, int32_t cap, int32_t* n) {
+  return guarded(h, [&](L& l) {
+    const int32_t m = std::min<int32_t>(cap, (int32_t)l.history.size());
+    if (out)
+      for (int32_t i = 0; i < m; ++i) out[i] = l.history[(size_t)i];
+    if (n) *n = m;
+  });
+}
+
+int osc_cg_single_rhs(osc_handle h, float gamma, const float* s, float tol, int32_t max_iters, float* h_out,
+                      int32_t* iters, float* res) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (!(gamma > 0)) throw Invalid("gamma must be > 0 for SPD");
+    if (max_iters < 1) throw Invalid("max_iters must be >= 1");
+    if (!s || !h_out) throw Invalid("osc_cg_single_rhs: NULL buffer");
+    ensure_cg_scratch(l, max_iters);
+    // N x 1 problem stored with pitch 4 (columns 1..3 stay zero)
+    const int32_t ld1 = 4;
+    const size_t n = (size_t)l.N * ld1;
+    DevBuf<float> S, X0, X, R, P, AP, psi0;
+    for (DevBuf<float>* b : {&S, &X0, &X, &R, &P, &AP}) {
+      b->alloc(n);
+      HIP_CHECK(hipMemsetAsync(b->p, 0, n * 4, l.stream));
+    }
+    psi0.alloc(ld1);
+    HIP_CHECK(hipMemsetAsync(psi0.p, 0, ld1 * 4, l.stream));
+    HIP_CHECK(hipMemcpy2DAsync(S.p, ld1 * 4, s, 4, 4, (size_t)l.N, hipMemcpyHostToDevice, l.stream));
+    OpParams op{};
+    op.cs_const = 1.0f + gamma;  // (L_sym + gamma I) x = (1 + gamma) x - W x
+    op.cs_B = 0.f;
+    op.cW = 1.0f;
+    op.cP = 0.f;
+    op.md_const = 1.0f + gamma;  // diag(L_sym) + gamma (diffusion.py:138-139), diag(L_sym) = 1
+    op.md_B = 0.f;
+    op.precond = 1;
+    op.rbU = 0.f;
+    op.rbY = 1.0f;
+    op.rbB = 0.f;
+    CgBuffers b{X0.p, X.p, R.p, P.p, AP.p, S.p, S.p, l.B.p, psi0.p, ld1, 0, ld1};
+    // scratch sized for ld >= 4 already
+    ncclComm_t saved = l.comm;
+    l.comm = nullptr;  // the diffusion solve is replicated, not sharded
+    CgResult r;
+    try {
+      r = run_cg(l, op, b, false, max_iters, tol);
+    } catch (...) {
+      l.comm = saved;
+      throw;
+    }
+    l.comm = saved;
+    HIP_CHECK(hipMemcpy2DAsync(h_out, 4, X.p, ld1 * 4, 4, (size_t)l.N, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+    if (iters) *iters = r.iters;
+    if (res) *res = r.res;
+  });
+}
+
+int osc_cosine_to(osc_handle h, const float* psi, float* out) {
+  return guarded(h, [&](L& l) {
+    if (!psi || !out) throw Invalid("osc_cosine_to: NULL buffer");
+    const int32_t ldn = l.ld;
+    DevBuf<float> Yn, q, o;
+    Yn.alloc((size_t)l.N * ldn);
+    q.alloc((size_t)l.D);
+    o.alloc((size_t)l.N);
+    double nn = 0.0;
+    std::vector<float> qn((size_t)l.D);
+    float ss = 0.f;
+    for (int c = 0; c < l.D; ++c) ss += psi[c] * psi[c];
+    (void)nn;
+    const float inv = 1.0f / (std::sqrt(ss) + 1e-12f);
+    for (int c = 0; c < l.D; ++c) qn[(size_t)c] = psi[c] * inv;
+    HIP_CHECK(hipMemcpyAsync(q.p, qn.data(), (size_t)l.D * 4, hipMemcpyHostToDevice, l.stream));
+    launch_normalize_rows(l.Y.p, l.ld, Yn.p, ldn, l.N, l.D, l.stream);
+    launch_rows_dot(Yn.p, ldn, q.p, o.p, l.N, l.D, l.stream);
+    HIP_CHECK(hipMemcpyAsync(out, o.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+  });
+}
+
+int osc_deltaH(osc_handle h, double* dH) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (!l.have_ustar) throw StateError("osc_deltaH: no resident U* (call osc_solve_ustar first)");
+    if (!dH) throw Invalid("osc_deltaH: dH is NULL");
+    ensure_cg_scratch(l, 1);
+    // diff = U - U*  ;  deltaH = sum diff . M diff   (receipts.py:21-25)
+    launch_axpby(l.P.p, l.U.p, 1.0f, l.Ustar.p, -1.0f, (int64_t)l.N * l.ld, l.stream);
+    const int grid = std::min(l.grid_cap, spmm_grid(l.N, l.c1 - l.c0));
+    SpmmArgs sa{};
+    sa.g = graph_view(l, path_active(l));
+    sa.op = ustar_op(l);
+    sa.X = l.P.p;
+    sa.B = l.B.p;
+    sa.psi = l.psi.p;
+    sa.part = l.part0.p;
+    sa.N = l.N;
+    sa.ld = l.ld;
+    sa.c0 = l.c0;
+    sa.c1 = l.c1;
+    {
+      ProfScope ps(l, 0);
+      launch_spmm(SPMM_DOT, sa, grid, l.stream);
+    }
+    launch_reduce_sum(l.part0.p, grid, l.ld, l.c0, l.c1, l.colsum.p, l.stream);
+    std::vector<double> cs((size_t)l.ld, 0.0);
+    HIP_CHECK(hipMemcpyAsync(cs.data() + l.c0, l.colsum.p + l.c0, (size_t)(l.c1 - l.c0) * 8, hipMemcpyDeviceToHost,
+                             l.stream));
+    sync(l);
+    double tot = 0.0;
+    for (int c = l.c0; c < l.c1; ++c) tot += cs[(size_t)c];
+    if (l.comm) {
+      DevBuf<double> t;
+      t.alloc(1);
+      HIP_CHECK(hipMemcpyAsync(t.p, &tot, 8, hipMemcpyHostToDevice, l.stream));
+      if (ncclAllReduce(t.p, t.p, 1, ncclDouble, ncclSum, l.comm, l.stream) != ncclSuccess)
+        throw CommError("ncclAllReduce(deltaH) failed");
+      HIP_CHECK(hipMemcpyAsync(&tot, t.p, 8, hipMemcpyDeviceToHost, l.stream));
+      sync(l);
+    }
+    *dH = tot;
+  });
+}
+
+static void receipt_rows(L& l, float z_th, DevBuf<float>& coh, DevBuf<float>& an, DevBuf<float>& qu,
+                         DevBuf<int32_t>& nj, DevBuf<float>& nz, DevBuf<float>& nr, bool want_comp, bool want_null) {
+  ReceiptArgs a{};
+  a.Y = l.Y.p;
+  a.Ustar = l.Ustar.p;
+  a.psi = l.psi.p;
+  a.B = l.B.p;
+  a.sqrt_deg = l.sqrt_deg.p;
+  a.col = l.ell_col.p;
+  a.adj = l.ell_a.p;
+  a.deg = l.deg.p;
+  a.width = l.width;
+  a.lamG = l.lamG;
+  a.lamC = l.lamC;
+  a.lamQ = l.lamQ;
+  a.z_th = z_th;
+  a.N = (int32_t)l.N;
+  a.D = l.D;
+  a.ld = l.ld;
+  if (want_comp) {
+    coh.alloc((size_t)l.N);
+    an.alloc((size_t)l.N);
+    qu.alloc((size_t)l.N);
+    a.coh = coh.p;
+    a.anchor = an.p;
+    a.query = qu.p;
+  }
+  if (want_null) {
+    nj.alloc((size_t)l.N);
+    nz.alloc((size_t)l.N);
+    nr.alloc((size_t)l.N);
+    a.null_j = nj.p;
+    a.null_z = nz.p;
+    a.null_r = nr.p;
+  }
+  launch_receipt_rows(a, l.stream);
+}
+
+int osc_receipt_components(osc_handle h, float* coh, float* anchor, float* query) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (!l.have_ustar) throw StateError("osc_receipt_components: no resident U*");
+    DevBuf<float> c, a, q, nz, nr;
+    DevBuf<int32_t> nj;
+    receipt_rows(l, 3.0f, c, a, q, nj, nz, nr, true, false);
+    if (coh) HIP_CHECK(hipMemcpyAsync(coh, c.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    if (anchor) HIP_CHECK(hipMemcpyAsync(anchor, a.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    if (query) HIP_CHECK(hipMemcpyAsync(query, q.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+  });
+}
+
+int osc_null_points(osc_handle h, float z_th, int32_t* i_out, int32_t* j_out, float* z_out, float* r_out,
+                    int32_t* count) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (!l.have_ustar) throw StateError("osc_null_points: no resident U*");
+    if (!count) throw Invalid("osc_null_points: count is NULL");
+    DevBuf<float> c, a, q, nz, nr;
+    DevBuf<int32_t> nj;
+    receipt_rows(l, z_th, c, a, q, nj, nz, nr, false, true);
+    std::vector<int32_t> hj((size_t)l.N);
+    std::vector<float> hz((size_t)l.N), hr((size_t)l.N);
+    HIP_CHECK(hipMemcpyAsync(hj.data(), nj.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    HIP_CHECK(hipMemcpyAsync(hz.data(), nz.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    HIP_CHECK(hipMemcpyAsync(hr.data(), nr.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+    int32_t n = 0;
+    for (int64_t i = 0; i < l.N; ++i) {
+      if (hj[(size_t)i] < 0) continue;
+      if (i_out) i_out[n] = (int32_t)i;
+      if (j_out) j_out[n] = hj[(size_t)i];
+      if (z_out) z_out[n] = hz[(size_t)i];
+      if (r_out) r_out[n] = hr[(size_t)i];
+      ++n;
+    }
+    *count = n;
+  });
+}
+
+int osc_profile_enable(osc_handle h, int32_t on) {
+  return guarded(h, [&](L& l) {
+    if (!on) prof_drain(l);
+    l.prof_on = on != 0;
+  });
+}
+int osc_profile_reset(osc_handle h) {
+  return guarded(h, [&](L& l) {
+    prof_drain(l);
+    for (int i = 0; i < 4; ++i) {
+      l.prof_count[i] = 0;
+      l.prof_ms[i] = 0.0;
+    }
+  });
+}
+int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* total_ms) {
+  return guarded(h, [&](L& l) {
+    if (which < 0 || which > 3) throw Invalid("osc_profile_get: which must be 0..3");
+    prof_drain(l);
+    if (launches) *launches = l.prof_count[which];
+    if (total_ms) *total_ms = l.prof_ms[which];
+  });
+}
+
+int osc_comm_unique_id(char id_out[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return OSC_E_COMM;
+  std::memcpy(id_out, &id, 128);
+  return OSC_OK;
+}
+
+int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world) {
+  return guarded(h, [&](L& l) {
+    if (world < 1 || rank < 0 || rank >= world) throw Invalid("osc_comm_init: bad rank/world");
+    if (l.comm) {
+      (void)ncclCommDestroy(l.comm);
+      l.comm = nullptr;
+    }
+    l.rank = rank;
+    l.world = world;
+    // column slabs in units of 4 floats, as even as possible
+    const int32_t q = l.ld / 4;
+    const int32_t lo = (int32_t)((int64_t)q * rank / world), hi = (int32_t)((int64_t)q * (rank + 1) / world);
+    l.c0 = lo * 4;
+    l.c1 = hi * 4;
+    if (l.c1 <= l.c0) throw Invalid("osc_comm_init: more ranks than 4-column groups");
+    if (world > 1) {
+      ncclUniqueId uid;
+      std::memcpy(&uid, id, 128);
+      if (ncclCommInitRank(&l.comm, world, uid, rank) != ncclSuccess) throw CommError("ncclCommInitRank failed");
+    }
+    l.have_ustar = false;
+  });
+}
+
+int osc_comm_shard(osc_handle h, int32_t* c0, int32_t* c1) {
+  return guarded(h, [&](L& l) {
+    if (c0) *c0 = l.c0;
+    if (c1) *c1 = std::min(l.c1, l.D);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,853 @@
+"""`OscillinkLattice` -- the reference's Python surface (oscillink/core/lattice.py) over the MI355X library.
+
+Same constructor, methods, attributes, return conventions and error behaviour as the reference class, so
+callers of `Oscillink(...).settle()/receipt()` can switch imports.  All numerics run on the GPU through
+liboscillink_hip.so (ctypes, include/oscillink_hip.h); the lattice graph is sparse (ELL on the device, CSR on
+the host) instead of the reference's dense N x N arrays.  `.A` / `.L_sym` / `.L_path` / `.A_path` are lazy dense
+views kept for small-N callers and tests.
+
+Host-side only (no kernel): parameter validation, U* cache keyed by the state signature, logging, callbacks,
+receipt assembly + HMAC signing, persistence.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import hmac
+import json
+import os
+import time
+from typing import Any, Optional
+
+import numpy as np
+
+from . import _native as nat
+
+__version__ = "0.1.13+mi355x.1"
+
+_DENSE_VIEW_LIMIT = 20000  # N above which dense N x N views are refused (1.6 GB at fp32)
+
+
+class OscillinkLattice:
+    """Short-term coherence lattice: mutual-kNN graph + SPD system + Jacobi-PCG settle (reference lattice.py:23-31)."""
+
+    # ------------------------------------------------------------------ construction (lattice.py:33-110)
+    def __init__(
+        self,
+        Y: np.ndarray,
+        kneighbors: int = 6,
+        row_cap_val: float = 1.0,
+        lamG: float = 1.0,
+        lamC: float = 0.5,
+        lamQ: float = 4.0,
+        deterministic_k: bool = False,
+        neighbor_seed: Optional[int] = None,
+        *,
+        device: Optional[int] = None,
+        _build_graph: bool = True,
+    ):
+        if not isinstance(Y, np.ndarray) or Y.ndim != 2:
+            raise ValueError("Y must be a 2D numpy array")
+        if kneighbors < 1:
+            raise ValueError("kneighbors must be >= 1")
+        if lamG <= 0:
+            raise ValueError("lamG must be > 0 for SPD")
+        for name, val in (("lamC", lamC), ("lamQ", lamQ)):
+            if val < 0:
+                raise ValueError(f"{name} must be >= 0")
+        self._h = None
+        self.Y: np.ndarray = np.ascontiguousarray(Y, dtype=np.float32).copy()
+        self.N, self.D = self.Y.shape
+        k_eff = min(int(kneighbors), max(1, self.N - 1))
+        self._kneighbors = k_eff
+        self._deterministic_k = bool(deterministic_k)
+        self._neighbor_seed = neighbor_seed
+        self._row_cap_val = float(row_cap_val)
+        if device is None:
+            device = int(os.environ.get("OSCILLINK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        self._device = int(device)
+
+        L = nat.lib()
+        if nat.device_count() < 1:
+            raise nat.NativeError("no HIP device visible: oscillink_amd runs on MI355X (gfx950) only, no CPU fallback")
+        h = nat.Handle()
+        t0 = time.time()
+        rc = L.osc_create(nat.f32(self.Y), self.N, self.D, k_eff, self._row_cap_val, int(self._deterministic_k),
+                          -1 if neighbor_seed is None else int(neighbor_seed), self._device, int(bool(_build_graph)),
+                          C.byref(h))
+        nat.check(rc, None, "osc_create")
+        self._h = h
+        self._graph_build_ms = 1000.0 * (time.time() - t0)
+
+        self._B = np.ones(self.N, dtype=np.float32)
+        self._psi = np.zeros(self.D, dtype=np.float32)
+        self.lamG, self.lamC, self.lamQ = lamG, lamC, lamQ
+        self.lamP = 0.0
+        self._chain_nodes: Optional[list[int]] = None
+        self._chain_weights: Optional[list[float]] = None
+        self.last: dict[str, Any] = {"iters": 0, "res": None, "t_ms": None}
+
+        self._U_host: Optional[np.ndarray] = self.Y.copy()  # device U == Y right after create
+        self._csr = None  # (rowptr, col, a, w, sqrt_deg) host cache
+        self._state_version = 0
+        self._sig_cache: Optional[tuple] = None
+        self._Ustar_cache: Optional[np.ndarray] = None
+        self._Ustar_sig: Optional[str] = None
+        self.stats: dict[str, int] = {"ustar_solves": 0, "ustar_cache_hits": 0}
+        self._settle_callbacks: list = []
+        self._logger = None
+        self._receipt_secret: Optional[bytes] = None
+        self._signature_mode = "minimal"
+        self._receipt_detail = "full"
+        self._last_dynamics: Optional[dict[str, Any]] = None
+        self._log("init", {"N": self.N, "D": self.D, "kneighbors_requested": kneighbors,
+                           "kneighbors_effective": k_eff, "deterministic_k": self._deterministic_k,
+                           "neighbor_seed": self._neighbor_seed})
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None:
+            try:
+                nat.lib().osc_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def close(self) -> None:
+        """Release the device memory now (otherwise at garbage collection)."""
+        self.__del__()
+
+    def _call(self, name: str, *args) -> None:
+        nat.check(getattr(nat.lib(), name)(self._h, *args), self._h, name)
+
+    # ------------------------------------------------------------------ array attributes
+    @property
+    def U(self) -> np.ndarray:
+        if self._U_host is None:
+            out = np.empty((self.N, self.D), dtype=np.float32)
+            self._call("osc_get_U", nat.f32(out))
+            self._U_host = out
+        return self._U_host
+
+    @U.setter
+    def U(self, value: np.ndarray) -> None:
+        v = np.ascontiguousarray(value, dtype=np.float32)
+        if v.shape != (self.N, self.D):
+            raise ValueError("U shape mismatch")
+        self._call("osc_set_U", nat.f32(v))
+        self._U_host = v.copy()
+
+    def reset_U(self) -> None:
+        """U <- Y on the device (the state right after construction); used by benchmark loops."""
+        self._call("osc_set_U", None)
+        self._U_host = None
+
+    @property
+    def B_diag(self) -> np.ndarray:
+        return self._B
+
+    @B_diag.setter
+    def B_diag(self, gates: np.ndarray) -> None:
+        g = np.ascontiguousarray(gates, dtype=np.float32)
+        if g.shape[0] != self.N:
+            raise ValueError("gates length mismatch N")
+        self._B = g.copy()
+        self._call("osc_set_query", None, nat.f32(self._B))
+        self._touch()
+
+    @property
+    def psi(self) -> np.ndarray:
+        return self._psi
+
+    @psi.setter
+    def psi(self, psi: np.ndarray) -> None:
+        p = np.ascontiguousarray(psi, dtype=np.float32).ravel()
+        if p.shape[0] != self.D:
+            raise ValueError("psi length mismatch D")
+        self._psi = p.copy()
+        self._call("osc_set_query", nat.f32(self._psi), None)
+        self._touch()
+
+    def _touch(self) -> None:
+        self._state_version += 1
+
+    # ---- graph views ----
+    def _host_csr(self):
+        if self._csr is None:
+            nnz, _, _ = self.graph_stats()
+            rowptr = np.zeros(self.N + 1, dtype=np.int64)
+            col = np.zeros(max(nnz, 1), dtype=np.int32)
+            a = np.zeros(max(nnz, 1), dtype=np.float32)
+            w = np.zeros(max(nnz, 1), dtype=np.float32)
+            sd = np.zeros(self.N, dtype=np.float32)
+            self._call("osc_get_csr", nat.i64(rowptr), nat.i32(col), nat.f32(a), nat.f32(w), nat.f32(sd))
+            self._csr = (rowptr, col[:nnz], a[:nnz], w[:nnz], sd)
+        return self._csr
+
+    def graph_stats(self) -> tuple[int, int, float]:
+        """(stored directed edges, max degree, device build ms)."""
+        nnz, mx, ms = C.c_int64(0), C.c_int32(0), C.c_double(0.0)
+        self._call("osc_graph_stats", C.byref(nnz), C.byref(mx), C.byref(ms))
+        return int(nnz.value), int(mx.value), float(ms.value)
+
+    def graph_csr(self):
+        """Sparse lattice graph: (rowptr int64 (N+1), col int32, A float32 (capped adjacency), W float32, sqrt_deg)."""
+        return self._host_csr()
+
+    def _dense_guard(self) -> None:
+        if self.N > _DENSE_VIEW_LIMIT:
+            raise MemoryError(f"dense N x N view refused for N={self.N} (> {_DENSE_VIEW_LIMIT}); use graph_csr()")
+
+    def _dense_from(self, vals: np.ndarray) -> np.ndarray:
+        rowptr, col, _, _, _ = self._host_csr()
+        out = np.zeros((self.N, self.N), dtype=np.float32)
+        rows = np.repeat(np.arange(self.N), np.diff(rowptr))
+        out[rows, col] = vals
+        return out
+
+    @property
+    def A(self) -> np.ndarray:
+        self._dense_guard()
+        return self._dense_from(self._host_csr()[2])
+
+    @A.setter
+    def A(self, A: np.ndarray) -> None:
+        """Inject a dense symmetric adjacency (from_state path, lattice.py:709-713)."""
+        A = np.asarray(A, dtype=np.float32)
+        if A.shape != (self.N, self.N):
+            raise ValueError("A shape mismatch")
+        r, c = np.nonzero(A > 0)
+        rowptr = np.zeros(self.N + 1, dtype=np.int64)
+        np.add.at(rowptr, r + 1, 1)
+        self.set_graph_csr(np.cumsum(rowptr), c.astype(np.int32), A[r, c].astype(np.float32))
+
+    def set_graph_csr(self, rowptr: np.ndarray, col: np.ndarray, a: np.ndarray) -> None:
+        """Inject a (symmetric, zero-diagonal, already capped) adjacency as CSR; sqrt_deg / W are recomputed."""
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if rowptr.shape[0] != self.N + 1:
+            raise ValueError("rowptr must have N+1 entries")
+        self._call("osc_set_csr", nat.i64(rowptr), nat.i32(col) if col.size else None, nat.f32(a) if a.size else None)
+        self._csr = None
+        self._touch()
+        self._invalidate_cache()
+
+    @property
+    def L_sym(self) -> np.ndarray:
+        self._dense_guard()
+        return np.eye(self.N, dtype=np.float32) - self._dense_from(self._host_csr()[3])
+
+    @property
+    def sqrt_deg(self) -> np.ndarray:
+        return self._host_csr()[4]
+
+    def _path_dense(self):
+        if self._chain_nodes is None:
+            return None, None
+        self._dense_guard()
+        A = np.zeros((self.N, self.N), dtype=np.float32)
+        ws = self._chain_weights or [1.0] * (len(self._chain_nodes) - 1)
+        for t in range(len(self._chain_nodes) - 1):
+            i, j, w = self._chain_nodes[t], self._chain_nodes[t + 1], float(ws[t])
+            A[i, j] = max(A[i, j], w)
+            A[j, i] = max(A[j, i], w)
+        d = A.sum(axis=1)
+        dm = 1.0 / np.sqrt(np.maximum(d, 1e-12))
+        Lp = np.eye(self.N, dtype=np.float32) - ((A * dm[:, None]) * dm[None, :]).astype(np.float32)
+        return Lp, A
+
+    @property
+    def L_path(self):
+        return self._path_dense()[0]
+
+    @property
+    def A_path(self):
+        return self._path_dense()[1]
+
+    # ------------------------------------------------------------------ public API (lattice.py:114-157)
+    def set_query(self, psi: np.ndarray, gates: Optional[np.ndarray] = None) -> None:
+        p = np.ascontiguousarray(psi, dtype=np.float32).ravel().copy()
+        g = None
+        if gates is not None:
+            if gates.shape[0] != self.N:
+                raise ValueError("gates length mismatch N")
+            g = np.ascontiguousarray(gates, dtype=np.float32).copy()
+        if p.shape[0] != self.D:
+            raise ValueError("psi length mismatch D")
+        self._psi = p
+        if g is not None:
+            self._B = g
+        self._call("osc_set_query", nat.f32(self._psi), nat.f32(self._B) if g is not None else None)
+        self._touch()
+        self._invalidate_cache()
+
+    def set_gates(self, gates: np.ndarray) -> None:
+        if gates.shape[0] != self.N:
+            raise ValueError("gates length mismatch N")
+        self._B = np.ascontiguousarray(gates, dtype=np.float32).copy()
+        self._call("osc_set_query", None, nat.f32(self._B))
+        self._touch()
+        self._invalidate_cache()
+
+    def add_chain(self, chain: list[int], lamP: float = 0.2, weights: Optional[list[float]] = None) -> None:
+        if lamP < 0:
+            raise ValueError("lamP must be >= 0")
+        if any((c < 0 or c >= self.N) for c in chain):
+            raise ValueError("chain indices out of bounds")
+        if len(chain) < 2:
+            raise ValueError("chain must contain at least two indices")
+        if weights is not None and len(weights) != len(chain) - 1:
+            raise ValueError("weights length must equal len(chain)-1")
+        ch = np.asarray(list(map(int, chain)), dtype=np.int32)
+        ws = None if weights is None else np.asarray(weights, dtype=np.float32)
+        self._call("osc_set_chain", nat.i32(ch), None if ws is None else nat.f32(ws), int(ch.size), float(lamP))
+        self.lamP = float(lamP)
+        self._chain_nodes = [int(c) for c in chain]
+        self._chain_weights = None if weights is None else [float(w) for w in weights]
+        self._touch()
+        self._invalidate_cache()
+        self._log("add_chain", {"length": len(chain), "lamP": lamP})
+
+    def clear_chain(self) -> None:
+        self._call("osc_clear_chain")
+        self.lamP = 0.0
+        self._chain_nodes = None
+        self._chain_weights = None
+        self._touch()
+        self._invalidate_cache()
+        self._log("clear_chain", {})
+
+    def _push_params(self) -> None:
+        """lamG/lamC/lamQ/lamP are plain attributes in the reference and may be assigned directly."""
+        self._call("osc_set_lams", float(self.lamG), float(self.lamC), float(self.lamQ))
+        if self._chain_nodes is not None and float(self.lamP) != getattr(self, "_lamP_dev", None):
+            ch = np.asarray(self._chain_nodes, dtype=np.int32)
+            ws = None if self._chain_weights is None else np.asarray(self._chain_weights, dtype=np.float32)
+            self._call("osc_set_chain", nat.i32(ch), None if ws is None else nat.f32(ws), int(ch.size), float(self.lamP))
+        self._lamP_dev = float(self.lamP)
+
+    # ------------------------------------------------------------------ settle (lattice.py:159-230)
+    def settle(self, dt: float = 1.0, max_iters: int = 12, tol: float = 1e-3, precond: str = "jacobi", *,
+               warm_start: bool = True, inertia: float = 0.0) -> dict[str, Any]:
+        """Implicit Euler step (I + dt M) U+ = U + dt (lamG Y + lamQ B 1 psi^T) by Jacobi-PCG on the GPU."""
+        dyn = os.getenv("OSCILLINK_RECEIPT_DYNAMICS", "0").strip().lower() in {"1", "true", "yes"}
+        U_prev = self.U.copy() if dyn else None
+        self._push_params()
+        iters, res, ms = C.c_int32(0), C.c_float(0.0), C.c_double(0.0)
+        self._call("osc_settle", float(dt), int(max_iters), float(tol), 1 if precond == "jacobi" else 0,
+                   int(bool(warm_start)), float(inertia), C.byref(iters), C.byref(res), C.byref(ms))
+        self._U_host = None
+        self.last = {"iters": int(iters.value), "res": float(res.value), "t_ms": float(ms.value)}
+        self._log("settle", self.last)
+        if self.last["res"] > tol * 10:
+            self._log("settle_convergence_warn", {"res": self.last["res"], "tol": tol, "iters": self.last["iters"]})
+        if dyn:
+            try:
+                self._last_dynamics = self._compute_dynamics(U_prev, self.U, self.last["iters"])
+            except Exception:
+                self._last_dynamics = None
+        for cb in list(self._settle_callbacks):
+            try:
+                cb(self, self.last)
+            except Exception:
+                pass
+        return self.last
+
+    def residual_history(self) -> list[float]:
+        """Residual after each iteration of the last solve (diagnostic; not in the reference)."""
+        buf = np.zeros(4096, dtype=np.float32)
+        n = C.c_int32(0)
+        self._call("osc_residual_history", nat.f32(buf), 4096, C.byref(n))
+        return buf[: n.value].astype(float).tolist()
+
+    # ------------------------------------------------------------------ U* (lattice.py:232-296)
+    def solve_Ustar(self, tol: float = 1e-4, max_iters: int = 64, use_cache: bool = True) -> np.ndarray:
+        sig = self._signature()
+        if use_cache and self._Ustar_cache is not None and self._Ustar_sig == sig:
+            self.stats["ustar_cache_hits"] += 1
+            self._log("ustar_cache_hit", {"signature": sig})
+            return self._Ustar_cache
+        self._push_params()
+        out = np.empty((self.N, self.D), dtype=np.float32)
+        iters, res, ms = C.c_int32(0), C.c_float(0.0), C.c_double(0.0)
+        self._call("osc_solve_ustar", float(tol), int(max_iters), nat.f32(out), C.byref(iters), C.byref(res),
+                   C.byref(ms))
+        converged = bool(float(res.value) <= tol)
+        self.last_ustar = {"iters": int(iters.value), "res": float(res.value), "converged": converged,
+                           "solve_ms": float(ms.value)}
+        self._device_ustar_sig = sig
+        if use_cache:
+            self._Ustar_cache = out
+            self._Ustar_sig = sig
+        self.stats["ustar_solves"] += 1
+        self._log("ustar_solve", {"signature": sig, "tol": tol, "max_iters": max_iters, **self.last_ustar})
+        if not converged:
+            self._log("ustar_convergence_warn", {"res": float(res.value), "tol": tol, "iters": int(iters.value)})
+        return out
+
+    def refresh_Ustar(self, tol: float = 1e-4, max_iters: int = 64) -> np.ndarray:
+        self._invalidate_cache()
+        self._log("refresh_ustar", {})
+        return self.solve_Ustar(tol=tol, max_iters=max_iters, use_cache=True)
+
+    def _ensure_device_ustar(self) -> np.ndarray:
+        """U* on the host AND resident on the device for the receipt kernels."""
+        Us = self.solve_Ustar()
+        if getattr(self, "_device_ustar_sig", None) != self._signature():
+            Us = self.solve_Ustar(use_cache=False)  # state was exported/imported around the cache: re-solve
+        return Us
+
+    # ------------------------------------------------------------------ receipts (lattice.py:298-455)
+    def receipt(self) -> dict[str, Any]:
+        self._ensure_device_ustar()
+        dH = C.c_double(0.0)
+        self._call("osc_deltaH", C.byref(dH))
+        dH = float(np.float32(dH.value))
+        if self._receipt_detail == "light":
+            coh_sum = anchor_sum = query_sum = 0.0
+            nulls_full: list[dict[str, Any]] = []
+        else:
+            coh, anc, qry = self._components()
+            coh_sum, anchor_sum, query_sum = float(np.sum(coh)), float(np.sum(anc)), float(np.sum(qry))
+            nulls_full = self._null_points(3.0)
+        try:
+            cap_val = int(os.getenv("OSCILLINK_RECEIPT_NULL_CAP", "0").strip())
+        except ValueError:
+            cap_val = 0
+        if cap_val > 0 and len(nulls_full) > cap_val:
+            nulls = sorted(nulls_full, key=lambda e: e.get("z", 0.0), reverse=True)[:cap_val]
+            null_meta = {"total_null_points": len(nulls_full), "returned_null_points": cap_val, "null_cap_applied": True}
+        else:
+            nulls = nulls_full
+            null_meta = {"total_null_points": len(nulls_full), "returned_null_points": len(nulls_full),
+                         "null_cap_applied": False}
+        nnz, _, _ = self.graph_stats()
+        lu = getattr(self, "last_ustar", {})
+        sig = self._signature()
+        meta: dict[str, Any] = {
+            "ustar_cached": bool(self._Ustar_cache is not None and self._Ustar_sig == sig),
+            "ustar_solves": int(self.stats["ustar_solves"]),
+            "ustar_cache_hits": int(self.stats["ustar_cache_hits"]),
+            "ustar_converged": bool(lu.get("converged", True)),
+            "ustar_res": float(lu.get("res", 0.0)),
+            "ustar_iters": int(lu.get("iters", 0)),
+            "ustar_solve_ms": float(lu.get("solve_ms", 0.0)),
+            "graph_build_ms": float(self._graph_build_ms),
+            "last_settle_ms": float(self.last.get("t_ms") or 0.0),
+            "avg_degree": float(nnz / max(self.N, 1)),
+            "edge_density": float(nnz / max(self.N * (self.N - 1), 1)),
+            "gates_min": float(np.min(self._B)),
+            "gates_max": float(np.max(self._B)),
+            "gates_mean": float(np.mean(self._B)),
+            "gates_uniform": bool(np.allclose(self._B, self._B[0])),
+            "state_sig": sig,
+            "receipt_detail": self._receipt_detail,
+            "null_points_summary": null_meta,
+        }
+        if self._receipt_secret is not None:
+            if self._signature_mode == "extended":
+                payload = {
+                    "sig_v": 1, "mode": "extended", "state_sig": sig, "deltaH_total": float(dH),
+                    "ustar_iters": int(lu.get("iters", 0)), "ustar_res": float(lu.get("res", 0.0)),
+                    "ustar_converged": bool(lu.get("converged", True)),
+                    "params": {"lamG": self.lamG, "lamC": self.lamC, "lamQ": self.lamQ, "lamP": self.lamP},
+                    "graph": {"k": self._kneighbors, "deterministic_k": self._deterministic_k,
+                              "neighbor_seed": self._neighbor_seed},
+                }
+            else:
+                payload = {"sig_v": 1, "mode": "minimal", "state_sig": sig, "deltaH_total": float(dH)}
+            raw = json.dumps(payload, sort_keys=True).encode("utf-8")
+            meta["signature"] = {"algorithm": "HMAC-SHA256", "payload": payload,
+                                 "signature": hmac.new(self._receipt_secret, raw, hashlib.sha256).hexdigest()}
+        out = {
+            "version": str(__version__),
+            "deltaH_total": float(dH),
+            "coh_drop_sum": coh_sum,
+            "anchor_pen_sum": anchor_sum,
+            "query_term_sum": query_sum,
+            "cg_iters": int(self.last.get("iters") or 0),
+            "residual": float(self.last.get("res") or 0.0),
+            "t_ms": float(self.last.get("t_ms") or 0.0),
+            "null_points": nulls,
+            "meta": meta,
+        }
+        if os.getenv("OSCILLINK_RECEIPT_DYNAMICS", "0").strip().lower() in {"1", "true", "yes"} and self._last_dynamics:
+            meta["dynamics"] = self._last_dynamics
+        self._log("receipt", {"deltaH_total": out["deltaH_total"], "ustar_cached": meta["ustar_cached"]})
+        return out
+
+    def _components(self):
+        coh = np.zeros(self.N, dtype=np.float32)
+        anc = np.zeros(self.N, dtype=np.float32)
+        qry = np.zeros(self.N, dtype=np.float32)
+        self._call("osc_receipt_components", nat.f32(coh), nat.f32(anc), nat.f32(qry))
+        return coh, anc, qry
+
+    def _coherence_drop(self, Ustar: Optional[np.ndarray] = None) -> np.ndarray:
+        self._ensure_device_ustar()
+        return self._components()[0]
+
+    def _null_points(self, z_th: float) -> list[dict[str, Any]]:
+        i = np.zeros(self.N, dtype=np.int32)
+        j = np.zeros(self.N, dtype=np.int32)
+        z = np.zeros(self.N, dtype=np.float32)
+        r = np.zeros(self.N, dtype=np.float32)
+        n = C.c_int32(0)
+        self._call("osc_null_points", float(z_th), nat.i32(i), nat.i32(j), nat.f32(z), nat.f32(r), C.byref(n))
+        return [{"edge": [int(i[t]), int(j[t])], "z": float(z[t]), "residual": float(r[t])} for t in range(n.value)]
+
+    def verify_current_receipt(self, secret) -> bool:
+        from .receipts import verify_receipt
+
+        return verify_receipt(self.receipt(), secret)
+
+    # ------------------------------------------------------------------ chain receipt (lattice.py:466-528), sparse
+    def chain_receipt(self, chain: list[int], z_th: float = 2.5) -> dict[str, Any]:
+        Ustar = self._ensure_device_ustar()
+        rowptr, col, a, _, sd = self._host_csr()
+        di = sd + 1e-12
+        N = self.N
+        lamC = float(self.lamC)
+
+        def un(i):
+            return Ustar[i] / di[i]
+
+        def row_stats(i, extra=None):
+            """mean / std (+1e-12) over the N entries of the dense residual row i (zeros included)."""
+            R = extra
+            mu = float(np.sum(R, dtype=np.float64) / N)
+            var = float((np.sum((R.astype(np.float64) - mu) ** 2) + (N - R.size) * mu * mu) / N)
+            return mu, float(np.sqrt(max(var, 0.0))) + 1e-12
+
+        def struct_row(i):
+            js = col[rowptr[i]: rowptr[i + 1]]
+            if js.size == 0:
+                return js, np.zeros(0, dtype=np.float32)
+            d = un(i)[None, :] - Ustar[js] / di[js, None]
+            return js, (lamC * a[rowptr[i]: rowptr[i + 1]] * np.einsum("ij,ij->i", d, d).astype(np.float32)).astype(np.float32)
+
+        # path adjacency: the lattice's own chain if set, else the argument (lattice.py:479-483)
+        nodes = self._chain_nodes if self._chain_nodes is not None else [int(c) for c in chain]
+        ws = (self._chain_weights if self._chain_nodes is not None else None) or [1.0] * (len(nodes) - 1)
+        padj: dict[int, dict[int, float]] = {}
+        for t in range(len(nodes) - 1):
+            i, j, w = nodes[t], nodes[t + 1], float(ws[t])
+            if 0 <= i < N and 0 <= j < N:
+                padj.setdefault(i, {})[j] = max(padj.get(i, {}).get(j, 0.0), w)
+                padj.setdefault(j, {})[i] = max(padj.get(j, {}).get(i, 0.0), w)
+        lam_p = max(lamC, 1e-6)
+
+        def path_row(i):
+            nb = padj.get(i, {})
+            js = np.array(sorted(nb), dtype=np.int64)
+            if js.size == 0:
+                return js, np.zeros(0, dtype=np.float32)
+            d = un(i)[None, :] - Ustar[js] / di[js, None]
+            wv = np.array([nb[int(j)] for j in js], dtype=np.float32)
+            return js, (lam_p * wv * np.einsum("ij,ij->i", d, d).astype(np.float32)).astype(np.float32)
+
+        edges: list[dict[str, Any]] = []
+        worst = (-1, -1.0, (-1, -1))
+        gain = 0.0
+        for k in range(len(chain) - 1):
+            i, j = int(chain[k]), int(chain[k + 1])
+            sj, sR = struct_row(i)
+            pj, pR = path_row(i)
+            mu_s, sig_s = row_stats(i, sR)
+            mu_p, sig_p = row_stats(i, pR)
+            rs = float(sR[np.nonzero(sj == j)[0][0]]) if np.any(sj == j) else 0.0
+            rp = float(pR[np.nonzero(pj == j)[0][0]]) if np.any(pj == j) else 0.0
+            z_struct = float((rs - mu_s) / sig_s)
+            z_path = float((rp - mu_p) / sig_p)
+            edges.append({"k": int(k), "edge": [i, j], "z_struct": z_struct, "z_path": z_path, "r_struct": rs,
+                          "r_path": rp})
+            if max(z_struct, z_path) > worst[1]:
+                worst = (k, max(z_struct, z_path), (i, j))
+            w_ij = float(a[rowptr[i]: rowptr[i + 1]][sj == j][0]) if np.any(sj == j) else 0.0
+            ydiff = self.Y[i] / di[i] - self.Y[j] / di[j]
+            udiff = un(i) - un(j)
+            gain += 0.5 * lamC * max(w_ij, 0.0) * (float(ydiff @ ydiff) - float(udiff @ udiff))
+        verdict = all(max(float(e["z_struct"]), float(e["z_path"])) <= float(z_th) for e in edges)
+        return {"verdict": bool(verdict),
+                "weakest_link": {"k": int(worst[0]), "edge": [int(worst[2][0]), int(worst[2][1])],
+                                 "zscore": float(worst[1])},
+                "coherence_gain": float(gain), "edges": edges}
+
+    # ------------------------------------------------------------------ bundle (lattice.py:530-568; graph.py:114-133)
+    def bundle(self, k: int = 8, alpha: float = 0.5) -> list[dict]:
+        Ustar = self._ensure_device_ustar()
+        u_norm = np.linalg.norm(Ustar, axis=1, keepdims=True) + 1e-12
+        psi_n = self._psi / (np.linalg.norm(self._psi) + 1e-12)
+        align = (Ustar / u_norm) @ psi_n
+        coh = self._components()[0]
+        mu, sigma = float(np.mean(coh)), float(np.std(coh) + 1e-12)
+        z = (coh - mu) / sigma if sigma > 0 else np.zeros_like(coh)
+        score = alpha * z + (1 - alpha) * align.squeeze()
+        order = self._mmr(score, k, 0.5)
+        return [{"id": int(i), "score": float(score[i]), "align": float(align[i])} for i in order]
+
+    def _mmr(self, scores: np.ndarray, k: int, lambda_div: float) -> list[int]:
+        """Greedy MMR over cosine similarity of Y; similarity rows are formed only for chosen items (O(kND))."""
+        if k <= 0:
+            return []
+        Yn = self.Y / (np.linalg.norm(self.Y, axis=1, keepdims=True) + 1e-12)
+        chosen: list[int] = []
+        maxsim = np.zeros(self.N, dtype=np.float64)
+        alive = np.ones(self.N, dtype=bool)
+        while len(chosen) < min(k, self.N):
+            val = (1 - lambda_div) * scores.astype(np.float64) - lambda_div * (maxsim if chosen else 0.0)
+            val = np.where(alive, val, -np.inf)
+            b = int(np.argmax(val))
+            chosen.append(b)
+            alive[b] = False
+            s = (Yn @ Yn[b]).astype(np.float64)
+            maxsim = s if len(chosen) == 1 else np.maximum(maxsim, s)
+        return chosen
+
+    # ------------------------------------------------------------------ callbacks / logging (lattice.py:571-579, 930-949)
+    def add_settle_callback(self, fn) -> None:
+        self._settle_callbacks.append(fn)
+
+    def remove_settle_callback(self, fn) -> None:
+        try:
+            self._settle_callbacks.remove(fn)
+        except ValueError:
+            pass
+
+    def set_logger(self, logger_callable) -> None:
+        self._logger = logger_callable
+
+    def _log(self, event: str, payload: dict) -> None:
+        if self._logger is not None:
+            try:
+                self._logger(event, payload)
+            except Exception:
+                pass
+
+    def set_receipt_secret(self, secret) -> None:
+        if secret is None:
+            self._receipt_secret = None
+        else:
+            self._receipt_secret = secret.encode("utf-8") if isinstance(secret, str) else secret
+
+    def set_signature_mode(self, mode: str) -> None:
+        m = mode.lower().strip()
+        if m not in {"minimal", "extended"}:
+            raise ValueError("mode must be 'minimal' or 'extended'")
+        self._signature_mode = m
+
+    def set_receipt_detail(self, mode: str) -> None:
+        m = mode.lower().strip()
+        if m not in {"full", "light"}:
+            raise ValueError("mode must be 'full' or 'light'")
+        self._receipt_detail = m
+
+    # ------------------------------------------------------------------ signature / cache (lattice.py:729-758)
+    def _edge_prefix(self, limit: int = 2048) -> np.ndarray:
+        rowptr, col, _, _, _ = self._host_csr()
+        m = min(limit, col.shape[0])
+        rows = np.searchsorted(rowptr, np.arange(m), side="right") - 1
+        return np.stack([rows.astype(np.int64), col[:m].astype(np.int64)], axis=1)
+
+    def _signature(self) -> str:
+        key = (self._state_version, float(self.lamG), float(self.lamC), float(self.lamQ), float(self.lamP),
+               self._chain_nodes is not None, len(self._chain_nodes) if self._chain_nodes else 0, self._kneighbors,
+               self._deterministic_k)
+        if self._sig_cache is not None and self._sig_cache[0] == key:
+            return self._sig_cache[1]
+        adj_sig = hashlib.sha256(np.ascontiguousarray(self._edge_prefix()).tobytes()).hexdigest()
+        data = {
+            "psi": np.round(self._psi, 6).tolist(),
+            "B": np.round(self._B, 6).tolist(),
+            "lam": [self.lamG, self.lamC, self.lamQ, self.lamP],
+            "chain_present": self._chain_nodes is not None,
+            "chain_len": len(self._chain_nodes) if self._chain_nodes else 0,
+            "k": self._kneighbors,
+            "detk": self._deterministic_k,
+            "adj": adj_sig,
+        }
+        sig = hashlib.sha256(json.dumps(data, sort_keys=True).encode("utf-8")).hexdigest()
+        self._sig_cache = (key, sig)
+        return sig
+
+    def _invalidate_cache(self) -> None:
+        self._Ustar_cache = None
+        self._Ustar_sig = None
+        self._log("invalidate_cache", {})
+
+    # ------------------------------------------------------------------ rebuild (lattice.py:760-801)
+    def rebuild_graph(self, *, row_cap_val: Optional[float] = None, kneighbors: Optional[int] = None,
+                      deterministic_k: Optional[bool] = None, neighbor_seed: Optional[int] = None) -> None:
+        if row_cap_val is not None:
+            self._row_cap_val = float(row_cap_val)
+        if kneighbors is not None:
+            self._kneighbors = min(int(kneighbors), max(1, self.N - 1))
+        if deterministic_k is not None:
+            self._deterministic_k = bool(deterministic_k)
+        if neighbor_seed is not None:
+            self._neighbor_seed = neighbor_seed
+        t0 = time.time()
+        self._call("osc_rebuild_graph", int(self._kneighbors), float(self._row_cap_val), int(self._deterministic_k),
+                   -1 if self._neighbor_seed is None else int(self._neighbor_seed))
+        self._graph_build_ms = 1000.0 * (time.time() - t0)
+        self._csr = None
+        self._touch()
+        self._invalidate_cache()
+        self._log("rebuild_graph", {"k": int(self._kneighbors), "row_cap_val": float(self._row_cap_val),
+                                    "deterministic_k": self._deterministic_k, "neighbor_seed": self._neighbor_seed})
+
+    # ------------------------------------------------------------------ persistence (lattice.py:582-726)
+    def _provenance(self) -> str:
+        h = hashlib.sha256()
+        h.update(self.Y.tobytes())
+        h.update(self._psi.tobytes())
+        h.update(self._B.tobytes())
+        h.update(np.array([self.lamG, self.lamC, self.lamQ, self.lamP], dtype=np.float64).tobytes())
+        h.update(np.ascontiguousarray(self._edge_prefix()).tobytes())
+        return h.hexdigest()
+
+    def export_state(self, include_graph: bool = True, include_chain: bool = True) -> dict[str, Any]:
+        state: dict[str, Any] = {
+            "version": str(__version__),
+            "shape": [int(self.N), int(self.D)],
+            "params": {"lamG": self.lamG, "lamC": self.lamC, "lamQ": self.lamQ, "lamP": self.lamP},
+            "Y": self.Y.tolist(),
+            "psi": self._psi.tolist(),
+            "B_diag": self._B.tolist(),
+            "kneighbors": int(self._kneighbors),
+            "deterministic_k": bool(self._deterministic_k),
+            "neighbor_seed": self._neighbor_seed,
+            "provenance": self._provenance(),
+        }
+        if include_graph:
+            state["A"] = self.A.tolist()
+        if include_chain and self._chain_nodes is not None:
+            pairs = set()
+            for t in range(len(self._chain_nodes) - 1):
+                i, j = self._chain_nodes[t], self._chain_nodes[t + 1]
+                if i != j:
+                    pairs.add((min(i, j), max(i, j)))
+            state["chain_edges"] = [[int(i), int(j)] for i, j in sorted(pairs)]
+            state["chain_nodes"] = list(self._chain_nodes)
+        return state
+
+    def save_state(self, path: str, format: str = "json", include_graph: bool = True, include_chain: bool = True) -> None:
+        fmt = format.lower()
+        if fmt == "json":
+            with open(path, "w", encoding="utf-8") as f:
+                json.dump(self.export_state(include_graph=include_graph, include_chain=include_chain), f, sort_keys=True)
+        elif fmt == "npz":
+            state = self.export_state(include_graph=False, include_chain=include_chain)
+            arrays: dict[str, np.ndarray] = {"Y": self.Y, "psi": self._psi, "B_diag": self._B}
+            if include_graph:
+                arrays["A"] = self.A
+            if include_chain and self._chain_nodes is not None:
+                arrays["chain_nodes"] = np.array(self._chain_nodes, dtype=np.int32)
+            for key in ["Y", "psi", "B_diag", "A", "chain_nodes"]:
+                state.pop(key, None)
+            np.savez_compressed(path, __meta__=np.array(json.dumps(state, sort_keys=True)), **arrays)
+        else:
+            raise ValueError("format must be 'json' or 'npz'")
+
+    @classmethod
+    def from_npz(cls, path: str) -> "OscillinkLattice":
+        with np.load(path, allow_pickle=False) as data:
+            state = json.loads(str(data["__meta__"]))
+            state["Y"] = data["Y"].astype(np.float32)
+            state["psi"] = data["psi"].astype(np.float32)
+            state["B_diag"] = data["B_diag"].astype(np.float32)
+            if "A" in data.files:
+                state["A"] = data["A"].astype(np.float32)
+            if "chain_nodes" in data.files:
+                state["chain_nodes"] = data["chain_nodes"].astype(int).tolist()
+        return cls.from_state(state)
+
+    @classmethod
+    def from_state(cls, state: dict[str, Any]) -> "OscillinkLattice":
+        Y = np.array(state["Y"], dtype=np.float32)
+        params = state.get("params", {})
+        have_A = "A" in state and np.asarray(state["A"]).shape == (Y.shape[0], Y.shape[0])
+        lat = cls(Y, kneighbors=state.get("kneighbors", 6), lamG=params.get("lamG", 1.0), lamC=params.get("lamC", 0.5),
+                  lamQ=params.get("lamQ", 4.0), deterministic_k=state.get("deterministic_k", False),
+                  neighbor_seed=state.get("neighbor_seed"), _build_graph=not have_A)
+        psi = np.array(state.get("psi", np.zeros(Y.shape[1], dtype=np.float32)), dtype=np.float32)
+        B = np.array(state.get("B_diag", np.ones(Y.shape[0], dtype=np.float32)), dtype=np.float32)
+        if have_A:  # stored adjacency overrides a rebuild (lattice.py:709-713)
+            lat.A = np.array(state["A"], dtype=np.float32)
+        lat.set_query(psi, gates=B)
+        lamP = params.get("lamP", 0.0)
+        if lamP > 0:
+            if "chain_nodes" in state:
+                lat.add_chain(list(map(int, state["chain_nodes"])), lamP=lamP)
+            elif state.get("chain_edges"):
+                lat.add_chain(sorted({i for e in state["chain_edges"] for i in e}), lamP=lamP)
+        if "provenance" in state:
+            lat._imported_provenance = state["provenance"]
+        return lat
+
+    # ------------------------------------------------------------------ dynamics (lattice.py:825-927), env-gated
+    def _compute_dynamics(self, U_prev: np.ndarray, U_next: np.ndarray, iters: int) -> dict[str, Any]:
+        dU = (U_next - U_prev).astype(np.float32)
+        move2 = np.sum(dU * dU, axis=1)
+        rowptr, col, a, w, sd = self._host_csr()
+        rows = np.repeat(np.arange(self.N), np.diff(rowptr))
+        # step energy: dU . M dU with the sparse operator
+        WX = np.zeros_like(dU)
+        np.add.at(WX, rows, w[:, None] * dU[col])
+        term = self.lamG * dU + self.lamC * (dU - WX) + self.lamQ * (self._B[:, None] * dU)
+        Lp = self.L_path if (self._chain_nodes is not None and self.lamP > 0 and self.N <= _DENSE_VIEW_LIMIT) else None
+        if Lp is not None:
+            term = term + self.lamP * (Lp @ dU)
+        dH_step = float(np.sum(dU * term))
+        di = sd + 1e-12
+        Up, Un = U_prev / di[:, None], U_next / di[:, None]
+        dp, dn = Up[rows] - Up[col], Un[rows] - Un[col]
+        f = np.maximum(0.0, 0.5 * self.lamC * a * (np.einsum("ij,ij->i", dp, dp) - np.einsum("ij,ij->i", dn, dn)))
+        top = np.argsort(-f, kind="stable")[:16]
+        flows = [{"edge": [int(rows[t]), int(col[t])], "flow": float(f[t])} for t in top if f[t] > 0]
+        inf = np.sqrt(move2 + 1e-12)
+        radius = 0
+        if inf.size and float(np.max(inf)) > 1e-9:
+            seeds = np.where(inf >= 0.1 * float(np.max(inf)))[0]
+            dist = np.full(self.N, -1, dtype=np.int64)
+            dist[seeds] = 0
+            frontier = seeds
+            while frontier.size:
+                nxt = []
+                for u in frontier:
+                    for v in col[rowptr[u]: rowptr[u + 1]]:
+                        if dist[v] < 0:
+                            dist[v] = dist[u] + 1
+                            nxt.append(v)
+                frontier = np.array(nxt, dtype=np.int64)
+            radius = int(np.max(dist))
+        return {"temperature": float(np.mean(move2)), "step_deltaH": dH_step,
+                "viscosity_step": float(iters) / (abs(dH_step) + 1e-12), "flow_total": float(np.sum(f)),
+                "top_flows": flows, "radius": int(radius),
+                "move2_mean": float(np.mean(move2) if move2.size else 0.0),
+                "move2_max": float(np.max(move2) if move2.size else 0.0)}
+
+    def __repr__(self) -> str:  # pragma: no cover
+        parts = [f"N={self.N}", f"D={self.D}", f"k={self._kneighbors}", f"lamG={self.lamG}", f"lamC={self.lamC}",
+                 f"lamQ={self.lamQ}"]
+        if self.lamP > 0 and self._chain_nodes is not None:
+            parts += [f"chain_len={len(self._chain_nodes)}", f"lamP={self.lamP}"]
+        if self._Ustar_cache is not None:
+            parts.append("U*cached")
+        return "OscillinkLattice(" + ", ".join(parts) + ")"
+
+
+def json_line_logger(stream=None):
+    """Logger callable writing compact JSON lines (reference lattice.py:995-1014)."""
+    import sys
+
+    stream = stream or sys.stderr
+
+    def _emit(ev: str, payload: dict):  # pragma: no cover
+        try:
+            stream.write(json.dumps({"event": ev, **payload}, separators=(",", ":")) + "\n")
+        except Exception:
+            pass
+
+    return _emit

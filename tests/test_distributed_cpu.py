@@ -1,0 +1,93 @@
+"""world_size-2 gloo test of the multi-GPU protocol (runs on CPU): the column-sharded CG -- each rank owns a column
+slab, per-column alpha/beta stay local, the only exchange is one all-reduce(max) of the stop-test residual per
+iteration -- reproduces the single-process oracle bit for bit on every slab, with identical iteration counts.
+The native library runs the same protocol with RCCL (osc_comm_init / run_cg in csrc/osc_api.hip)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oscillink_oracle as orc
+    from oscillink_amd.sharding import column_shard
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)
+    N, D, k = 300, 50, 7
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    lat = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True, dense=False)
+    lat.set_query(psi)
+    lat.add_chain([3, 8, 1], lamP=0.2)
+    c0, c1 = column_shard(D, rank, world)
+    dt, tol, max_iters = 1.0, 1e-3, 12
+
+    def A_mul(X):  # the operator acts row-wise on columns: a column slab is closed under it
+        out = X + dt * (lat.lamG * X + lat.lamC * lat._L(X) + lat.lamQ * (lat.B_diag[:, None] * X))
+        return out + dt * (lat.lamP * lat._Lp(X))
+
+    b = (lat.U + dt * lat._rhs())[:, c0:c1]
+    Md = (1.0 + dt * lat._diag_base())[:, None] + 1e-12
+    x = lat.U[:, c0:c1].copy()
+    r = b - A_mul(x)
+    z = r / Md
+    p = z.copy()
+    rz = (r * z).sum(axis=0)
+    iters = max_iters
+    for it in range(1, max_iters + 1):
+        Ap = A_mul(p)
+        alpha = rz / ((p * Ap).sum(axis=0) + 1e-18)
+        x = x + p * alpha
+        r = r - Ap * alpha
+        res = torch.tensor([float(np.linalg.norm(r, axis=0).max())], dtype=torch.float64)
+        dist.all_reduce(res, op=dist.ReduceOp.MAX)  # the ONLY collective of an iteration
+        if float(res.item()) <= tol:
+            iters = it
+            break
+        z = r / Md
+        rzn = (r * z).sum(axis=0)
+        p = z + p * (rzn / (rz + 1e-18))
+        rz = rzn
+    full = lat.settle(dt=dt, max_iters=max_iters, tol=tol)
+    ok = (iters == full["iters"]) and np.array_equal(x.astype(np.float32), lat.U[:, c0:c1]) \
+        and abs(float(res.item()) - full["res"]) <= 1e-12
+    q.put((rank, bool(ok), iters, full["iters"], (c0, c1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_column_sharded_cg_two_ranks_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort()
+    assert got[0][4][0] == 0 and got[0][4][1] == got[1][4][0] and got[1][4][1] == 50
+    for rank, ok, it, it_full, _ in got:
+        assert ok, (rank, it, it_full)

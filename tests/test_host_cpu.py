@@ -1,0 +1,109 @@
+"""CPU-side checks of the product's host layer: the C-ABI library builds, loads and exports every symbol the
+header declares; validation and signing logic; failing loudly without a GPU.  No compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from oscillink_amd import _build, _native
+
+    _build.build()
+    return _native.lib()
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "oscillink_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(osc_[a-z_A-Z0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from oscillink_amd import _native
+
+    names = _header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/oscillink_hip.h but not exported"
+        assert n in _native.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(_native.SIGNATURES) == set(names)
+    assert b"gfx950" in lib.osc_version()
+    n = ctypes.c_int32(-1)
+    assert lib.osc_device_count(ctypes.byref(n)) == 0 and n.value >= 0
+
+
+def test_validation_precedes_device_and_missing_gpu_fails_loudly(lib):
+    import oscillink_amd
+    from oscillink_amd import _native
+
+    Y = np.random.default_rng(0).standard_normal((12, 8)).astype(np.float32)
+    for bad in (dict(kneighbors=0), dict(lamG=0.0), dict(lamC=-1.0), dict(lamQ=-0.5)):
+        with pytest.raises(ValueError):
+            oscillink_amd.Oscillink(Y, **bad)
+    with pytest.raises(ValueError):
+        oscillink_amd.Oscillink(Y[0])
+    if _native.device_count() == 0:  # no silent CPU path
+        with pytest.raises(_native.NativeError):
+            oscillink_amd.Oscillink(Y)
+        with pytest.raises(_native.NativeError):
+            oscillink_amd.compute_diffusion_gates(Y, Y[0])
+    with pytest.raises(ValueError):
+        oscillink_amd.compute_diffusion_gates(Y, Y[0][:3])
+    with pytest.raises(ValueError):
+        oscillink_amd.compute_diffusion_gates(Y, Y[0], gamma=0.0)
+    assert oscillink_amd.Oscillink is oscillink_amd.OscillinkLattice
+
+
+def test_create_rejects_bad_arguments_without_a_device(lib):
+    from oscillink_amd import _native as nat
+
+    h = nat.Handle()
+    Y = np.zeros((4, 4), dtype=np.float32)
+    assert lib.osc_create(None, 4, 4, 2, 1.0, 0, -1, 0, 1, ctypes.byref(h)) == nat.OSC_E_INVALID
+    assert lib.osc_create(nat.f32(Y), 0, 4, 2, 1.0, 0, -1, 0, 1, ctypes.byref(h)) == nat.OSC_E_INVALID
+    assert lib.osc_create(nat.f32(Y), 4, 4, 0, 1.0, 0, -1, 0, 1, ctypes.byref(h)) == nat.OSC_E_INVALID
+    assert b"osc_create" in lib.osc_last_error(None)
+    if nat.device_count() == 0:
+        assert lib.osc_create(nat.f32(Y), 4, 4, 2, 1.0, 0, -1, 0, 1, ctypes.byref(h)) == nat.OSC_E_NODEVICE
+        assert b"no CPU fallback" in lib.osc_last_error(None)
+
+
+def test_receipt_signature_helpers():
+    import hashlib
+    import hmac
+    import json
+
+    from oscillink_amd import verify_receipt, verify_receipt_mode
+
+    payload = {"sig_v": 1, "mode": "extended", "state_sig": "abc", "deltaH_total": 1.5, "ustar_iters": 5}
+    sig = hmac.new(b"k", json.dumps(payload, sort_keys=True).encode(), hashlib.sha256).hexdigest()
+    rec = {"meta": {"signature": {"algorithm": "HMAC-SHA256", "payload": payload, "signature": sig}}}
+    assert verify_receipt(rec, "k") and verify_receipt(rec, b"k") and not verify_receipt(rec, "x")
+    assert verify_receipt_mode(rec, "k", require_mode="extended")[0]
+    assert not verify_receipt_mode(rec, "k", require_mode="minimal")[0]
+    assert not verify_receipt_mode(rec, "k", required_sig_v=2)[0]
+    assert not verify_receipt({}, "k") and verify_receipt_mode({"meta": {}}, "k") == (False, None)
+    minimal = {"sig_v": 1, "mode": "minimal", "state_sig": "abc", "deltaH_total": 1.5}
+    sig_min = hmac.new(b"k", json.dumps(minimal, sort_keys=True).encode(), hashlib.sha256).hexdigest()
+    rec2 = {"meta": {"signature": {"algorithm": "HMAC-SHA256", "payload": payload, "signature": sig_min}}}
+    ok, sub = verify_receipt_mode(rec2, "k", minimal_subset=True)
+    assert ok and sub["mode"] == "minimal"
+
+
+def test_column_shard_plan():
+    from oscillink_amd.sharding import column_shard, padded_width
+
+    assert padded_width(50) == 52 and padded_width(768) == 768
+    for D, world in ((768, 8), (384, 8), (1536, 4), (50, 3), (128, 1)):
+        spans = [column_shard(D, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == D
+        for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+            assert a1 == b0 and a0 % 4 == 0 and a1 > a0
+    with pytest.raises(ValueError):
+        column_shard(8, 0, 3)
