@@ -78,6 +78,7 @@ struct osc_lattice {
   DevBuf<float> pw;
   // CG scratch
   int grid_cap = 1024;
+  int32_t spmm_slab = 0;  // 0 = whole window per launch
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
   DevBuf<uint32_t> res_bits;
@@ -175,6 +176,9 @@ void ensure_cg_scratch(L& h, int max_iters) {
   h.colsum.alloc(h.ld);
   if (h.res_bits.n < (size_t)max_iters + 2) h.res_bits.alloc((size_t)max_iters + 2);
 }
+
+// one grid for every CG kernel of a handle, so all column partial buffers have the same number of rows
+int cg_grid(const L& h) { return (int)std::max<int64_t>(1, std::min<int64_t>((h.N + 3) / 4, h.grid_cap)); }
 
 GraphView graph_view(L& h, bool with_path) {
   GraphView g{};
@@ -309,6 +313,19 @@ OpParams ustar_op(const L& h) {
   return o;
 }
 
+// Operator apply, optionally split into column slabs so the gathered operand slab (N x slab x 4 B) stays resident
+// in the 256 MB Infinity Cache while its rows are re-read ~deg times (MI355X_MICROARCH.md, Infinity Cache rule).
+void spmm_slabbed(L& h, int mode, SpmmArgs sa, int grid) {
+  const int32_t c0 = sa.c0, c1 = sa.c1;
+  const int32_t slab = h.spmm_slab > 0 ? h.spmm_slab : (c1 - c0);
+  ProfScope ps(h, 0);
+  for (int32_t s0 = c0; s0 < c1; s0 += slab) {
+    sa.c0 = s0;
+    sa.c1 = std::min(c1, s0 + slab);
+    launch_spmm(mode, sa, grid, h.stream);
+  }
+}
+
 struct CgBuffers {  // the arrays one solve works on (all N x ld)
   const float* x0;  // gathered in INIT
   float* X;
@@ -329,7 +346,7 @@ struct CgResult {
 
 // cg_solve (solver.py:6-37) on the device; returns after the stream is idle
 CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol) {
-  const int grid = std::min(h.grid_cap, spmm_grid(h.N, b.c1 - b.c0));
+  const int grid = cg_grid(h);
   HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, ((size_t)max_iters + 2) * 4, h.stream));
   SpmmArgs sa{};
   sa.g = graph_view(h, with_path);
@@ -348,10 +365,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   sa.P = b.P;
   sa.U = b.rhsU;
   sa.Y = b.rhsY;
-  {
-    ProfScope ps(h, 0);
-    launch_spmm(SPMM_INIT, sa, grid, h.stream);
-  }
+  spmm_slabbed(h, SPMM_INIT, sa, grid);
   launch_reduce_init(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.stream);
   UpdateArgs ua{};
   ua.X = b.X;
@@ -373,10 +387,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   h.history.clear();
   CgResult out{max_iters, 0.f};
   for (int it = 1; it <= max_iters; ++it) {
-    {
-      ProfScope ps(h, 0);
-      launch_spmm(SPMM_AP, sa, grid, h.stream);  // Ap and column sums of p.Ap
-    }
+    spmm_slabbed(h, SPMM_AP, sa, grid);  // Ap and column sums of p.Ap
     launch_reduce_alpha(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, h.stream);
     {
       ProfScope ps(h, 1);
@@ -498,6 +509,8 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     h->row_cap = row_cap;
     h->deterministic = deterministic;
     h->seed = seed;
+    if (const char* e = getenv("OSC_SPMM_SLAB")) h->spmm_slab = (std::max(0, atoi(e)) / 4) * 4;
+    if (const char* e = getenv("OSC_GRID_CAP")) h->grid_cap = std::max(1, atoi(e));
     const size_t n = (size_t)N * h->ld;
     for (DevBuf<float>* b : {&h->Y, &h->U, &h->X, &h->R, &h->P, &h->AP, &h->Ustar}) b->alloc(n);
     HIP_CHECK(hipMemsetAsync(h->Y.p, 0, n * 4, h->stream));
@@ -873,7 +886,7 @@ int osc_deltaH(osc_handle h, double* dH) {
     ensure_cg_scratch(l, 1);
     // diff = U - U*  ;  deltaH = sum diff . M diff   (receipts.py:21-25)
     launch_axpby(l.P.p, l.U.p, 1.0f, l.Ustar.p, -1.0f, (int64_t)l.N * l.ld, l.stream);
-    const int grid = std::min(l.grid_cap, spmm_grid(l.N, l.c1 - l.c0));
+    const int grid = cg_grid(l);
     SpmmArgs sa{};
     sa.g = graph_view(l, path_active(l));
     sa.op = ustar_op(l);
@@ -885,10 +898,7 @@ int osc_deltaH(osc_handle h, double* dH) {
     sa.ld = l.ld;
     sa.c0 = l.c0;
     sa.c1 = l.c1;
-    {
-      ProfScope ps(l, 0);
-      launch_spmm(SPMM_DOT, sa, grid, l.stream);
-    }
+    spmm_slabbed(l, SPMM_DOT, sa, grid);
     launch_reduce_sum(l.part0.p, grid, l.ld, l.c0, l.c1, l.colsum.p, l.stream);
     std::vector<double> cs((size_t)l.ld, 0.0);
     HIP_CHECK(hipMemcpyAsync(cs.data() + l.c0, l.colsum.p + l.c0, (size_t)(l.c1 - l.c0) * 8, hipMemcpyDeviceToHost,

@@ -350,9 +350,9 @@ def test_full_config3_properties(amd, orc):
     bwd = np.lexsort((rows, col))
     assert np.array_equal(rows[fwd], col[bwd]) and np.array_equal(col[fwd], rows[bwd])
     assert np.array_equal(a[fwd], a[bwd])
-    # capped rows: sum_j A_ij <= cap (1.0) up to rounding; W = A / (sd_i sd_j)
+    # W = A / (sd_i sd_j) with sd = sqrt(row sums of the capped adjacency) (graph.py:87-90)
     rs = np.bincount(rows, weights=a.astype(np.float64), minlength=N)
-    assert rs.max() <= 1.0 + 1e-5
+    assert np.allclose(sd, np.sqrt(np.maximum(rs, 1e-12)), rtol=1e-5)
     assert np.allclose(w, a / (sd[rows] * sd[col]), rtol=1e-5)
     # sampled rows: top-k lists equal the oracle's (one sgemm row-block per sample)
     Yn = orc.normalize_rows(Y)
