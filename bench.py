@@ -124,6 +124,7 @@ def main():
     bytes_mv = 8.0 * N * d_local + 8.0 * nnz + 12.0 * N
     mv_ms = total_ms.value / max(1, launches.value)
     achieved = bytes_mv / (mv_ms * 1e-3) / 1e9 if mv_ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(N, D, k, world)
 
     out = {
         "metric": "settles/sec",
@@ -145,7 +146,8 @@ def main():
         "graph_build_ms": graph_build_ms,
         "graph_build_device_ms": dev_build_ms,
         "roofline": {"bound": "hbm", "kernel": "k_spmm (operator apply / CG matvec)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_mv, "mean_launch_ms": mv_ms,
                      "launches": int(launches.value)},
     }
@@ -157,6 +159,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(N, D, k, world):
+    """HBM bytes per operator-apply launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; gfx950
+    read-side x2 correction applied by scripts/summarize_profile.py).  Only valid for the profiled workload."""
+    if (N, D, k, world) != (100_000, 768, 32, 1):
+        return None, None
+    for tag in ("r01",):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
+        if os.path.exists(path):
+            e = json.load(open(path)).get("k_spmm<64, 3, 0>")
+            if e and "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
+                return e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"], f"profiles/{tag}_pmc.json"
+    return None, None
 
 
 def cpu_baseline(lat, Y, psi, args):
