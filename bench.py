@@ -56,7 +56,8 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run
+    if launched:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -76,7 +77,7 @@ def main():
     nnz, max_deg, dev_build_ms = lat.graph_stats()
     lat.set_query(psi)
 
-    if world > 1:  # bootstrap the library's own RCCL communicator: rank 0 makes the id, torch broadcasts it
+    if launched:  # bootstrap the library's own RCCL communicator: rank 0 makes the id, torch broadcasts it
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             buf = C.create_string_buffer(128)
@@ -88,7 +89,7 @@ def main():
     def sync_all():
         nat.lib().osc_device_synchronize(local_rank)
         torch.cuda.synchronize()
-        if world > 1:
+        if launched:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -108,7 +109,7 @@ def main():
         iters_total += last["iters"]
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if launched:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -156,7 +157,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(lat, Y, psi, args)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
   constexpr int CPW = NCH * LPR * 4;
   constexpr int U = Unroll<NCH>::U;
   __shared__ __attribute__((aligned(16))) float red[4 * CPW];
+  if (a.gate != nullptr && *a.gate <= a.gate_tol) return;  // converged earlier: speculative launch is a no-op
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, lr = lane % LPR;
   const int32_t ld = a.ld;
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
   constexpr int RPW = 64 / LPR;
   constexpr int CPW = NCH * LPR * 4;
   __shared__ __attribute__((aligned(16))) float red[4 * CPW];
+  if (a.gate != nullptr && *a.gate <= a.gate_tol) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, lr = lane % LPR;
   const int32_t ld = a.ld;
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
 template <int LPR, int NCH>
 __global__ __launch_bounds__(256) void k_update_p(const UpdateArgs a) {
   constexpr int RPW = 64 / LPR;
+  if (a.gate != nullptr && *a.gate <= a.gate_tol) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, lr = lane % LPR;
   const int32_t ld = a.ld;
@@ -301,7 +304,22 @@ __device__ __forceinline__ bool reduce_cols(const float* p0, const float* p1, in
 #pragma unroll
   for (int i = 0; i < NIN; ++i) s[i] = 0.0;
   if (ok) {
-    for (int b = g; b < nb; b += 16) {
+    // 8 independent loads in flight per input: the loop is latency-bound, not bandwidth-bound
+    int b = g;
+    for (; b + 7 * 16 < nb; b += 8 * 16) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v0[u] = p0[(size_t)(b + 16 * u) * ld + col];
+        if (NIN > 1) v1[u] = p1[(size_t)(b + 16 * u) * ld + col];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s[0] += (double)v0[u];
+        if (NIN > 1) s[NIN - 1] += (double)v1[u];
+      }
+    }
+    for (; b < nb; b += 16) {
       s[0] += (double)p0[(size_t)b * ld + col];
       if (NIN > 1) s[NIN - 1] += (double)p1[(size_t)b * ld + col];
     }
@@ -329,7 +347,8 @@ __global__ __launch_bounds__(1024) void k_reduce_init(const float* part, int nb,
 }
 
 __global__ __launch_bounds__(1024) void k_reduce_alpha(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1,
-                                                       const double* rz, float* alpha) {
+                                                       const double* rz, float* alpha, Gate gt) {
+  if (gt.p != nullptr && *gt.p <= gt.tol) return;
   double t[1];
   int col;
   if (reduce_cols<1>(part, nullptr, nb, ld, c0, c1, t, col))
@@ -338,7 +357,8 @@ __global__ __launch_bounds__(1024) void k_reduce_alpha(const float* part, int nb
 
 __global__ __launch_bounds__(1024) void k_reduce_beta(const float* part_rr, const float* part_rz, int nb, int32_t ld,
                                                       int32_t c0, int32_t c1, double* rz, float* beta,
-                                                      uint32_t* res_bits) {
+                                                      uint32_t* res_bits, Gate gt) {
+  if (gt.p != nullptr && *gt.p <= gt.tol) return;
   double t[2];
   int col;
   const bool w = reduce_cols<2>(part_rr, part_rz, nb, ld, c0, c1, t, col);
@@ -443,14 +463,14 @@ void launch_reduce_init(const float* part, int nb, int32_t ld, int32_t c0, int32
   HIP_CHECK(hipGetLastError());
 }
 void launch_reduce_alpha(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, const double* rz, float* alpha,
-                         hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_alpha, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part, nb, ld, c0, c1, rz, alpha);
+                         Gate g, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_alpha, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part, nb, ld, c0, c1, rz, alpha, g);
   HIP_CHECK(hipGetLastError());
 }
 void launch_reduce_beta(const float* part_rr, const float* part_rz, int nb, int32_t ld, int32_t c0, int32_t c1,
-                        double* rz, float* beta, uint32_t* res_bits_slot, hipStream_t s) {
+                        double* rz, float* beta, uint32_t* res_bits_slot, Gate g, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_beta, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part_rr, part_rz, nb, ld, c0, c1, rz,
-                     beta, res_bits_slot);
+                     beta, res_bits_slot, g);
   HIP_CHECK(hipGetLastError());
 }
 void launch_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols, hipStream_t s) {

@@ -89,6 +89,10 @@ struct SpmmArgs {
   int64_t N;
   int32_t ld;         // row pitch in floats (multiple of 4)
   int32_t c0, c1;     // column window [c0, c1), multiples of 4
+  // speculative-launch gate: the kernel is a no-op when *gate <= gate_tol (the CG already converged; the host
+  // enqueues one iteration ahead of its residual read-back).  nullptr = always run.
+  const float* gate;
+  float gate_tol;
 };
 
 struct UpdateArgs {
@@ -104,6 +108,13 @@ struct UpdateArgs {
   OpParams op;
   int64_t N;
   int32_t ld, c0, c1;
+  const float* gate;  // see SpmmArgs
+  float gate_tol;
+};
+
+struct Gate {
+  const float* p;
+  float tol;
 };
 
 // launchers implemented in cg_kernels.hip
@@ -114,9 +125,9 @@ void launch_update_p(const UpdateArgs& a, int grid, hipStream_t s);
 // column reductions over `nb` partial rows
 void launch_reduce_init(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* rz, hipStream_t s);
 void launch_reduce_alpha(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, const double* rz,
-                         float* alpha, hipStream_t s);
+                         float* alpha, Gate g, hipStream_t s);
 void launch_reduce_beta(const float* part_rr, const float* part_rz, int nb, int32_t ld, int32_t c0, int32_t c1,
-                        double* rz, float* beta, uint32_t* res_bits_slot, hipStream_t s);
+                        double* rz, float* beta, uint32_t* res_bits_slot, Gate g, hipStream_t s);
 void launch_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols,
                        hipStream_t s);
 void launch_axpby(float* out, const float* a, float ca, const float* b, float cb, int64_t n, hipStream_t s);

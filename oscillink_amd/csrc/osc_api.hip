@@ -24,6 +24,7 @@ thread_local std::string g_create_error;
 struct ProfSlot {
   hipEvent_t a, b;
   int which;
+  int iter;  // CG iteration the launch belongs to (0 = not part of a CG loop); speculative no-ops are dropped
 };
 
 struct Invalid : std::runtime_error {
@@ -82,11 +83,15 @@ struct osc_lattice {
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
   DevBuf<uint32_t> res_bits;
+  float* res_host = nullptr;  // pinned mirror of res_bits for the per-iteration read-back
+  size_t res_host_n = 0;
+  std::vector<hipEvent_t> iter_events;
   std::vector<float> history;
   // column shard (multi-GPU, column-sharded CG); single GPU: [0, ld)
   int32_t c0 = 0, c1 = 0;
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  bool u_sharded = false;  // U holds only this rank's columns (after a sharded settle)
   DevBuf<float> comm_buf;
   // profiling
   bool prof_on = false;
@@ -102,6 +107,8 @@ struct osc_lattice {
       (void)hipEventDestroy(s.b);
     }
     for (auto e : prof_pool) (void)hipEventDestroy(e);
+    for (auto e : iter_events) (void)hipEventDestroy(e);
+    if (res_host) (void)hipHostFree(res_host);
     if (comm) (void)ncclCommDestroy(comm);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -126,8 +133,10 @@ void prof_drain(L& h) {
     HIP_CHECK(hipEventSynchronize(s.b));
     float ms = 0.f;
     HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));
-    h.prof_count[s.which] += 1;
-    h.prof_ms[s.which] += ms;
+    if (s.which >= 0) {
+      h.prof_count[s.which] += 1;
+      h.prof_ms[s.which] += ms;
+    }
     h.prof_pool.push_back(s.a);
     h.prof_pool.push_back(s.b);
   }
@@ -137,9 +146,10 @@ struct ProfScope {
   L& h;
   ProfSlot s{};
   bool on;
-  ProfScope(L& h_, int which) : h(h_), on(h_.prof_on) {
+  ProfScope(L& h_, int which, int iter = 0) : h(h_), on(h_.prof_on) {
     if (on) {
       s.which = which;
+      s.iter = iter;
       s.a = prof_event(h);
       s.b = prof_event(h);
       HIP_CHECK(hipEventRecord(s.a, h.stream));
@@ -315,10 +325,22 @@ OpParams ustar_op(const L& h) {
 
 // Operator apply, optionally split into column slabs so the gathered operand slab (N x slab x 4 B) stays resident
 // in the 256 MB Infinity Cache while its rows are re-read ~deg times (MI355X_MICROARCH.md, Infinity Cache rule).
-void spmm_slabbed(L& h, int mode, SpmmArgs sa, int grid) {
+int32_t auto_slab(const L& h, int32_t ncols) {
+  if (h.spmm_slab > 0) return h.spmm_slab;
+  if (h.spmm_slab < 0) return ncols;  // OSC_SPMM_SLAB=-1: never split
+  // keep the gathered slab (N x slab x 4 B) around 50 MB so it and the streams beside it stay inside 256 MB
+  const double budget = 56.0 * 1024 * 1024;
+  if ((double)h.N * ncols * 4.0 <= 2.0 * budget) return ncols;
+  int32_t slab = 64;
+  for (int32_t w : {128, 256, 384, 512, 768, 1024, 2048})
+    if ((double)h.N * w * 4.0 <= budget) slab = w;
+  return slab;
+}
+
+void spmm_slabbed(L& h, int mode, SpmmArgs sa, int grid, int iter = 0) {
   const int32_t c0 = sa.c0, c1 = sa.c1;
-  const int32_t slab = h.spmm_slab > 0 ? h.spmm_slab : (c1 - c0);
-  ProfScope ps(h, 0);
+  const int32_t slab = auto_slab(h, c1 - c0);
+  ProfScope ps(h, 0, iter);
   for (int32_t s0 = c0; s0 < c1; s0 += slab) {
     sa.c0 = s0;
     sa.c1 = std::min(c1, s0 + slab);
@@ -344,10 +366,26 @@ struct CgResult {
   float res;
 };
 
-// cg_solve (solver.py:6-37) on the device; returns after the stream is idle
+// cg_solve (solver.py:6-37) on the device; returns after the stream is idle.
+// The host enqueues iteration it+1 before it reads iteration it's residual; every kernel of a speculative iteration
+// carries a gate (residual of the previous iteration, tol) and is a no-op once the CG has converged, so the
+// reference's "stop before the beta/p update" semantics hold exactly while the stream never drains between
+// iterations.
 CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol) {
   const int grid = cg_grid(h);
   HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, ((size_t)max_iters + 2) * 4, h.stream));
+  if (h.res_host_n < (size_t)max_iters + 2) {
+    if (h.res_host) (void)hipHostFree(h.res_host);
+    h.res_host = nullptr;
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h.res_host), ((size_t)max_iters + 2) * 4, hipHostMallocDefault));
+    h.res_host_n = (size_t)max_iters + 2;
+  }
+  while (h.iter_events.size() < (size_t)max_iters + 2) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h.iter_events.push_back(e);
+  }
+  const float* res_dev = reinterpret_cast<const float*>(h.res_bits.p);
   SpmmArgs sa{};
   sa.g = graph_view(h, with_path);
   sa.op = op;
@@ -365,6 +403,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   sa.P = b.P;
   sa.U = b.rhsU;
   sa.Y = b.rhsY;
+  sa.gate = nullptr;
   spmm_slabbed(h, SPMM_INIT, sa, grid);
   launch_reduce_init(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.stream);
   UpdateArgs ua{};
@@ -384,36 +423,75 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   ua.c1 = b.c1;
   sa.X = b.P;
   sa.OUT = b.AP;
-  h.history.clear();
-  CgResult out{max_iters, 0.f};
-  for (int it = 1; it <= max_iters; ++it) {
-    spmm_slabbed(h, SPMM_AP, sa, grid);  // Ap and column sums of p.Ap
-    launch_reduce_alpha(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, h.stream);
+
+  auto enqueue_iter = [&](int it) {  // everything of iteration `it` up to its residual, gated on iteration it-1
+    const Gate g{it > 1 ? res_dev + (it - 1) : nullptr, tol};
+    sa.gate = g.p;
+    sa.gate_tol = tol;
+    ua.gate = g.p;
+    ua.gate_tol = tol;
+    if (it > 1) {
+      ProfScope ps(h, 2, it);
+      launch_update_p(ua, grid, h.stream);  // p = z + beta p of iteration it-1 (solver.py:32-36)
+    }
+    spmm_slabbed(h, SPMM_AP, sa, grid, it);  // Ap and column sums of p.Ap
+    launch_reduce_alpha(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
     {
-      ProfScope ps(h, 1);
+      ProfScope ps(h, 1, it);
       launch_update_xr(ua, grid, h.stream);
     }
-    launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, h.stream);
-    float res = 0.f;
+    launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream);
     if (h.comm) {  // column-sharded: the stop test is the max over all shards (solver.py:29)
       if (ncclAllReduce(h.res_bits.p + it, h.res_bits.p + it, 1, ncclFloat, ncclMax, h.comm, h.stream) != ncclSuccess)
         throw CommError("ncclAllReduce(max residual) failed");
     }
-    HIP_CHECK(hipMemcpyAsync(&res, h.res_bits.p + it, 4, hipMemcpyDeviceToHost, h.stream));
-    sync(h);
+    HIP_CHECK(hipMemcpyAsync(h.res_host + it, h.res_bits.p + it, 4, hipMemcpyDeviceToHost, h.stream));
+    HIP_CHECK(hipEventRecord(h.iter_events[(size_t)it], h.stream));
+  };
+
+  h.history.clear();
+  CgResult out{max_iters, 0.f};
+  const size_t prof_mark = h.prof_pending.size();
+  enqueue_iter(1);
+  for (int it = 1; it <= max_iters; ++it) {
+    if (it < max_iters) enqueue_iter(it + 1);  // speculative: no-ops if iteration `it` converged
+    HIP_CHECK(hipEventSynchronize(h.iter_events[(size_t)it]));
+    const float res = h.res_host[it];
     h.history.push_back(res);
     out.res = res;
     if ((double)res <= (double)tol) {
       out.iters = it;
       break;
     }
-    if (it < max_iters) {
-      ProfScope ps(h, 2);
-      launch_update_p(ua, grid, h.stream);
-    }
   }
   sync(h);
+  for (size_t i = prof_mark; i < h.prof_pending.size(); ++i)  // speculative (gated-off) launches are not samples
+    if (h.prof_pending[i].iter > out.iters) h.prof_pending[i].which = -1;
   return out;
+}
+
+// Column-sharded runs: every rank owns columns [c0, c1) of an N x ld array.  Make the whole array valid on every
+// rank: one ncclBroadcast of each rank's packed slab (slab widths may differ by 4 columns, so not an all-gather).
+// Collective: every rank must call it.
+void gather_columns(L& h, float* arr) {
+  if (!h.comm || h.world <= 1) return;
+  const int32_t q = h.ld / 4;
+  int32_t wmax = 0;
+  for (int r = 0; r < h.world; ++r) wmax = std::max(wmax, (int32_t)(((int64_t)q * (r + 1) / h.world - (int64_t)q * r / h.world) * 4));
+  h.comm_buf.alloc((size_t)h.N * wmax);
+  for (int r = 0; r < h.world; ++r) {
+    const int32_t lo = (int32_t)((int64_t)q * r / h.world) * 4, hi = (int32_t)((int64_t)q * (r + 1) / h.world) * 4;
+    const int32_t w = hi - lo;
+    if (w <= 0) continue;
+    if (r == h.rank)
+      HIP_CHECK(hipMemcpy2DAsync(h.comm_buf.p, (size_t)w * 4, arr + lo, (size_t)h.ld * 4, (size_t)w * 4, (size_t)h.N,
+                                 hipMemcpyDeviceToDevice, h.stream));
+    if (ncclBroadcast(h.comm_buf.p, h.comm_buf.p, (size_t)h.N * w, ncclFloat, r, h.comm, h.stream) != ncclSuccess)
+      throw CommError("ncclBroadcast(column slab) failed");
+    if (r != h.rank)
+      HIP_CHECK(hipMemcpy2DAsync(arr + lo, (size_t)h.ld * 4, h.comm_buf.p, (size_t)w * 4, (size_t)w * 4, (size_t)h.N,
+                                 hipMemcpyDeviceToDevice, h.stream));
+  }
 }
 
 void require_graph(L& h) {
@@ -509,7 +587,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     h->row_cap = row_cap;
     h->deterministic = deterministic;
     h->seed = seed;
-    if (const char* e = getenv("OSC_SPMM_SLAB")) h->spmm_slab = (std::max(0, atoi(e)) / 4) * 4;
+    if (const char* e = getenv("OSC_SPMM_SLAB")) h->spmm_slab = atoi(e) < 0 ? -1 : (atoi(e) / 4) * 4;
     if (const char* e = getenv("OSC_GRID_CAP")) h->grid_cap = std::max(1, atoi(e));
     const size_t n = (size_t)N * h->ld;
     for (DevBuf<float>* b : {&h->Y, &h->U, &h->X, &h->R, &h->P, &h->AP, &h->Ustar}) b->alloc(n);
@@ -731,6 +809,10 @@ int osc_set_lams(osc_handle h, float lamG, float lamC, float lamQ) {
 int osc_get_U(osc_handle h, float* out) {
   return guarded(h, [&](L& l) {
     if (!out) throw Invalid("osc_get_U: out is NULL");
+    if (l.u_sharded) {  // collective in column-sharded runs
+      gather_columns(l, l.U.p);
+      l.u_sharded = false;
+    }
     download_rows(l, out, l.U.p);
     sync(l);
   });
@@ -740,6 +822,7 @@ int osc_set_U(osc_handle h, const float* U) {
   return guarded(h, [&](L& l) {
     if (U) upload_rows(l, l.U.p, U);
     else HIP_CHECK(hipMemcpyAsync(l.U.p, l.Y.p, (size_t)l.N * l.ld * 4, hipMemcpyDeviceToDevice, l.stream));
+    l.u_sharded = false;
     sync(l);
   });
 }
@@ -768,6 +851,10 @@ int osc_settle(osc_handle h, float dt, int32_t max_iters, float tol, int32_t pre
     // when x0 aliases AP the INIT pass reads it completely before the first SPMM_AP launch writes AP: same stream
     const CgResult r = run_cg(l, op, b, path_active(l), max_iters, tol);
     l.U.swap(l.X);  // U <- U+ (lattice.py:206)
+    if (l.comm && l.world > 1) {
+      // the swapped-in buffer only holds this rank's columns; the others are refreshed lazily by osc_get_U.
+      l.u_sharded = true;
+    }
     if (ms) *ms = now_ms() - t0;
     if (iters) *iters = r.iters;
     if (res) *res = r.res;
@@ -786,6 +873,7 @@ int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out
     CgBuffers b{l.Y.p, l.X.p, l.R.p, l.P.p, l.AP.p, l.U.p, l.Y.p, l.B.p, l.psi.p, l.ld, l.c0, l.c1};
     const CgResult r = run_cg(l, op, b, path_active(l), max_iters, tol);
     l.Ustar.swap(l.X);
+    gather_columns(l, l.Ustar.p);  // receipts read whole rows of U*
     l.have_ustar = true;
     if (ms) *ms = now_ms() - t0;
     if (iters) *iters = r.iters;
@@ -898,6 +986,7 @@ int osc_deltaH(osc_handle h, double* dH) {
     sa.ld = l.ld;
     sa.c0 = l.c0;
     sa.c1 = l.c1;
+    sa.gate = nullptr;
     spmm_slabbed(l, SPMM_DOT, sa, grid);
     launch_reduce_sum(l.part0.p, grid, l.ld, l.c0, l.c1, l.colsum.p, l.stream);
     std::vector<double> cs((size_t)l.ld, 0.0);
@@ -1046,7 +1135,7 @@ int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world)
     l.c0 = lo * 4;
     l.c1 = hi * 4;
     if (l.c1 <= l.c0) throw Invalid("osc_comm_init: more ranks than 4-column groups");
-    if (world > 1) {
+    {
       ncclUniqueId uid;
       std::memcpy(&uid, id, 128);
       if (ncclCommInitRank(&l.comm, world, uid, rank) != ncclSuccess) throw CommError("ncclCommInitRank failed");
