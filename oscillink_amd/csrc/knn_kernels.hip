@@ -76,13 +76,19 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
   float* Bs = lds + BM * LDT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int rblk = blockIdx.x / S, split = blockIdx.x % S;
+  // XCD-aware item order: blocks b and b+8 share an XCD (round-robin dispatch), so XCD x = b % 8 walks row blocks
+  // x, x+8, ... and, for each, all S column splits back to back: the blocks resident on an XCD at one time share
+  // a few 393 KB query panels, which then stay in that XCD's 4 MB L2 across all their column tiles.
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int rblk = (jx / S) * 8 + xcd, split = jx % S;
+  if (rblk * BM >= N) return;
   const int row0 = rblk * BM;
   const int cbeg = split * cols_per_split;
   const int cend = min(N, cbeg + cols_per_split);
   const int nkt = ldn / BK;
 
-  // candidate lists: row R(g,h) of this wave lives in lv[g][*] across the 32 lanes of half h
+  // candidate lists, kept SORTED (similarity desc, index asc): rank r = (lane & 31) + 32 e of row R(g,h) lives in
+  // lv[g][e] of the lanes of half h.  thr[g] = similarity at rank k-1 (NEG until k candidates were seen).
   float lv[16][E];
   int li[16][E];
   float thr[16];
@@ -91,11 +97,12 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
     thr[g] = NEG;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const bool live = (l31 + 32 * e) < k;
-      lv[g][e] = live ? NEG : 3.0e38f;  // dead slots can never be the worst entry
+      lv[g][e] = NEG;
       li[g][e] = 0x7fffffff;
     }
   }
+  const int thr_lane = ((k - 1) & 31) + 32 * h;  // lane of this half holding rank k-1
+  const int thr_e = (k - 1) >> 5;
 
   // staging: 128 rows x 32 floats per operand tile = 1024 float4; thread owns 4 of each
   int srow[4], sc4[4];
@@ -174,57 +181,56 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
         if (need_mask && (ccol >= cend || ccol == grow)) c = NEG;  // graph.py:37 (diag = -inf) and the ragged tail
         bool pred = (c >= thr[g]) && (c > NEG);
         unsigned long long m = __ballot(pred);
-        while (m) {
+        while (m) {  // rare path: one candidate per half-wave per trip, exact sorted insert
           touched = true;
           const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
           const bool has = mh != 0u;
           const int srcl = has ? (__ffs(mh) - 1) : 0;
           const float cv = __shfl(c, srcl + 32 * h, 64);
           const int cc = ct + 32 * t + srcl;
-          // worst entry of this half's list for row g
-          float wv = lv[g][0];
-          int wi = li[g][0];
+          // insertion rank = number of list entries that beat the candidate
+          int p = 0;
 #pragma unroll
-          for (int e = 1; e < E; ++e)
-            if (worse(lv[g][e], li[g][e], wv, wi)) {
-              wv = lv[g][e];
-              wi = li[g][e];
-            }
-          int wl = lane;
-#pragma unroll
-          for (int o = 1; o < 32; o <<= 1) {
-            const float ov = __shfl_xor(wv, o, 64);
-            const int oi = __shfl_xor(wi, o, 64);
-            const int ol = __shfl_xor(wl, o, 64);
-            if (worse(ov, oi, wv, wi) || (ov == wv && oi == wi && ol < wl)) {
-              wv = ov;
-              wi = oi;
-              wl = ol;
-            }
+          for (int e = 0; e < E; ++e) {
+            const bool better = lv[g][e] > cv || (lv[g][e] == cv && li[g][e] < cc);
+            const unsigned long long bm = __ballot(better);
+            p += __popc(h ? (unsigned)(bm >> 32) : (unsigned)bm);
           }
-          const bool repl = has && (cv > wv || (cv == wv && cc < wi));
-          if (repl && lane == wl) {
-            bool done = false;
+          if (!has) p = 1 << 20;
+          // shift ranks > p down by one (v_mov_dpp wave_shr:1; the rank-32e slot takes the carry of register e-1)
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-              if (!done && lv[g][e] == wv && li[g][e] == wi) {
-                lv[g][e] = cv;
-                li[g][e] = cc;
-                done = true;
+          for (int e = E - 1; e >= 0; --e) {
+            const int rank = l31 + 32 * e;
+            const float sv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lv[g][e]), 0x138, 0xf, 0xf, false));
+            const int si = __builtin_amdgcn_update_dpp(0, li[g][e], 0x138, 0xf, 0xf, false);
+            float inv = sv;
+            int ini = si;
+            if (e > 0) {
+              const float cvv = __shfl(lv[g][e - 1], 31 + 32 * h, 64);
+              const int cii = __shfl(li[g][e - 1], 31 + 32 * h, 64);
+              if (l31 == 0) {
+                inv = cvv;
+                ini = cii;
               }
+            }
+            if (rank > p) {
+              lv[g][e] = inv;
+              li[g][e] = ini;
+            } else if (rank == p) {
+              lv[g][e] = cv;
+              li[g][e] = cc;
             }
           }
           if (has && l31 == srcl) pred = false;
           m = __ballot(pred);
         }
       }
-      if (touched) {  // refresh the filter threshold = current worst similarity (NEG while the list is not full)
-        float wv = lv[g][0];
+      if (touched) {  // refresh the filter threshold = similarity at rank k-1
+        float src = lv[g][0];
 #pragma unroll
-        for (int e = 1; e < E; ++e) wv = fminf(wv, lv[g][e]);
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) wv = fminf(wv, __shfl_xor(wv, o, 64));
-        thr[g] = wv;
+        for (int e = 1; e < E; ++e)
+          if (thr_e == e) src = lv[g][e];
+        thr[g] = __shfl(src, thr_lane, 64);
       }
     }
   }
@@ -407,12 +413,13 @@ KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots) {
     if (S_eff != S) continue;
     const long items = (long)p.row_blocks * S;
     const long rounds = (items + slots - 1) / slots;
-    const double cost = (double)rounds * tiles_per * (1.0 + 0.012 * S);  // imbalance x (1 + warm-up overhead)
+    const double cost = (double)rounds * tiles_per * (1.0 + 0.004 * S);  // imbalance x (1 + list warm-up overhead)
     if (cost < best_cost) {
       best_cost = cost;
       best_S = S;
     }
   }
+  if (const char* e = getenv("OSC_KNN_SPLITS")) best_S = std::max(1, std::min(col_tiles, atoi(e)));
   p.S = best_S;
   p.cols_per_split = ((col_tiles + p.S - 1) / p.S) * BN;
   return p;
@@ -420,7 +427,7 @@ KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots) {
 
 void launch_knn_topk(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t N, int32_t k, float* cand_val,
                      int32_t* cand_idx, hipStream_t s) {
-  const dim3 grid((unsigned)(p.row_blocks * p.S)), block(256);
+  const dim3 grid((unsigned)(8 * ((p.row_blocks + 7) / 8) * p.S)), block(256);
   if (p.E == 1)
     hipLaunchKernelGGL(k_knn_topk<1>, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx);
   else if (p.E == 2)
