@@ -71,12 +71,7 @@ def main():
     psi = Y[:32].mean(axis=0)
     psi = (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
 
-    t0 = time.time()
-    lat = Oscillink(Y, kneighbors=k, deterministic_k=False, device=local_rank)
-    graph_build_ms = 1000.0 * (time.time() - t0)
-    nnz, max_deg, dev_build_ms = lat.graph_stats()
-    lat.set_query(psi)
-
+    comm = None
     if launched:  # bootstrap the library's own RCCL communicator: rank 0 makes the id, torch broadcasts it
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -84,7 +79,13 @@ def main():
             nat.check(nat.lib().osc_comm_unique_id(buf), None, "osc_comm_unique_id")
             uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
         dist.broadcast(uid, src=0)
-        lat._call("osc_comm_init", bytes(uid.cpu().numpy().tobytes()), rank, world)
+        comm = (uid.cpu().numpy().tobytes(), rank, world)
+
+    t0 = time.time()
+    lat = Oscillink(Y, kneighbors=k, deterministic_k=False, device=local_rank, comm=comm)
+    graph_build_ms = 1000.0 * (time.time() - t0)
+    nnz, max_deg, dev_build_ms = lat.graph_stats()
+    lat.set_query(psi)
 
     def sync_all():
         nat.lib().osc_device_synchronize(local_rank)

@@ -10,9 +10,11 @@ struct KnnPlan {
   int row_blocks;      // ceil(N / 128)
   int S;               // column splits
   int cols_per_split;  // multiple of 128
+  int rb_begin;        // first row block this process computes (multi-GPU: row-block-sharded build)
+  int rb_count;        // number of row blocks this process computes
 };
 
-KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots);
+KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots, int rb_begin = 0, int rb_count = -1);
 void launch_normalize_rows(const float* Y, int32_t ldy, float* Yn, int32_t ldn, int64_t N, int32_t D, hipStream_t s);
 void launch_rows_dot(const float* Yn, int32_t ldn, const float* q, float* out, int64_t N, int32_t D, hipStream_t s);
 void launch_knn_topk(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t N, int32_t k, float* cand_val,

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void k_rows_dot(const float* Yn, int32_t ldn, 
 // work item = (row block of 128, column split s of S).  cand_*: [N][S][32E]
 template <int E>
 __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k, int32_t S,
-                                              int32_t cols_per_split, float* cand_val, int32_t* cand_idx) {
+                                              int32_t cols_per_split, float* cand_val, int32_t* cand_idx,
+                                              int32_t rb_begin, int32_t rb_count) {
   __shared__ __attribute__((aligned(16))) float lds[2 * BM * LDT];
   float* As = lds;
   float* Bs = lds + BM * LDT;
@@ -80,8 +81,9 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
   // x, x+8, ... and, for each, all S column splits back to back: the blocks resident on an XCD at one time share
   // a few 393 KB query panels, which then stay in that XCD's 4 MB L2 across all their column tiles.
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int rblk = (jx / S) * 8 + xcd, split = jx % S;
-  if (rblk * BM >= N) return;
+  const int rloc = (jx / S) * 8 + xcd, split = jx % S;
+  const int rblk = rb_begin + rloc;
+  if (rloc >= rb_count || rblk * BM >= N) return;
   const int row0 = rblk * BM;
   const int cbeg = split * cols_per_split;
   const int cend = min(N, cbeg + cols_per_split);
@@ -254,24 +256,25 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
 template <int E>
 __global__ __launch_bounds__(256, 2) void k_knn_topk(const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k,
                                                      int32_t S, int32_t cols_per_split, float* cand_val,
-                                                     int32_t* cand_idx) {
-  knn_topk_body<E>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx);
+                                                     int32_t* cand_idx, int32_t rb_begin, int32_t rb_count) {
+  knn_topk_body<E>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count);
 }
 // k in (64, 128]: 128 list registers per lane -> one wave per SIMD with the whole 512-entry register file
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_knn_topk_wide(
     const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k, int32_t S, int32_t cols_per_split, float* cand_val,
-    int32_t* cand_idx) {
-  knn_topk_body<4>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx);
+    int32_t* cand_idx, int32_t rb_begin, int32_t rb_count) {
+  knn_topk_body<4>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count);
 }
 
 // one wave per row: rank-select the k best of the S*KC candidates -> sorted (sim desc, idx asc), clipped at 0
 __global__ __launch_bounds__(256) void k_knn_merge(const float* cand_val, const int32_t* cand_idx, int32_t ncand,
-                                                   int32_t N, int32_t k, float* out_val, int32_t* out_idx) {
+                                                   int32_t row_begin, int32_t N, int32_t k, float* out_val,
+                                                   int32_t* out_idx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* sv = reinterpret_cast<float*>(smem) + (size_t)wave * ncand;
   int32_t* si = reinterpret_cast<int32_t*>(smem + (size_t)4 * ncand * sizeof(float)) + (size_t)wave * ncand;
-  const int row = blockIdx.x * 4 + wave;
+  const int row = row_begin + blockIdx.x * 4 + wave;  // N = end of this process's row range
   if (row < N) {
     for (int c = lane; c < ncand; c += 64) {
       sv[c] = cand_val[(size_t)row * ncand + c];
@@ -397,11 +400,14 @@ void launch_rows_dot(const float* Yn, int32_t ldn, const float* q, float* out, i
   HIP_CHECK(hipGetLastError());
 }
 
-KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots) {
+KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots, int rb_begin, int rb_count) {
   KnnPlan p;
   p.E = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
   p.KC = 32 * p.E;
-  p.row_blocks = (N + BM - 1) / BM;
+  const int all_blocks = (N + BM - 1) / BM;
+  p.rb_begin = rb_begin;
+  p.rb_count = rb_count < 0 ? all_blocks : rb_count;
+  p.row_blocks = std::max(1, p.rb_count);
   const int col_tiles = (N + BN - 1) / BN;
   // choose the column split count S: enough work items to balance `slots` resident blocks, while keeping
   // the per-item list warm-up (k log) small.
@@ -427,13 +433,17 @@ KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots) {
 
 void launch_knn_topk(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t N, int32_t k, float* cand_val,
                      int32_t* cand_idx, hipStream_t s) {
-  const dim3 grid((unsigned)(8 * ((p.row_blocks + 7) / 8) * p.S)), block(256);
+  if (p.rb_count <= 0) return;
+  const dim3 grid((unsigned)(8 * ((p.rb_count + 7) / 8) * p.S)), block(256);
   if (p.E == 1)
-    hipLaunchKernelGGL(k_knn_topk<1>, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx);
+    hipLaunchKernelGGL(k_knn_topk<1>, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx,
+                       p.rb_begin, p.rb_count);
   else if (p.E == 2)
-    hipLaunchKernelGGL(k_knn_topk<2>, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx);
+    hipLaunchKernelGGL(k_knn_topk<2>, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx,
+                       p.rb_begin, p.rb_count);
   else
-    hipLaunchKernelGGL(k_knn_topk_wide, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx);
+    hipLaunchKernelGGL(k_knn_topk_wide, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx,
+                       p.rb_begin, p.rb_count);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -441,8 +451,10 @@ void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* ca
                       float* out_val, int32_t* out_idx, hipStream_t s) {
   const int ncand = p.S * p.KC;
   const size_t shmem = (size_t)4 * ncand * (sizeof(float) + sizeof(int32_t));
-  hipLaunchKernelGGL(k_knn_merge, dim3((unsigned)((N + 3) / 4)), dim3(256), shmem, s, cand_val, cand_idx, ncand, N, k,
-                     out_val, out_idx);
+  const int row_begin = p.rb_begin * BM, row_end = std::min(N, (p.rb_begin + p.rb_count) * BM);
+  if (row_end <= row_begin) return;
+  hipLaunchKernelGGL(k_knn_merge, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), shmem, s, cand_val,
+                     cand_idx, ncand, row_begin, row_end, k, out_val, out_idx);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -262,22 +262,43 @@ void build_graph(L& h) {
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, h.device));
   const int slots = prop.multiProcessorCount * (k <= 64 ? 2 : 1);
-  const KnnPlan plan = knn_plan(N, k, slots);
+  // multi-GPU: row-block-sharded build -- this rank computes the top-k lists of its 128-row blocks against all
+  // columns, then one all-gather of the (idx, sim) lists; mutual test / cap / Laplacian weights run on every rank.
+  const int all_rb = (N + 127) / 128;
+  // OSC_KNN_FAKE_SHARDS=G (test hook): run the G per-rank passes of a sharded build one after another on this GPU
+  int fake = 0;
+  if (const char* e = getenv("OSC_KNN_FAKE_SHARDS")) fake = std::max(0, atoi(e));
+  const bool sharded = h.comm != nullptr && h.world > 1;
+  const int parts = sharded ? h.world : (fake > 1 ? fake : 1);
+  const int rb_per = (all_rb + parts - 1) / parts;
+  const size_t list_rows = parts > 1 ? (size_t)rb_per * 128 * parts : (size_t)h.N;
+  h.knn_val.alloc(list_rows * k);
+  h.knn_idx.alloc(list_rows * k);
+  h.knn_k = k;
+  HIP_CHECK(hipMemsetAsync(h.knn_val.p, 0, list_rows * k * 4, h.stream));
+  HIP_CHECK(hipMemsetAsync(h.knn_idx.p, 0xFF, list_rows * k * 4, h.stream));
   DevBuf<float> cand_val;
   DevBuf<int32_t> cand_idx;
-  const size_t ncand = (size_t)h.N * plan.S * plan.KC;
-  cand_val.alloc(ncand);
-  cand_idx.alloc(ncand);
-  {
-    ProfScope ps(h, 3);
-    launch_knn_topk(plan, Yn.p, ldn, N, k, cand_val.p, cand_idx.p, h.stream);
+  for (int part = 0; part < parts; ++part) {
+    if (sharded && part != h.rank) continue;
+    const int rb_begin = std::min(all_rb, part * rb_per);
+    const int rb_count = std::max(0, std::min(rb_per, all_rb - rb_begin));
+    const KnnPlan plan = knn_plan(N, k, slots, rb_begin, rb_count);
+    const size_t ncand = (size_t)h.N * plan.S * plan.KC;
+    cand_val.alloc(ncand);
+    cand_idx.alloc(ncand);
+    {
+      ProfScope ps(h, 3);
+      launch_knn_topk(plan, Yn.p, ldn, N, k, cand_val.p, cand_idx.p, h.stream);
+    }
+    launch_knn_merge(plan, cand_val.p, cand_idx.p, N, k, h.knn_val.p, h.knn_idx.p, h.stream);
   }
-  h.knn_val.alloc((size_t)h.N * k);
-  h.knn_idx.alloc((size_t)h.N * k);
-  h.knn_k = k;
-  HIP_CHECK(hipMemsetAsync(h.knn_val.p, 0, (size_t)h.N * k * 4, h.stream));
-  HIP_CHECK(hipMemsetAsync(h.knn_idx.p, 0xFF, (size_t)h.N * k * 4, h.stream));
-  launch_knn_merge(plan, cand_val.p, cand_idx.p, N, k, h.knn_val.p, h.knn_idx.p, h.stream);
+  if (sharded) {
+    const size_t cnt = (size_t)rb_per * 128 * k;  // equal chunk per rank, in place
+    if (ncclAllGather(h.knn_val.p + (size_t)h.rank * cnt, h.knn_val.p, cnt, ncclFloat, h.comm, h.stream) != ncclSuccess ||
+        ncclAllGather(h.knn_idx.p + (size_t)h.rank * cnt, h.knn_idx.p, cnt, ncclInt32, h.comm, h.stream) != ncclSuccess)
+      throw CommError("ncclAllGather(kNN lists) failed");
+  }
   alloc_ell(h, k);
   launch_mutual_ell(h.knn_val.p, h.knn_idx.p, N, k, h.width, h.ell_col.p, h.ell_a.p, h.deg.p, h.stream);
   DevBuf<float> scale;

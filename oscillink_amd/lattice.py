@@ -44,6 +44,7 @@ class OscillinkLattice:
         neighbor_seed: Optional[int] = None,
         *,
         device: Optional[int] = None,
+        comm: Optional[tuple] = None,
         _build_graph: bool = True,
     ):
         if not isinstance(Y, np.ndarray) or Y.ndim != 2:
@@ -72,11 +73,21 @@ class OscillinkLattice:
             raise nat.NativeError("no HIP device visible: oscillink_amd runs on MI355X (gfx950) only, no CPU fallback")
         h = nat.Handle()
         t0 = time.time()
+        # comm = (ncclUniqueId bytes, rank, world): one process per GPU.  The graph is then built row-block-sharded
+        # (all-gather of the top-k lists) and the CG runs column-sharded (one all-reduce(max) per iteration).
+        build_now = bool(_build_graph) and comm is None
         rc = L.osc_create(nat.f32(self.Y), self.N, self.D, k_eff, self._row_cap_val, int(self._deterministic_k),
-                          -1 if neighbor_seed is None else int(neighbor_seed), self._device, int(bool(_build_graph)),
+                          -1 if neighbor_seed is None else int(neighbor_seed), self._device, int(build_now),
                           C.byref(h))
         nat.check(rc, None, "osc_create")
         self._h = h
+        if comm is not None:
+            uid, rank, world = comm
+            nat.check(L.osc_comm_init(h, bytes(uid), int(rank), int(world)), h, "osc_comm_init")
+            if _build_graph:
+                nat.check(L.osc_rebuild_graph(h, k_eff, self._row_cap_val, int(self._deterministic_k),
+                                              -1 if neighbor_seed is None else int(neighbor_seed)), h,
+                          "osc_rebuild_graph")
         self._graph_build_ms = 1000.0 * (time.time() - t0)
 
         self._B = np.ones(self.N, dtype=np.float32)

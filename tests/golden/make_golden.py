@@ -136,6 +136,11 @@ def run_case(name, *, N, D, k, gen, psi_mode, chain=None, lamP=0.2, gates=None, 
     )
     if g is not None:
         out["gates"] = g
+    if detail == "full":
+        bd = lat.bundle(k=6, alpha=0.5)
+        out["bundle_ids"] = np.array([b["id"] for b in bd], dtype=np.int32)
+        out["bundle_score"] = np.array([b["score"] for b in bd], dtype=np.float64)
+        out["bundle_align"] = np.array([b["align"] for b in bd], dtype=np.float64)
     if store_U:
         out["U"] = lat.U.astype(np.float32)
         out["Ustar"] = Ustar.astype(np.float32)

@@ -172,6 +172,21 @@ def test_reference_recorded_perf_snapshot_on_device(amd):
     assert cr["weakest_link"]["zscore"] == pytest.approx(ka["weakest_link"]["zscore"], rel=1e-3)
 
 
+@pytest.mark.parametrize("name", ["c1_n80_d128_k8", "g1_n400_d64_k6_chain8", "gates_chain_n333_d50_k7"])
+def test_bundle_matches_fixture(amd, name):
+    """bundle() (lattice.py:530-568): z(coherence drop) + alignment score, MMR-diversified over Y."""
+    case = load_case(name)
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=True)
+    _configure(lat, case, rc, psi)
+    lat.settle(max_iters=rc["settle_max_iters"], tol=rc["settle_tol"])
+    bd = lat.bundle(k=6, alpha=0.5)
+    assert [b["id"] for b in bd] == case["bundle_ids"].tolist()
+    assert np.allclose([b["score"] for b in bd], case["bundle_score"], rtol=1e-3, atol=1e-4)
+    assert np.allclose([b["align"] for b in bd], case["bundle_align"], rtol=1e-3, atol=1e-5)
+
+
 def test_chain_receipt_matches_fixture(amd):
     case = load_case("g1_n400_d64_k6_chain8")
     rc = case["recipe"]
@@ -277,6 +292,21 @@ def test_start_modes_inertia_and_unpreconditioned(amd, orc):
         b = lat.settle(**kw)
         assert a["iters"] == b["iters"], kw
         assert relerr(lat.U, ref.U) < 2e-5, kw
+
+
+def test_row_block_sharded_knn_passes_equal_single_pass(amd, monkeypatch):
+    """The multi-GPU lattice build shards 128-row blocks over ranks; OSC_KNN_FAKE_SHARDS runs the per-rank passes one
+    after another on this GPU.  The assembled graph must equal the single-pass build bit for bit."""
+    rng = np.random.default_rng(11)
+    Y = rng.standard_normal((1000, 48)).astype(np.float32)
+    lat = amd.Oscillink(Y, kneighbors=9, deterministic_k=True)
+    base = [x.copy() for x in lat.graph_csr()]
+    for parts in ("2", "3", "8", "16"):
+        monkeypatch.setenv("OSC_KNN_FAKE_SHARDS", parts)
+        lat.rebuild_graph()
+        for a_, b_ in zip(base, lat.graph_csr()):
+            assert np.array_equal(a_, b_), parts
+    monkeypatch.delenv("OSC_KNN_FAKE_SHARDS")
 
 
 def test_signed_receipt_roundtrip(amd):
