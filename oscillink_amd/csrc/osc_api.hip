@@ -841,9 +841,17 @@ int osc_get_U(osc_handle h, float* out) {
 
 int osc_set_U(osc_handle h, const float* U) {
   return guarded(h, [&](L& l) {
-    if (U) upload_rows(l, l.U.p, U);
-    else HIP_CHECK(hipMemcpyAsync(l.U.p, l.Y.p, (size_t)l.N * l.ld * 4, hipMemcpyDeviceToDevice, l.stream));
-    l.u_sharded = false;
+    if (U) {
+      upload_rows(l, l.U.p, U);
+      l.u_sharded = false;
+    } else if (l.comm && l.world > 1) {  // column-sharded: only this rank's slab takes part in the next solve
+      HIP_CHECK(hipMemcpy2DAsync(l.U.p + l.c0, (size_t)l.ld * 4, l.Y.p + l.c0, (size_t)l.ld * 4,
+                                 (size_t)(l.c1 - l.c0) * 4, (size_t)l.N, hipMemcpyDeviceToDevice, l.stream));
+      l.u_sharded = true;
+    } else {
+      HIP_CHECK(hipMemcpyAsync(l.U.p, l.Y.p, (size_t)l.N * l.ld * 4, hipMemcpyDeviceToDevice, l.stream));
+      l.u_sharded = false;
+    }
     sync(l);
   });
 }

@@ -417,3 +417,75 @@ def test_full_config3_properties(amd, orc):
     lat.reset_U()
     lat.settle(max_iters=st["iters"], tol=0.0)
     assert relerr(lat2.U[:2000], 2.0 * lat.U[:2000]) < 1e-5
+
+
+@pytest.mark.parametrize("N,D,k", [(700, 40, 48), (600, 36, 64), (500, 24, 100), (300, 20, 128)])
+def test_wide_neighbor_lists_against_oracle(amd, orc, N, D, k):
+    """k in (32, 64] uses two list entries per lane, k in (64, 128] the one-wave-per-SIMD variant; same graph,
+    same solve as the oracle."""
+    rng = np.random.default_rng(k)
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    ref = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True)
+    lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+    rp, col, a, w, sd = lat.graph_csr()
+    r, c, wv = orc._edges(ref.A)
+    assert np.array_equal(np.repeat(np.arange(N), np.diff(rp)), r) and np.array_equal(col, c)
+    assert np.allclose(a, wv, rtol=1e-5)
+    for L in (ref, lat):
+        L.set_query(psi)
+        L.add_chain([4, 9, 2, 7], lamP=0.3, weights=[1.0, 0.5, 2.0])
+    a_ = ref.settle(tol=1e-4)
+    b_ = lat.settle(tol=1e-4)
+    assert a_["iters"] == b_["iters"] and relerr(lat.U, ref.U) < 2e-5
+    assert lat.receipt()["deltaH_total"] == pytest.approx(ref.deltaH(), rel=TOL)
+
+
+def test_kneighbors_above_device_limit_is_reported(amd):
+    Y = np.random.default_rng(0).standard_normal((400, 8)).astype(np.float32)
+    with pytest.raises(NotImplementedError):
+        amd.Oscillink(Y, kneighbors=200)
+
+
+def test_config5_shape_gates_chain_properties(amd, orc):
+    """BASELINE config 5 shape on one GPU (N=200k, D=1536, k=64, diffusion gates + chain): the lamQ diag term and the
+    receipt breakdown at full size; sampled-row kNN parity against one sgemm row block of the oracle."""
+    rng = np.random.default_rng(5)
+    N, D, k = 200_000, 1536, 64
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = Y[:32].mean(axis=0)
+    psi = (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
+    lat = amd.Oscillink(Y, kneighbors=k)
+    rp, col, a, w, sd = lat.graph_csr()
+    deg = np.diff(rp)
+    assert deg.max() <= k and deg.min() >= 0 and a.min() > 0
+    sample = rng.choice(N, size=64, replace=False)
+    Yn = orc.normalize_rows(Y)
+    S = Yn[sample] @ Yn.T
+    S[np.arange(sample.size), sample] = -np.inf
+    top = np.argsort(-S, axis=1, kind="stable")[:, :k]
+    import ctypes as C
+
+    from oscillink_amd import _native as nat
+
+    idx = np.zeros((N, k), dtype=np.int32)
+    val = np.zeros((N, k), dtype=np.float32)
+    ke = C.c_int32(0)
+    lat._call("osc_get_knn_lists", nat.i32(idx), nat.f32(val), C.byref(ke))
+    mism = sum(len(set(idx[s].tolist()) ^ set(top[t].tolist())) for t, s in enumerate(sample))
+    assert mism <= 4, mism
+    gates = amd.compute_diffusion_gates(Y, psi, kneighbors=k, gamma=0.15, method="cg", lattice=lat)
+    assert gates.shape == (N,) and 0.0 <= gates.min() and gates.max() == 1.0 and gates.std() > 0
+    lat.set_query(psi, gates=gates)
+    lat.add_chain(list(range(8)), lamP=0.2)
+    st = lat.settle(max_iters=12, tol=1e-3)
+    hist = lat.residual_history()
+    assert st["iters"] <= 8 and all(y < x for x, y in zip(hist, hist[1:]))
+    lat.set_receipt_detail("full")
+    rec = lat.receipt()
+    assert rec["deltaH_total"] >= -1e-3 and rec["meta"]["ustar_converged"]
+    assert rec["anchor_pen_sum"] > 0 and rec["query_term_sum"] > 0
+    assert rec["meta"]["null_points_summary"]["total_null_points"] == len(rec["null_points"])
+    # energy identity at the stationary point: with U = U*, deltaH = 0 exactly
+    lat.U = lat.solve_Ustar()
+    assert abs(lat.receipt()["deltaH_total"]) < 1e-6 * max(1.0, rec["anchor_pen_sum"])
