@@ -21,6 +21,18 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, defines: list[str]) -> str:
+    """Build liboscillink_hip_<name>.so with extra -D flags (kernel A/B experiments; select with OSC_LIB_PATH)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(HERE, f"liboscillink_hip_{name}.so")
+    cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-shared", "-o", out,
+           *[os.path.join(CSRC, s) for s in SOURCES], "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source and link the shared library. Returns the library path."""
     if not force and not _stale():
@@ -52,4 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

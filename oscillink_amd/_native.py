@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboscillink_hip.so")
+# OSC_LIB_PATH selects another build of the same library (A/B experiments with kernel variants)
+LIB_PATH = os.environ.get("OSC_LIB_PATH") or os.path.join(_HERE, "liboscillink_hip.so")
 
 OSC_OK, OSC_E_INVALID, OSC_E_NODEVICE, OSC_E_HIP, OSC_E_STATE, OSC_E_UNSUPPORTED, OSC_E_COMM = 0, -1, -2, -3, -4, -5, -6
 

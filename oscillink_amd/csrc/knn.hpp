@@ -5,22 +5,33 @@
 namespace osc {
 
 struct KnnPlan {
-  int E;               // list entries per lane (capacity 32E >= k)
+  int E;               // list entries per lane (capacity 32E >= keep)
   int KC;              // candidate slots per (row, split) = 32E
-  int row_blocks;      // ceil(N / 128)
+  int keep;            // entries each list keeps (threshold = similarity at rank keep-1)
+  int row_blocks;      // 128-row blocks this launch covers
   int S;               // column splits
   int cols_per_split;  // multiple of 128
   int rb_begin;        // first row block this process computes (multi-GPU: row-block-sharded build)
   int rb_count;        // number of row blocks this process computes
+  bool f16;            // prefilter variant (fp16 MFMA on the fp16 image of 16*Yn)
+  const int32_t* qrows;  // optional explicit list of query rows (per-row exact fallback), device pointer
+  int nq;
 };
 
-KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots, int rb_begin = 0, int rb_count = -1);
+// keep <= 128 (exact) / <= 96 (f16).  slots = resident blocks on the device (load balance of the split count)
+KnnPlan knn_plan(int32_t N, int32_t keep, int32_t slots, int rb_begin, int rb_count, bool f16);
 void launch_normalize_rows(const float* Y, int32_t ldy, float* Yn, int32_t ldn, int64_t N, int32_t D, hipStream_t s);
 void launch_rows_dot(const float* Yn, int32_t ldn, const float* q, float* out, int64_t N, int32_t D, hipStream_t s);
-void launch_knn_topk(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t N, int32_t k, float* cand_val,
-                     int32_t* cand_idx, hipStream_t s);
-void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* cand_idx, int32_t N, int32_t k,
-                      float* out_val, int32_t* out_idx, hipStream_t s);
+void launch_to_f16(const float* Yn, int32_t ldn, void* Yh, int32_t ldh, int64_t N, int32_t D, hipStream_t s);
+// Yop: fp32 Yn (ld floats) or the fp16 image (ld = ldh/2 float slots)
+void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, float* cand_val, int32_t* cand_idx,
+                     hipStream_t s);
+// rank-select the best k_out of the S*KC candidates of each row of the plan's range (or of plan.qrows)
+void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* cand_idx, int32_t N, int32_t k_out,
+                      float* out_val, int32_t* out_idx, int clip, hipStream_t s);
+void launch_knn_rescore(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t D, int32_t N, const int32_t* cidx,
+                        const float* cval, int32_t k, float delta, float* out_val, int32_t* out_idx, int32_t* fail_rows,
+                        int32_t* fail_count, hipStream_t s);
 void launch_mutual_ell(const float* kval, const int32_t* kidx, int32_t N, int32_t k, int32_t width, int32_t* ell_col,
                        float* ell_a, int32_t* deg, hipStream_t s);
 void launch_cap_and_normalize(float* ell_a, float* ell_w, const int32_t* ell_col, const int32_t* deg, int32_t width,

@@ -28,6 +28,7 @@ namespace osc {
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
 
 constexpr float NEG = -3.0e38f;
 constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;
@@ -68,10 +69,16 @@ __global__ __launch_bounds__(256) void k_rows_dot(const float* Yn, int32_t ldn, 
 
 // ---------------------------------------------------------------------------------------------
 // work item = (row block of 128, column split s of S).  cand_*: [N][S][32E]
-template <int E>
+//
+// F16 = true is the PREFILTER variant: Yn is the fp16 image of 16*Yn (two halfs per float slot, so tile staging and
+// fragment addresses are byte-identical to the fp32 variant) and each (k16-step, tile) is ONE v_mfma_f32_32x32x16_f16
+// instead of four fp32 MFMAs.  Its scores only choose candidates; exact fp32 re-scoring follows (k_knn_rescore).
+// qrows != nullptr: the query rows are the nq rows listed there (per-row exact fallback), else rows are identity.
+template <int E, bool F16>
 __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k, int32_t S,
                                               int32_t cols_per_split, float* cand_val, int32_t* cand_idx,
-                                              int32_t rb_begin, int32_t rb_count) {
+                                              int32_t rb_begin, int32_t rb_count, const int32_t* __restrict__ qrows,
+                                              int32_t nq) {
   __shared__ __attribute__((aligned(16))) float lds[2 * BM * LDT];
   float* As = lds;
   float* Bs = lds + BM * LDT;
@@ -83,7 +90,8 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
   const int rloc = (jx / S) * 8 + xcd, split = jx % S;
   const int rblk = rb_begin + rloc;
-  if (rloc >= rb_count || rblk * BM >= N) return;
+  const int nrows = qrows ? nq : N;  // number of query rows
+  if (rloc >= rb_count || rblk * BM >= nrows) return;
   const int row0 = rblk * BM;
   const int cbeg = split * cols_per_split;
   const int cend = min(N, cbeg + cols_per_split);
@@ -103,7 +111,7 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
       li[g][e] = 0x7fffffff;
     }
   }
-  const int thr_lane = ((k - 1) & 31) + 32 * h;  // lane of this half holding rank k-1
+  const int thr_l = (k - 1) & 31;  // lane (within a half) and register holding rank k-1
   const int thr_e = (k - 1) >> 5;
 
   // staging: 128 rows x 32 floats per operand tile = 1024 float4; thread owns 4 of each
@@ -116,9 +124,19 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
   }
   const float* a_ptr[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) a_ptr[q] = Yn + (size_t)min(row0 + srow[q], N - 1) * ldn + sc4[q];
+  for (int q = 0; q < 4; ++q) {
+    const int pos = min(row0 + srow[q], nrows - 1);
+    a_ptr[q] = Yn + (size_t)(qrows ? qrows[pos] : pos) * ldn + sc4[q];
+  }
 
-  const int wrow_base = row0 + 32 * wave;  // global row of this wave's local row 0
+  const int wrow_base = row0 + 32 * wave;  // query position of this wave's local row 0
+  // global row id of the query row each half-wave register g stands for (g&3)+8(g>>2)+4h
+  int grow_of[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int pos = wrow_base + (g & 3) + 8 * (g >> 2) + 4 * h;
+    grow_of[g] = pos < nrows ? (qrows ? qrows[pos] : pos) : -1;
+  }
 
   for (int ct = cbeg; ct < cend; ct += BN) {
     const float* b_ptr[4];
@@ -162,57 +180,73 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
         for (int t = 0; t < 4; ++t) bv[t] = ld4(bp + 32 * t * LDT + 8 * s);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[t].y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
+          if constexpr (F16) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, av), __builtin_bit_cast(half8, bv[t]),
+                                                            acc[t], 0, 0, 0);
+          } else {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[t].y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
+          }
         }
       }
     }
 
     // ---- running top-k update for this 32 x 128 slice -------------------------------------
-    const bool need_mask = (ct + BN > cend) || (ct < wrow_base + 32 && ct + BN > wrow_base);
+    const bool need_mask = (qrows != nullptr) || (ct + BN > cend) || (ct < wrow_base + 32 && ct + BN > wrow_base);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const int grow = wrow_base + (g & 3) + 8 * (g >> 2) + 4 * h;  // global query row of this half
+      const int grow = grow_of[g];  // global query row of this half
       bool touched = false;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float c = acc[t][g];
         const int ccol = ct + 32 * t + l31;
         if (need_mask && (ccol >= cend || ccol == grow)) c = NEG;  // graph.py:37 (diag = -inf) and the ragged tail
-        bool pred = (c >= thr[g]) && (c > NEG);
+        // prefilter scores only pick candidates (ties at the list boundary are covered by the margin): strict test
+#ifdef OSC_KNN_NOEPI  // experiment: GEMM + filter only, no list maintenance (results are wrong)
+        const bool pred = false && (c > thr[g]);
+        asm volatile("" ::"v"(c));
+#else
+        const bool pred = (F16 ? (c > thr[g]) : (c >= thr[g])) && (c > NEG);
+#endif
         unsigned long long m = __ballot(pred);
-        while (m) {  // rare path: one candidate per half-wave per trip, exact sorted insert
+        unsigned m0 = (unsigned)m, m1 = (unsigned)(m >> 32);  // wave-uniform (SGPR) candidate masks of the two halves
+        while (m0 | m1) {  // rare path: one candidate per half-wave per trip, exact sorted insert, no LDS traffic
           touched = true;
-          const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
-          const bool has = mh != 0u;
-          const int srcl = has ? (__ffs(mh) - 1) : 0;
-          const float cv = __shfl(c, srcl + 32 * h, 64);
-          const int cc = ct + 32 * t + srcl;
+          const int s0 = m0 ? (__ffs(m0) - 1) : 0, s1 = m1 ? (__ffs(m1) - 1) : 0;
+          const float cv0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), s0));
+          const float cv1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 32 + s1));
+          const float cv = h ? cv1 : cv0;
+          const int cc = ct + 32 * t + (h ? s1 : s0);
           // insertion rank = number of list entries that beat the candidate
-          int p = 0;
+          int p0 = 0, p1 = 0;
 #pragma unroll
           for (int e = 0; e < E; ++e) {
             const bool better = lv[g][e] > cv || (lv[g][e] == cv && li[g][e] < cc);
             const unsigned long long bm = __ballot(better);
-            p += __popc(h ? (unsigned)(bm >> 32) : (unsigned)bm);
+            p0 += __popc((unsigned)bm);
+            p1 += __popc((unsigned)(bm >> 32));
           }
-          if (!has) p = 1 << 20;
+          if (!m0) p0 = 1 << 20;
+          if (!m1) p1 = 1 << 20;
+          const int p = h ? p1 : p0;
           // shift ranks > p down by one (v_mov_dpp wave_shr:1; the rank-32e slot takes the carry of register e-1)
 #pragma unroll
           for (int e = E - 1; e >= 0; --e) {
             const int rank = l31 + 32 * e;
-            const float sv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lv[g][e]), 0x138, 0xf, 0xf, false));
-            const int si = __builtin_amdgcn_update_dpp(0, li[g][e], 0x138, 0xf, 0xf, false);
-            float inv = sv;
-            int ini = si;
+            float inv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lv[g][e]), 0x138, 0xf, 0xf, false));
+            int ini = __builtin_amdgcn_update_dpp(0, li[g][e], 0x138, 0xf, 0xf, false);
             if (e > 0) {
-              const float cvv = __shfl(lv[g][e - 1], 31 + 32 * h, 64);
-              const int cii = __shfl(li[g][e - 1], 31 + 32 * h, 64);
+              const int pv = __float_as_int(lv[g][e - 1]);
+              const float c0 = __int_as_float(__builtin_amdgcn_readlane(pv, 31));
+              const float c1 = __int_as_float(__builtin_amdgcn_readlane(pv, 63));
+              const int i0 = __builtin_amdgcn_readlane(li[g][e - 1], 31);
+              const int i1 = __builtin_amdgcn_readlane(li[g][e - 1], 63);
               if (l31 == 0) {
-                inv = cvv;
-                ini = cii;
+                inv = h ? c1 : c0;
+                ini = h ? i1 : i0;
               }
             }
             if (rank > p) {
@@ -223,16 +257,18 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
               li[g][e] = cc;
             }
           }
-          if (has && l31 == srcl) pred = false;
-          m = __ballot(pred);
+          m0 &= m0 - 1;  // drop the candidate just handled in each half
+          m1 &= m1 - 1;
         }
       }
-      if (touched) {  // refresh the filter threshold = similarity at rank k-1
+      if (touched) {  // refresh the filter threshold = similarity at rank keep-1
         float src = lv[g][0];
 #pragma unroll
         for (int e = 1; e < E; ++e)
           if (thr_e == e) src = lv[g][e];
-        thr[g] = __shfl(src, thr_lane, 64);
+        const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), thr_l));
+        const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), 32 + thr_l));
+        thr[g] = h ? t1 : t0;
       }
     }
   }
@@ -241,8 +277,8 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
   constexpr int KC = 32 * E;
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
-    const int grow = wrow_base + (g & 3) + 8 * (g >> 2) + 4 * h;
-    if (grow < N) {
+    const int grow = grow_of[g];
+    if (grow >= 0) {
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const size_t o = ((size_t)grow * S + split) * KC + l31 + 32 * e;
@@ -253,36 +289,115 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
   }
 }
 
-template <int E>
+template <int E, bool F16>
 __global__ __launch_bounds__(256, 2) void k_knn_topk(const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k,
                                                      int32_t S, int32_t cols_per_split, float* cand_val,
-                                                     int32_t* cand_idx, int32_t rb_begin, int32_t rb_count) {
-  knn_topk_body<E>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count);
+                                                     int32_t* cand_idx, int32_t rb_begin, int32_t rb_count,
+                                                     const int32_t* __restrict__ qrows, int32_t nq) {
+  knn_topk_body<E, F16>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count, qrows, nq);
 }
 // k in (64, 128]: 128 list registers per lane -> one wave per SIMD with the whole 512-entry register file
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_knn_topk_wide(
     const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k, int32_t S, int32_t cols_per_split, float* cand_val,
-    int32_t* cand_idx, int32_t rb_begin, int32_t rb_count) {
-  knn_topk_body<4>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count);
+    int32_t* cand_idx, int32_t rb_begin, int32_t rb_count, const int32_t* __restrict__ qrows, int32_t nq) {
+  knn_topk_body<4, false>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count, qrows, nq);
+}
+
+// fp16 image of 16*Yn for the prefilter (|Yn| <= 1, so no overflow; the scale keeps small entries out of the
+// fp16 subnormal range).  Row pitch ldh halfs (multiple of 64), zero padded.
+__global__ __launch_bounds__(256) void k_to_f16(const float* Yn, int32_t ldn, _Float16* Yh, int32_t ldh, int64_t N,
+                                                int32_t D) {
+  const int64_t row = blockIdx.x;
+  for (int c = threadIdx.x; c < ldh; c += 256)
+    Yh[row * ldh + c] = c < D ? (_Float16)(16.0f * Yn[row * ldn + c]) : (_Float16)0.0f;
+}
+
+// Exact fp32 re-scoring of the prefilter's candidates, one wave per row.
+//   score(i,j) = sum_k Yn_i[k] Yn_j[k], lanes stride k, butterfly sum: symmetric in (i,j) bit for bit.
+//   final list = best k by (score desc, index asc), clipped at 0 (graph.py:46-49, 62).
+//   verify: every column outside the candidate list has prefilter score <= v_last, hence exact score
+//   <= v_last/256 + delta; the row is safe iff that is < the exact k-th score.  Unsafe rows are queued for the
+//   exact kernel (fail_rows / fail_count).
+__global__ __launch_bounds__(256) void k_knn_rescore(const float* __restrict__ Yn, int32_t ldn, int32_t D, int32_t N,
+                                                     int32_t row_begin, int32_t row_end, const int32_t* cidx,
+                                                     const float* cval, int32_t KC, int32_t k, float delta,
+                                                     float* out_val, int32_t* out_idx, int32_t* fail_rows,
+                                                     int32_t* fail_count) {
+  const int lane = threadIdx.x & 63;
+  const int row = row_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= row_end) return;
+  const float* yi = Yn + (size_t)row * ldn;
+  float sc[2] = {NEG, NEG};   // exact score of candidate slot lane + 64 m   (KC <= 128)
+  int id[2] = {-1, -1};
+  int nvalid = 0;
+  for (int q = 0; q < KC; ++q) {
+    const int j = cidx[(size_t)row * KC + q];
+    if (j < 0 || j >= N) continue;  // uniform
+    ++nvalid;
+    const float* yj = Yn + (size_t)j * ldn;
+    float s = 0.f;
+    for (int c = lane * 4; c < ldn; c += 256) {  // rows are zero-padded to ldn (multiple of 32 floats)
+      const float4 a = ld4(yi + c), b = ld4(yj + c);
+      s = fmaf(a.x, b.x, s);
+      s = fmaf(a.y, b.y, s);
+      s = fmaf(a.z, b.z, s);
+      s = fmaf(a.w, b.w, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == (q & 63)) {
+      if (q < 64) { sc[0] = s; id[0] = j; } else { sc[1] = s; id[1] = j; }
+    }
+  }
+  // rank of my slots among all valid candidates
+  int rank[2] = {0, 0};
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2) {
+    for (int l = 0; l < 64; ++l) {
+      const float ov = __shfl(sc[m2], l, 64);
+      const int oi = __shfl(id[m2], l, 64);
+      if (oi < 0) continue;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        if (id[m] >= 0 && (ov > sc[m] || (ov == sc[m] && oi < id[m]))) ++rank[m];
+    }
+  }
+  float tk = NEG;  // exact k-th best score
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    if (id[m] >= 0 && rank[m] < k) {
+      out_val[(size_t)row * k + rank[m]] = fmaxf(sc[m], 0.f);
+      out_idx[(size_t)row * k + rank[m]] = id[m];
+    }
+    if (id[m] >= 0 && rank[m] == k - 1) tk = sc[m];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tk = fmaxf(tk, __shfl_xor(tk, o, 64));
+  if (lane == 0 && nvalid == KC) {  // a full list: columns were left out, prove none of them belongs
+    const float vlast = cval[(size_t)row * KC + KC - 1] * (1.0f / 256.0f);
+    if (!(vlast + delta < tk)) fail_rows[atomicAdd(fail_count, 1)] = row;
+  }
 }
 
 // one wave per row: rank-select the k best of the S*KC candidates -> sorted (sim desc, idx asc), clipped at 0
 __global__ __launch_bounds__(256) void k_knn_merge(const float* cand_val, const int32_t* cand_idx, int32_t ncand,
                                                    int32_t row_begin, int32_t N, int32_t k, float* out_val,
-                                                   int32_t* out_idx) {
+                                                   int32_t* out_idx, int32_t clip, const int32_t* __restrict__ qrows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* sv = reinterpret_cast<float*>(smem) + (size_t)wave * ncand;
   int32_t* si = reinterpret_cast<int32_t*>(smem + (size_t)4 * ncand * sizeof(float)) + (size_t)wave * ncand;
-  const int row = row_begin + blockIdx.x * 4 + wave;  // N = end of this process's row range
-  if (row < N) {
+  int row = row_begin + blockIdx.x * 4 + wave;  // N = end of the row range (or of the qrows list)
+  const bool live = row < N;
+  if (live && qrows) row = qrows[row];
+  if (live) {
     for (int c = lane; c < ncand; c += 64) {
       sv[c] = cand_val[(size_t)row * ncand + c];
       si[c] = cand_idx[(size_t)row * ncand + c];
     }
   }
   __syncthreads();
-  if (row >= N) return;
+  if (!live) return;
   for (int c = lane; c < ncand; c += 64) {
     const float v = sv[c];
     const int i = si[c];
@@ -294,7 +409,7 @@ __global__ __launch_bounds__(256) void k_knn_merge(const float* cand_val, const 
       if (dv < 3.0e38f && (dv > v || (dv == v && di < i))) ++rank;
     }
     if (rank < k) {
-      out_val[(size_t)row * k + rank] = fmaxf(v, 0.f);  // graph.py:62
+      out_val[(size_t)row * k + rank] = clip ? fmaxf(v, 0.f) : v;  // graph.py:62
       out_idx[(size_t)row * k + rank] = i;
     }
   }
@@ -400,10 +515,15 @@ void launch_rows_dot(const float* Yn, int32_t ldn, const float* q, float* out, i
   HIP_CHECK(hipGetLastError());
 }
 
-KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots, int rb_begin, int rb_count) {
-  KnnPlan p;
-  p.E = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
+KnnPlan knn_plan(int32_t N, int32_t keep, int32_t slots, int rb_begin, int rb_count, bool f16) {
+  KnnPlan p{};
+  p.keep = keep;
+  p.E = (keep + 31) / 32;
+  if (p.E == 3 && !f16) p.E = 4;  // exact variants: 1, 2 and the wide one
   p.KC = 32 * p.E;
+  p.f16 = f16;
+  p.qrows = nullptr;
+  p.nq = 0;
   const int all_blocks = (N + BM - 1) / BM;
   p.rb_begin = rb_begin;
   p.rb_count = rb_count < 0 ? all_blocks : rb_count;
@@ -419,7 +539,7 @@ KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots, int rb_begin, int rb_count
     if (S_eff != S) continue;
     const long items = (long)p.row_blocks * S;
     const long rounds = (items + slots - 1) / slots;
-    const double cost = (double)rounds * tiles_per * (1.0 + 0.004 * S);  // imbalance x (1 + list warm-up overhead)
+    const double cost = (double)rounds * tiles_per * (1.0 + (f16 ? 0.12 : 0.004) * S);  // imbalance x warm-up overhead
     if (cost < best_cost) {
       best_cost = cost;
       best_S = S;
@@ -431,30 +551,52 @@ KnnPlan knn_plan(int32_t N, int32_t k, int32_t slots, int rb_begin, int rb_count
   return p;
 }
 
-void launch_knn_topk(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t N, int32_t k, float* cand_val,
-                     int32_t* cand_idx, hipStream_t s) {
-  if (p.rb_count <= 0) return;
-  const dim3 grid((unsigned)(8 * ((p.rb_count + 7) / 8) * p.S)), block(256);
-  if (p.E == 1)
-    hipLaunchKernelGGL(k_knn_topk<1>, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx,
-                       p.rb_begin, p.rb_count);
-  else if (p.E == 2)
-    hipLaunchKernelGGL(k_knn_topk<2>, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx,
-                       p.rb_begin, p.rb_count);
-  else
-    hipLaunchKernelGGL(k_knn_topk_wide, grid, block, 0, s, Yn, ldn, N, k, p.S, p.cols_per_split, cand_val, cand_idx,
-                       p.rb_begin, p.rb_count);
+void launch_to_f16(const float* Yn, int32_t ldn, void* Yh, int32_t ldh, int64_t N, int32_t D, hipStream_t s) {
+  hipLaunchKernelGGL(k_to_f16, dim3((unsigned)N), dim3(256), 0, s, Yn, ldn, reinterpret_cast<_Float16*>(Yh), ldh, N, D);
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* cand_idx, int32_t N, int32_t k,
-                      float* out_val, int32_t* out_idx, hipStream_t s) {
+void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, float* cand_val, int32_t* cand_idx,
+                     hipStream_t s) {
+  if (p.rb_count <= 0) return;
+  const dim3 grid((unsigned)(8 * ((p.rb_count + 7) / 8) * p.S)), block(256);
+#define OSC_KNN_ARGS Yop, ld, N, p.keep, p.S, p.cols_per_split, cand_val, cand_idx, p.rb_begin, p.rb_count, p.qrows, p.nq
+  if (p.f16) {
+    if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, true>), grid, block, 0, s, OSC_KNN_ARGS);
+    else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, true>), grid, block, 0, s, OSC_KNN_ARGS);
+    else if (p.E == 3) hipLaunchKernelGGL((k_knn_topk<3, true>), grid, block, 0, s, OSC_KNN_ARGS);
+    else throw std::runtime_error("f16 prefilter supports at most 96 kept candidates");
+  } else {
+    if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, false>), grid, block, 0, s, OSC_KNN_ARGS);
+    else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, false>), grid, block, 0, s, OSC_KNN_ARGS);
+    else hipLaunchKernelGGL(k_knn_topk_wide, grid, block, 0, s, OSC_KNN_ARGS);
+  }
+#undef OSC_KNN_ARGS
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* cand_idx, int32_t N, int32_t k_out,
+                      float* out_val, int32_t* out_idx, int clip, hipStream_t s) {
   const int ncand = p.S * p.KC;
   const size_t shmem = (size_t)4 * ncand * (sizeof(float) + sizeof(int32_t));
-  const int row_begin = p.rb_begin * BM, row_end = std::min(N, (p.rb_begin + p.rb_count) * BM);
+  int row_begin = p.rb_begin * BM, row_end = std::min(N, (p.rb_begin + p.rb_count) * BM);
+  if (p.qrows) {
+    row_begin = 0;
+    row_end = p.nq;
+  }
   if (row_end <= row_begin) return;
   hipLaunchKernelGGL(k_knn_merge, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), shmem, s, cand_val,
-                     cand_idx, ncand, row_begin, row_end, k, out_val, out_idx);
+                     cand_idx, ncand, row_begin, row_end, k_out, out_val, out_idx, clip, p.qrows);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_knn_rescore(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t D, int32_t N, const int32_t* cidx,
+                        const float* cval, int32_t k, float delta, float* out_val, int32_t* out_idx, int32_t* fail_rows,
+                        int32_t* fail_count, hipStream_t s) {
+  const int row_begin = p.rb_begin * BM, row_end = std::min(N, (p.rb_begin + p.rb_count) * BM);
+  if (row_end <= row_begin) return;
+  hipLaunchKernelGGL(k_knn_rescore, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), 0, s, Yn, ldn, D, N,
+                     row_begin, row_end, cidx, cval, p.keep, k, delta, out_val, out_idx, fail_rows, fail_count);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/oscillink_hip.h"
@@ -40,6 +41,33 @@ struct CommError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
+// hipStreamCreate costs 1.5-4 ms on this stack: streams of destroyed handles are parked per device and reused.
+// (The only process-wide state of the library; guarded by a mutex, holds no lattice data.)
+std::mutex g_pool_mu;
+std::map<int, std::vector<hipStream_t>> g_stream_pool;
+
+hipStream_t acquire_stream(int device) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto& v = g_stream_pool[device];
+    if (!v.empty()) {
+      hipStream_t s = v.back();
+      v.pop_back();
+      return s;
+    }
+  }
+  hipStream_t s = nullptr;
+  HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+void release_stream(int device, hipStream_t s) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto& v = g_stream_pool[device];
+  if (v.size() < 64) v.push_back(s);
+  else (void)hipStreamDestroy(s);
+}
+
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -68,6 +96,7 @@ struct osc_lattice {
   DevBuf<float> knn_val;
   DevBuf<int32_t> knn_idx;
   int32_t knn_k = 0;
+  int32_t knn_fallback_rows = 0;  // rows of the last build the prefilter could not prove and the exact kernel redid
   double build_ms = 0.0;
   int64_t nnz = 0;
   int32_t max_deg = 0;
@@ -110,7 +139,7 @@ struct osc_lattice {
     for (auto e : iter_events) (void)hipEventDestroy(e);
     if (res_host) (void)hipHostFree(res_host);
     if (comm) (void)ncclCommDestroy(comm);
-    if (stream) (void)hipStreamDestroy(stream);
+    release_stream(device, stream);
   }
 };
 
@@ -277,21 +306,77 @@ void build_graph(L& h) {
   h.knn_k = k;
   HIP_CHECK(hipMemsetAsync(h.knn_val.p, 0, list_rows * k * 4, h.stream));
   HIP_CHECK(hipMemsetAsync(h.knn_idx.p, 0xFF, list_rows * k * 4, h.stream));
-  DevBuf<float> cand_val;
-  DevBuf<int32_t> cand_idx;
+  // Two ways to the per-row top-k lists (identical results):
+  //  exact     : fp32 MFMA similarity tiles + running top-k.
+  //  prefilter : fp16 MFMA tiles keep the best KC >= k+16 candidates per row, exact fp32 re-scoring picks the k;
+  //              a row is accepted only if the worst-case fp16 error bound proves no left-out column can belong
+  //              to its top-k, otherwise the row is redone by the exact kernel.
+  // kept candidates per row: k plus a margin; rows whose margin turns out too thin are redone exactly
+  const int keep_f = std::min(96, k + std::max(12, k / 2));
+  bool prefilter = (keep_f >= k + 8);
+  if (const char* e = getenv("OSC_KNN_MODE")) {
+    if (!strcmp(e, "exact")) prefilter = false;
+  }
+  DevBuf<float> cand_val, cval;
+  DevBuf<int32_t> cand_idx, cidx, fail_rows, fail_count;
+  DevBuf<float> Yh;  // fp16 image, viewed as float slots
+  const int32_t ldh = ((h.D + 63) / 64) * 64;
+  h.knn_fallback_rows = 0;
+  if (prefilter) {
+    Yh.alloc((size_t)h.N * ldh / 2);
+    launch_to_f16(Yn.p, ldn, Yh.p, ldh, h.N, h.D, h.stream);
+    cval.alloc((size_t)h.N * keep_f);
+    cidx.alloc((size_t)h.N * keep_f);
+    fail_rows.alloc((size_t)h.N);
+    fail_count.alloc(1);
+    HIP_CHECK(hipMemsetAsync(fail_count.p, 0, 4, h.stream));
+  }
+  // worst-case |fp16-path score - exact score| for unit rows: (2u + u^2) with u = 2^-11, plus fp32 accumulation
+  const float delta = 9.8e-4f + 1.2e-7f * (float)h.D;
   for (int part = 0; part < parts; ++part) {
     if (sharded && part != h.rank) continue;
     const int rb_begin = std::min(all_rb, part * rb_per);
     const int rb_count = std::max(0, std::min(rb_per, all_rb - rb_begin));
-    const KnnPlan plan = knn_plan(N, k, slots, rb_begin, rb_count);
-    const size_t ncand = (size_t)h.N * plan.S * plan.KC;
-    cand_val.alloc(ncand);
-    cand_idx.alloc(ncand);
-    {
-      ProfScope ps(h, 3);
-      launch_knn_topk(plan, Yn.p, ldn, N, k, cand_val.p, cand_idx.p, h.stream);
+    if (prefilter) {
+      const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true);
+      const size_t ncand = (size_t)h.N * plan.S * plan.KC;
+      cand_val.alloc(ncand);
+      cand_idx.alloc(ncand);
+      {
+        ProfScope ps(h, 3);
+        launch_knn_topk(plan, Yh.p, ldh / 2, N, cand_val.p, cand_idx.p, h.stream);
+      }
+      HIP_CHECK(hipMemsetAsync(cidx.p, 0xFF, (size_t)h.N * keep_f * 4, h.stream));
+      launch_knn_merge(plan, cand_val.p, cand_idx.p, N, keep_f, cval.p, cidx.p, 0, h.stream);
+      launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
+                         fail_count.p, h.stream);
+    } else {
+      const KnnPlan plan = knn_plan(N, k, slots, rb_begin, rb_count, false);
+      const size_t ncand = (size_t)h.N * plan.S * plan.KC;
+      cand_val.alloc(ncand);
+      cand_idx.alloc(ncand);
+      {
+        ProfScope ps(h, 3);
+        launch_knn_topk(plan, Yn.p, ldn, N, cand_val.p, cand_idx.p, h.stream);
+      }
+      launch_knn_merge(plan, cand_val.p, cand_idx.p, N, k, h.knn_val.p, h.knn_idx.p, 1, h.stream);
     }
-    launch_knn_merge(plan, cand_val.p, cand_idx.p, N, k, h.knn_val.p, h.knn_idx.p, h.stream);
+  }
+  if (prefilter) {
+    int32_t nfail = 0;
+    HIP_CHECK(hipMemcpyAsync(&nfail, fail_count.p, 4, hipMemcpyDeviceToHost, h.stream));
+    sync(h);
+    h.knn_fallback_rows = nfail;
+    if (nfail > 0) {  // redo the unproven rows with the exact kernel (ties / dense clusters of near-equal scores)
+      KnnPlan plan = knn_plan(N, k, slots, 0, (nfail + 127) / 128, false);
+      plan.qrows = fail_rows.p;
+      plan.nq = nfail;
+      const size_t ncand = (size_t)h.N * plan.S * plan.KC;
+      cand_val.alloc(ncand);
+      cand_idx.alloc(ncand);
+      launch_knn_topk(plan, Yn.p, ldn, N, cand_val.p, cand_idx.p, h.stream);
+      launch_knn_merge(plan, cand_val.p, cand_idx.p, N, k, h.knn_val.p, h.knn_idx.p, 1, h.stream);
+    }
   }
   if (sharded) {
     const size_t cnt = (size_t)rb_per * 128 * k;  // equal chunk per rank, in place
@@ -598,7 +683,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
       g_create_error = std::string("osc_create: device is ") + prop.gcnArchName + ", this build targets gfx950 only";
       return OSC_E_NODEVICE;
     }
-    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->stream = acquire_stream(device);
     h->N = N;
     h->D = D;
     h->ld = ((D + 3) / 4) * 4;
