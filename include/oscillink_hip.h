@@ -106,6 +106,8 @@ int osc_settle(osc_handle h, float dt, int32_t max_iters, float tol, int32_t pre
  * U* stays resident on the device for osc_deltaH / receipts; Ustar_out (N x D) may be NULL. */
 int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out, int32_t* iters, float* res,
                     double* ms);
+/* copy the resident U* (N x D) to the host; OSC_E_STATE if no solve happened since the last state change */
+int osc_get_ustar(osc_handle h, float* out);
 /* residual after every iteration of the last solve (solver.py:29), n <= cap entries written */
 int osc_residual_history(osc_handle h, float* out, int32_t cap, int32_t* n);
 
@@ -125,6 +127,10 @@ int osc_receipt_components(osc_handle h, float* coh_drop, float* anchor_pen, flo
  * residual > 0 and z > z_th.  Output arrays hold N entries; *count rows are written in row order. */
 int osc_null_points(osc_handle h, float z_th, int32_t* i_out, int32_t* j_out, float* z_out, float* r_out,
                     int32_t* count);
+
+/* components + null points in ONE pass over the edges (what receipt() in "full" detail needs; lattice.py:320-332) */
+int osc_receipt_rows(osc_handle h, float z_th, float* coh_drop, float* anchor_pen, float* query_term, int32_t* i_out,
+                     int32_t* j_out, float* z_out, float* r_out, int32_t* count);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the handle's own stream.  which: 0 = operator apply (SpMM, the

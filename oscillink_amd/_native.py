@@ -46,12 +46,14 @@ SIGNATURES = {
     "osc_settle": (C.c_int, [Handle, C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_float, c_i32p, c_f32p,
                              c_f64p]),
     "osc_solve_ustar": (C.c_int, [Handle, C.c_float, C.c_int32, c_f32p, c_i32p, c_f32p, c_f64p]),
+    "osc_get_ustar": (C.c_int, [Handle, c_f32p]),
     "osc_residual_history": (C.c_int, [Handle, c_f32p, C.c_int32, c_i32p]),
     "osc_cg_single_rhs": (C.c_int, [Handle, C.c_float, c_f32p, C.c_float, C.c_int32, c_f32p, c_i32p, c_f32p]),
     "osc_cosine_to": (C.c_int, [Handle, c_f32p, c_f32p]),
     "osc_deltaH": (C.c_int, [Handle, c_f64p]),
     "osc_receipt_components": (C.c_int, [Handle, c_f32p, c_f32p, c_f32p]),
     "osc_null_points": (C.c_int, [Handle, C.c_float, c_i32p, c_i32p, c_f32p, c_f32p, c_i32p]),
+    "osc_receipt_rows": (C.c_int, [Handle, C.c_float, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_i32p]),
     "osc_profile_enable": (C.c_int, [Handle, C.c_int32]),
     "osc_profile_reset": (C.c_int, [Handle]),
     "osc_profile_get": (C.c_int, [Handle, C.c_int32, c_i64p, c_f64p]),

@@ -999,6 +999,15 @@ int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out
   });
 }
 
+int osc_get_ustar(osc_handle h, float* out) {
+  return guarded(h, [&](L& l) {
+    if (!out) throw Invalid("osc_get_ustar: out is NULL");
+    if (!l.have_ustar) throw StateError("osc_get_ustar: no resident U* (call osc_solve_ustar first)");
+    download_rows(l, out, l.Ustar.p);
+    sync(l);
+  });
+}
+
 int osc_residual_history(osc_handle h, float* out, int32_t cap, int32_t* n) {
   return guarded(h, [&](L& l) {
     const int32_t m = std::min<int32_t>(cap, (int32_t)l.history.size());
@@ -1185,6 +1194,37 @@ int osc_null_points(osc_handle h, float z_th, int32_t* i_out, int32_t* j_out, fl
     receipt_rows(l, z_th, c, a, q, nj, nz, nr, false, true);
     std::vector<int32_t> hj((size_t)l.N);
     std::vector<float> hz((size_t)l.N), hr((size_t)l.N);
+    HIP_CHECK(hipMemcpyAsync(hj.data(), nj.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    HIP_CHECK(hipMemcpyAsync(hz.data(), nz.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    HIP_CHECK(hipMemcpyAsync(hr.data(), nr.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+    int32_t n = 0;
+    for (int64_t i = 0; i < l.N; ++i) {
+      if (hj[(size_t)i] < 0) continue;
+      if (i_out) i_out[n] = (int32_t)i;
+      if (j_out) j_out[n] = hj[(size_t)i];
+      if (z_out) z_out[n] = hz[(size_t)i];
+      if (r_out) r_out[n] = hr[(size_t)i];
+      ++n;
+    }
+    *count = n;
+  });
+}
+
+int osc_receipt_rows(osc_handle h, float z_th, float* coh, float* anchor, float* query, int32_t* i_out, int32_t* j_out,
+                     float* z_out, float* r_out, int32_t* count) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (!l.have_ustar) throw StateError("osc_receipt_rows: no resident U*");
+    if (!count) throw Invalid("osc_receipt_rows: count is NULL");
+    DevBuf<float> c, a, q, nz, nr;
+    DevBuf<int32_t> nj;
+    receipt_rows(l, z_th, c, a, q, nj, nz, nr, true, true);
+    std::vector<int32_t> hj((size_t)l.N);
+    std::vector<float> hz((size_t)l.N), hr((size_t)l.N);
+    if (coh) HIP_CHECK(hipMemcpyAsync(coh, c.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    if (anchor) HIP_CHECK(hipMemcpyAsync(anchor, a.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    if (query) HIP_CHECK(hipMemcpyAsync(query, q.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     HIP_CHECK(hipMemcpyAsync(hj.data(), nj.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     HIP_CHECK(hipMemcpyAsync(hz.data(), nz.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     HIP_CHECK(hipMemcpyAsync(hr.data(), nr.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));

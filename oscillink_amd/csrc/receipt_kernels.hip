@@ -11,6 +11,8 @@
 namespace osc {
 namespace {
 
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -25,11 +27,12 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
   const float inv_i = 1.0f / (a.sqrt_deg[row] + 1e-12f);
   // anchor / query terms
   float an = 0.f, qu = 0.f;
-  for (int c = lane; c < a.D; c += 64) {
-    const float us = a.Ustar[ro + c];
-    const float dy = us - a.Y[ro + c], dq = us - a.psi[c];
-    an = fmaf(dy, dy, an);
-    qu = fmaf(dq, dq, qu);
+  for (int c = lane * 4; c < a.ld; c += 256) {  // pitch ld is a multiple of 4; pad columns are zero everywhere
+    const float4 us = ld4(a.Ustar + ro + c), y = ld4(a.Y + ro + c), ps = ld4(a.psi + c);
+    const float d0 = us.x - y.x, d1 = us.y - y.y, d2 = us.z - y.z, d3 = us.w - y.w;
+    const float q0 = us.x - ps.x, q1 = us.y - ps.y, q2 = us.z - ps.z, q3 = us.w - ps.w;
+    an = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, an))));
+    qu = fmaf(q0, q0, fmaf(q1, q1, fmaf(q2, q2, fmaf(q3, q3, qu))));
   }
   an = wave_sum(an);
   qu = wave_sum(qu);
@@ -45,11 +48,15 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
     const size_t jo = (size_t)j * a.ld;
     const float inv_j = 1.0f / (a.sqrt_deg[j] + 1e-12f);
     float dy = 0.f, du = 0.f;
-    for (int c = lane; c < a.D; c += 64) {
-      const float y = a.Y[ro + c] * inv_i - a.Y[jo + c] * inv_j;
-      const float u = a.Ustar[ro + c] * inv_i - a.Ustar[jo + c] * inv_j;
-      dy = fmaf(y, y, dy);
-      du = fmaf(u, u, du);
+    for (int c = lane * 4; c < a.ld; c += 256) {
+      const float4 yi = ld4(a.Y + ro + c), yj = ld4(a.Y + jo + c);
+      const float4 ui = ld4(a.Ustar + ro + c), uj = ld4(a.Ustar + jo + c);
+      const float y0 = yi.x * inv_i - yj.x * inv_j, y1 = yi.y * inv_i - yj.y * inv_j;
+      const float y2 = yi.z * inv_i - yj.z * inv_j, y3 = yi.w * inv_i - yj.w * inv_j;
+      const float u0 = ui.x * inv_i - uj.x * inv_j, u1 = ui.y * inv_i - uj.y * inv_j;
+      const float u2 = ui.z * inv_i - uj.z * inv_j, u3 = ui.w * inv_i - uj.w * inv_j;
+      dy = fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, fmaf(y3, y3, dy))));
+      du = fmaf(u0, u0, fmaf(u1, u1, fmaf(u2, u2, fmaf(u3, u3, du))));
     }
     dy = wave_sum(dy);
     du = wave_sum(du);

@@ -104,6 +104,7 @@ class OscillinkLattice:
         self._sig_cache: Optional[tuple] = None
         self._Ustar_cache: Optional[np.ndarray] = None
         self._Ustar_sig: Optional[str] = None
+        self._device_ustar_sig: Optional[str] = None
         self.stats: dict[str, int] = {"ustar_solves": 0, "ustar_cache_hits": 0}
         self._settle_callbacks: list = []
         self._logger = None
@@ -375,39 +376,58 @@ class OscillinkLattice:
     # ------------------------------------------------------------------ U* (lattice.py:232-296)
     def solve_Ustar(self, tol: float = 1e-4, max_iters: int = 64, use_cache: bool = True) -> np.ndarray:
         sig = self._signature()
-        if use_cache and self._Ustar_cache is not None and self._Ustar_sig == sig:
+        if use_cache and self._Ustar_sig == sig and self._device_ustar_sig == sig:
             self.stats["ustar_cache_hits"] += 1
             self._log("ustar_cache_hit", {"signature": sig})
+            if self._Ustar_cache is None:  # solved on the device for a receipt: fetch the rows on first host use
+                self._Ustar_cache = self._download_ustar()
             return self._Ustar_cache
-        self._push_params()
+        self._solve_ustar_device(sig, tol, max_iters, use_cache)
+        out = self._download_ustar()
+        if use_cache:
+            self._Ustar_cache = out
+        return out
+
+    def _download_ustar(self) -> np.ndarray:
         out = np.empty((self.N, self.D), dtype=np.float32)
+        self._call("osc_get_ustar", nat.f32(out))
+        return out
+
+    def _solve_ustar_device(self, sig: str, tol: float, max_iters: int, use_cache: bool) -> None:
+        """Stationary solve on the device; U* stays resident there (receipts read it in place)."""
+        self._push_params()
         iters, res, ms = C.c_int32(0), C.c_float(0.0), C.c_double(0.0)
-        self._call("osc_solve_ustar", float(tol), int(max_iters), nat.f32(out), C.byref(iters), C.byref(res),
-                   C.byref(ms))
+        self._call("osc_solve_ustar", float(tol), int(max_iters), None, C.byref(iters), C.byref(res), C.byref(ms))
         converged = bool(float(res.value) <= tol)
         self.last_ustar = {"iters": int(iters.value), "res": float(res.value), "converged": converged,
                            "solve_ms": float(ms.value)}
         self._device_ustar_sig = sig
-        if use_cache:
-            self._Ustar_cache = out
-            self._Ustar_sig = sig
+        self._Ustar_cache = None
+        self._Ustar_sig = sig if use_cache else None
         self.stats["ustar_solves"] += 1
         self._log("ustar_solve", {"signature": sig, "tol": tol, "max_iters": max_iters, **self.last_ustar})
         if not converged:
             self._log("ustar_convergence_warn", {"res": float(res.value), "tol": tol, "iters": int(iters.value)})
-        return out
 
     def refresh_Ustar(self, tol: float = 1e-4, max_iters: int = 64) -> np.ndarray:
         self._invalidate_cache()
         self._log("refresh_ustar", {})
         return self.solve_Ustar(tol=tol, max_iters=max_iters, use_cache=True)
 
-    def _ensure_device_ustar(self) -> np.ndarray:
-        """U* on the host AND resident on the device for the receipt kernels."""
-        Us = self.solve_Ustar()
-        if getattr(self, "_device_ustar_sig", None) != self._signature():
-            Us = self.solve_Ustar(use_cache=False)  # state was exported/imported around the cache: re-solve
-        return Us
+    def _ensure_device_ustar(self) -> None:
+        """U* resident on the device for the receipt kernels (same cache/stat semantics as solve_Ustar())."""
+        sig = self._signature()
+        if self._Ustar_sig == sig and self._device_ustar_sig == sig:
+            self.stats["ustar_cache_hits"] += 1
+            self._log("ustar_cache_hit", {"signature": sig})
+            return
+        self._solve_ustar_device(sig, 1e-4, 64, True)
+
+    def _host_ustar(self) -> np.ndarray:
+        self._ensure_device_ustar()
+        if self._Ustar_cache is None:
+            self._Ustar_cache = self._download_ustar()
+        return self._Ustar_cache
 
     # ------------------------------------------------------------------ receipts (lattice.py:298-455)
     def receipt(self) -> dict[str, Any]:
@@ -417,27 +437,30 @@ class OscillinkLattice:
         dH = float(np.float32(dH.value))
         if self._receipt_detail == "light":
             coh_sum = anchor_sum = query_sum = 0.0
-            nulls_full: list[dict[str, Any]] = []
         else:
-            coh, anc, qry = self._components()
+            coh, anc, qry, null_arrays = self._receipt_rows(3.0)
             coh_sum, anchor_sum, query_sum = float(np.sum(coh)), float(np.sum(anc)), float(np.sum(qry))
-            nulls_full = self._null_points(3.0)
         try:
             cap_val = int(os.getenv("OSCILLINK_RECEIPT_NULL_CAP", "0").strip())
         except ValueError:
             cap_val = 0
-        if cap_val > 0 and len(nulls_full) > cap_val:
-            nulls = sorted(nulls_full, key=lambda e: e.get("z", 0.0), reverse=True)[:cap_val]
-            null_meta = {"total_null_points": len(nulls_full), "returned_null_points": cap_val, "null_cap_applied": True}
+        if self._receipt_detail == "light":
+            nulls, total = [], 0
         else:
-            nulls = nulls_full
-            null_meta = {"total_null_points": len(nulls_full), "returned_null_points": len(nulls_full),
-                         "null_cap_applied": False}
+            i, j, z, r, total = null_arrays
+            if cap_val > 0 and total > cap_val:  # keep the highest z (lattice.py:341-349); stable like sorted()
+                keep = np.argsort(-z[:total], kind="stable")[:cap_val]
+                nulls = self._null_dicts(i[keep], j[keep], z[keep], r[keep], cap_val)
+            else:
+                nulls = self._null_dicts(i, j, z, r, total)
+        capped = cap_val > 0 and total > cap_val
+        null_meta = {"total_null_points": total, "returned_null_points": cap_val if capped else total,
+                     "null_cap_applied": bool(capped)}
         nnz, _, _ = self.graph_stats()
         lu = getattr(self, "last_ustar", {})
         sig = self._signature()
         meta: dict[str, Any] = {
-            "ustar_cached": bool(self._Ustar_cache is not None and self._Ustar_sig == sig),
+            "ustar_cached": bool(self._Ustar_sig is not None and self._Ustar_sig == sig),
             "ustar_solves": int(self.stats["ustar_solves"]),
             "ustar_cache_hits": int(self.stats["ustar_cache_hits"]),
             "ustar_converged": bool(lu.get("converged", True)),
@@ -495,6 +518,24 @@ class OscillinkLattice:
         self._call("osc_receipt_components", nat.f32(coh), nat.f32(anc), nat.f32(qry))
         return coh, anc, qry
 
+    def _receipt_rows(self, z_th: float):
+        coh = np.zeros(self.N, dtype=np.float32)
+        anc = np.zeros(self.N, dtype=np.float32)
+        qry = np.zeros(self.N, dtype=np.float32)
+        i = np.zeros(self.N, dtype=np.int32)
+        j = np.zeros(self.N, dtype=np.int32)
+        z = np.zeros(self.N, dtype=np.float32)
+        r = np.zeros(self.N, dtype=np.float32)
+        n = C.c_int32(0)
+        self._call("osc_receipt_rows", float(z_th), nat.f32(coh), nat.f32(anc), nat.f32(qry), nat.i32(i), nat.i32(j),
+                   nat.f32(z), nat.f32(r), C.byref(n))
+        return coh, anc, qry, (i, j, z, r, int(n.value))
+
+    @staticmethod
+    def _null_dicts(i, j, z, r, n):
+        il, jl, zl, rl = i[:n].tolist(), j[:n].tolist(), z[:n].astype(float).tolist(), r[:n].astype(float).tolist()
+        return [{"edge": [a, b], "z": c, "residual": d} for a, b, c, d in zip(il, jl, zl, rl)]
+
     def _coherence_drop(self, Ustar: Optional[np.ndarray] = None) -> np.ndarray:
         self._ensure_device_ustar()
         return self._components()[0]
@@ -506,7 +547,7 @@ class OscillinkLattice:
         r = np.zeros(self.N, dtype=np.float32)
         n = C.c_int32(0)
         self._call("osc_null_points", float(z_th), nat.i32(i), nat.i32(j), nat.f32(z), nat.f32(r), C.byref(n))
-        return [{"edge": [int(i[t]), int(j[t])], "z": float(z[t]), "residual": float(r[t])} for t in range(n.value)]
+        return self._null_dicts(i, j, z, r, n.value)
 
     def verify_current_receipt(self, secret) -> bool:
         from .receipts import verify_receipt
@@ -515,7 +556,7 @@ class OscillinkLattice:
 
     # ------------------------------------------------------------------ chain receipt (lattice.py:466-528), sparse
     def chain_receipt(self, chain: list[int], z_th: float = 2.5) -> dict[str, Any]:
-        Ustar = self._ensure_device_ustar()
+        Ustar = self._host_ustar()
         rowptr, col, a, _, sd = self._host_csr()
         di = sd + 1e-12
         N = self.N
@@ -587,7 +628,7 @@ class OscillinkLattice:
 
     # ------------------------------------------------------------------ bundle (lattice.py:530-568; graph.py:114-133)
     def bundle(self, k: int = 8, alpha: float = 0.5) -> list[dict]:
-        Ustar = self._ensure_device_ustar()
+        Ustar = self._host_ustar()
         u_norm = np.linalg.norm(Ustar, axis=1, keepdims=True) + 1e-12
         psi_n = self._psi / (np.linalg.norm(self._psi) + 1e-12)
         align = (Ustar / u_norm) @ psi_n
@@ -844,7 +885,7 @@ class OscillinkLattice:
                  f"lamQ={self.lamQ}"]
         if self.lamP > 0 and self._chain_nodes is not None:
             parts += [f"chain_len={len(self._chain_nodes)}", f"lamP={self.lamP}"]
-        if self._Ustar_cache is not None:
+        if self._Ustar_sig is not None:
             parts.append("U*cached")
         return "OscillinkLattice(" + ", ".join(parts) + ")"
 

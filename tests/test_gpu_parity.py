@@ -309,6 +309,25 @@ def test_row_block_sharded_knn_passes_equal_single_pass(amd, monkeypatch):
     monkeypatch.delenv("OSC_KNN_FAKE_SHARDS")
 
 
+def test_null_point_cap_env(amd, monkeypatch):
+    """OSCILLINK_RECEIPT_NULL_CAP (lattice.py:336-356; reference tests/test_null_cap.py:15-33)."""
+    Y = np.random.default_rng(2).standard_normal((120, 32)).astype(np.float32)
+    lat = amd.Oscillink(Y, kneighbors=6, deterministic_k=True)
+    lat.settle()
+    full = lat.receipt()
+    total = len(full["null_points"])
+    assert total > 3 and not full["meta"]["null_points_summary"]["null_cap_applied"]
+    monkeypatch.setenv("OSCILLINK_RECEIPT_NULL_CAP", "3")
+    rec = lat.receipt()
+    assert len(rec["null_points"]) == 3
+    assert rec["meta"]["null_points_summary"] == {"total_null_points": total, "returned_null_points": 3,
+                                                  "null_cap_applied": True}
+    top = sorted(full["null_points"], key=lambda e: e["z"], reverse=True)[:3]
+    assert [n["edge"] for n in rec["null_points"]] == [n["edge"] for n in top]
+    monkeypatch.setenv("OSCILLINK_RECEIPT_NULL_CAP", "garbage")
+    assert len(lat.receipt()["null_points"]) == total
+
+
 def test_signed_receipt_roundtrip(amd):
     Y = np.random.default_rng(1).standard_normal((60, 16)).astype(np.float32)
     lat = amd.Oscillink(Y, kneighbors=4)
