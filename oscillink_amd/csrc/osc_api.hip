@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "knn.hpp"
 #include "receipts.hpp"
+#include "small.hpp"
 
 using namespace osc;
 
@@ -111,7 +112,12 @@ struct osc_lattice {
   int32_t spmm_slab = 0;  // 0 = whole window per launch
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
-  DevBuf<uint32_t> res_bits;
+  DevBuf<uint32_t> res_bits, arrive;  // arrive: per-iteration barrier counters (+1 status word) of the one-launch path
+  bool small_path = true;             // OSC_SMALL_PATH=0 disables the one-launch CG for small lattices
+  DevBuf<int32_t> ell_col_t;          // transposed ELL for the one-launch path (built on first use per graph)
+  DevBuf<float> ell_w_t;
+  bool ell_t_ready = false;
+  int64_t small_solves = 0;
   float* res_host = nullptr;  // pinned mirror of res_bits for the per-iteration read-back
   size_t res_host_n = 0;
   std::vector<hipEvent_t> iter_events;
@@ -251,6 +257,7 @@ void graph_counts(L& h) {
 }
 
 void alloc_ell(L& h, int32_t width) {
+  h.ell_t_ready = false;
   h.width = std::max<int32_t>(1, width);
   const size_t n = (size_t)h.N * h.width;
   h.ell_col.alloc(n);
@@ -313,9 +320,10 @@ void build_graph(L& h) {
   //              to its top-k, otherwise the row is redone by the exact kernel.
   // kept candidates per row: k plus a margin; rows whose margin turns out too thin are redone exactly
   const int keep_f = std::min(96, k + std::max(12, k / 2));
-  bool prefilter = (keep_f >= k + 8);
-  if (const char* e = getenv("OSC_KNN_MODE")) {
+  bool prefilter = (keep_f >= k + 8) && N >= 4096;  // tiny lattices: the extra passes cost more than they save
+  if (const char* e = getenv("OSC_KNN_MODE")) {  // "exact" | "prefilter": force one path (tests, A/B)
     if (!strcmp(e, "exact")) prefilter = false;
+    if (!strcmp(e, "prefilter")) prefilter = (keep_f >= k + 8);
   }
   DevBuf<float> cand_val, cval;
   DevBuf<int32_t> cand_idx, cidx, fail_rows, fail_count;
@@ -477,7 +485,73 @@ struct CgResult {
 // carries a gate (residual of the previous iteration, tol) and is a no-op once the CG has converged, so the
 // reference's "stop before the beta/p update" semantics hold exactly while the stream never drains between
 // iterations.
+// Small lattices: the whole solve in ONE launch with the state in LDS (small_kernels.hip).  Returns false when the
+// lattice does not fit that path (or its barrier timed out) and the general path must run.
+bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol,
+                  CgResult& out) {
+  if (!h.small_path || h.comm != nullptr || b.c0 != 0 || b.c1 != b.ld || max_iters > 4096) return false;
+  const int C = small_pick_cols((int32_t)h.N, b.ld);
+  if (C <= 0) return false;
+  const size_t nslots = (size_t)max_iters + 2;
+  const size_t nctl = 2 * nslots + 2;  // [residual slots | arrival counters | status]: one memset, one read-back
+  if (h.arrive.n < nctl) h.arrive.alloc(nctl);
+  if (h.res_host_n < nctl) {
+    if (h.res_host) (void)hipHostFree(h.res_host);
+    h.res_host = nullptr;
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h.res_host), nctl * 4, hipHostMallocDefault));
+    h.res_host_n = nctl;
+  }
+  HIP_CHECK(hipMemsetAsync(h.arrive.p, 0, nctl * 4, h.stream));
+  SmallArgs a{};
+  if (!h.ell_t_ready) {
+    h.ell_col_t.alloc((size_t)h.N * h.width);
+    h.ell_w_t.alloc((size_t)h.N * h.width);
+    launch_transpose_ell(h.ell_col.p, h.ell_w.p, (int32_t)h.N, h.width, h.ell_col_t.p, h.ell_w_t.p, h.stream);
+    h.ell_t_ready = true;
+  }
+  a.g = graph_view(h, with_path);
+  a.col_t = h.ell_col_t.p;
+  a.w_t = h.ell_w_t.p;
+  a.op = op;
+  a.x0 = b.x0;
+  a.X = b.X;
+  a.U = b.rhsU;
+  a.Y = b.rhsY;
+  a.B = b.B;
+  a.psi = b.psi;
+  a.res_bits = h.arrive.p;
+  a.arrive = h.arrive.p + nslots;
+  a.status = h.arrive.p + 2 * nslots;
+  a.N = (int32_t)h.N;
+  a.ld = b.ld;
+  a.max_iters = max_iters;
+  a.tol = tol;
+  launch_settle_small(a, C, h.stream);
+  HIP_CHECK(hipMemcpyAsync(h.res_host, h.arrive.p, nctl * 4, hipMemcpyDeviceToHost, h.stream));
+  sync(h);
+  uint32_t st;
+  std::memcpy(&st, h.res_host + 2 * nslots, 4);
+  if (st != 0) return false;  // barrier timeout (GPU shared with other persistent work): take the general path
+  h.history.clear();
+  out = CgResult{max_iters, 0.f};
+  for (int it = 1; it <= max_iters; ++it) {
+    const float res = h.res_host[it];
+    h.history.push_back(res);
+    out.res = res;
+    if ((double)res <= (double)tol) {
+      out.iters = it;
+      break;
+    }
+  }
+  h.small_solves += 1;
+  return true;
+}
+
 CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol) {
+  {
+    CgResult small{};
+    if (run_cg_small(h, op, b, with_path, max_iters, tol, small)) return small;
+  }
   const int grid = cg_grid(h);
   HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, ((size_t)max_iters + 2) * 4, h.stream));
   if (h.res_host_n < (size_t)max_iters + 2) {
@@ -695,6 +769,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     h->seed = seed;
     if (const char* e = getenv("OSC_SPMM_SLAB")) h->spmm_slab = atoi(e) < 0 ? -1 : (atoi(e) / 4) * 4;
     if (const char* e = getenv("OSC_GRID_CAP")) h->grid_cap = std::max(1, atoi(e));
+    if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
     const size_t n = (size_t)N * h->ld;
     for (DevBuf<float>* b : {&h->Y, &h->U, &h->X, &h->R, &h->P, &h->AP, &h->Ustar}) b->alloc(n);
     HIP_CHECK(hipMemsetAsync(h->Y.p, 0, n * 4, h->stream));

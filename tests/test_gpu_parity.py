@@ -94,6 +94,20 @@ def test_cg_with_injected_graph_matches_reference(amd, name):
         assert rec["meta"]["state_sig"] == str(case["state_sig"])
 
 
+@pytest.mark.parametrize("name", ["c2_n1200_d128_k16", "g1_n400_d64_k6_chain8", "gates_chain_n333_d50_k7"])
+def test_general_multi_kernel_cg_on_small_fixtures(amd, name, monkeypatch):
+    """Small lattices normally take the one-launch LDS-resident CG; OSC_SMALL_PATH=0 forces the general multi-kernel
+    path (the one config 3 runs) through the same fixtures, and both must agree with the reference."""
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    case = load_case(name)
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
+    lat.set_graph_csr(*_csr_from_case(case))
+    _configure(lat, case, rc, psi)
+    _check_solves(lat, case, rc, tol_u=2e-5)
+
+
 @pytest.mark.parametrize("name", ALL_CASES)
 def test_device_knn_graph_matches_reference(amd, name):
     """Device mutual-kNN + cap + Laplacian weights against the reference's adjacency (same edge set, same weights)."""
@@ -292,6 +306,27 @@ def test_start_modes_inertia_and_unpreconditioned(amd, orc):
         b = lat.settle(**kw)
         assert a["iters"] == b["iters"], kw
         assert relerr(lat.U, ref.U) < 2e-5, kw
+
+
+@pytest.mark.parametrize("name", ["c2_n1200_d128_k16", "gates_chain_n333_d50_k7", "nondet_n256_d32_k5"])
+def test_prefilter_and_exact_knn_paths_agree_with_reference(amd, name, monkeypatch):
+    """The fp16-prefilter + exact re-scoring build (default for N >= 4096) and the all-fp32 MFMA build are forced in
+    turn on the same fixture; both must give the reference's edge set.  The all-ties input exercises the per-row
+    exact fallback (no candidate list can be proven there)."""
+    case = load_case(name)
+    rc = case["recipe"]
+    Y, _ = make_inputs(rc)
+    for mode in ("prefilter", "exact"):
+        monkeypatch.setenv("OSC_KNN_MODE", mode)
+        lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"])
+        rowptr, col, a, w, sd = lat.graph_csr()
+        assert np.array_equal(rowptr, case["indptr"]) and np.array_equal(col, case["indices"]), mode
+        assert np.allclose(a, case["A_data"], rtol=1e-5, atol=1e-8), mode
+    monkeypatch.setenv("OSC_KNN_MODE", "prefilter")
+    Yt = np.ones((300, 6), dtype=np.float32)
+    ties = amd.Oscillink(Yt, kneighbors=5, deterministic_k=True).A
+    monkeypatch.setenv("OSC_KNN_MODE", "exact")
+    assert np.array_equal(ties, amd.Oscillink(Yt, kneighbors=5, deterministic_k=True).A)
 
 
 def test_row_block_sharded_knn_passes_equal_single_pass(amd, monkeypatch):
