@@ -145,7 +145,7 @@ def main():
                    "N": N, "D": D, "k": k, "nnz": nnz, "max_degree": max_deg,
                    "parallelism": "single" if world == 1 else f"column-sharded CG x{world}",
                    "cg_iters_per_settle": iters_total / args.steps, "residual": last["res"]},
-        "graph_build_ms": graph_build_ms,
+        "lattice_create_ms": graph_build_ms,  # first call in the process: HIP context + code objects + upload + build
         "graph_build_device_ms": dev_build_ms,
         "roofline": {"bound": "hbm", "kernel": "k_spmm (operator apply / CG matvec)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -164,16 +164,18 @@ def main():
 
 
 def pmc_traffic(N, D, k, world):
-    """HBM bytes per operator-apply launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; gfx950
-    read-side x2 correction applied by scripts/summarize_profile.py).  Only valid for the profiled workload."""
+    """HBM bytes per operator apply from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; gfx950 read-side
+    x2 correction applied by scripts/summarize_profile.py).  The apply is launched as column slabs of 128
+    (k_spmm<32, 1, 0>), so the per-launch PMC mean is multiplied by the slab count.  Only valid for the profiled
+    workload (config 3, one GPU)."""
     if (N, D, k, world) != (100_000, 768, 32, 1):
         return None, None
-    for tag in ("r01",):
-        path = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
-        if os.path.exists(path):
-            e = json.load(open(path)).get("k_spmm<64, 3, 0>")
-            if e and "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
-                return e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"], f"profiles/{tag}_pmc.json"
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if os.path.exists(path):
+        e = json.load(open(path)).get("k_spmm<32, 1, 0>")
+        if e and "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
+            slabs = (D + 127) // 128
+            return slabs * (e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]), "profiles/r01_pmc.json"
     return None, None
 
 

@@ -23,10 +23,11 @@ def short(name):
     return n.split("(")[0]
 
 
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
-if stats:
-    with open(stats[0]) as f, open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as g:
-        g.write(f.read())
+for sub, name in (("trace", "kernel_stats"), ("trace_knn_exact", "knn_exact_kernel_stats")):
+    stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        with open(stats[0]) as f, open(os.path.join(dst, f"{tag}_{name}.csv"), "w") as g:
+            g.write(f.read())
 
 pmc = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> values
 for d in glob.glob(os.path.join(src, "pmc_*")):
@@ -39,13 +40,25 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recurs
     for row in csv.DictReader(open(f)):
         dur[short(row["Kernel_Name"])].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
 
+def live(v):
+    """Drop the speculative CG launches that were gated off (they return at once: tiny counters / durations)."""
+    if not v:
+        return v
+    cut = 0.05 * max(v)
+    kept = [x for x in v if x >= cut]
+    return kept or v
+
+
 out = {}
 for k, cs in pmc.items():
-    e = {"launches_profiled": max(len(v) for v in cs.values())}
+    e = {"launches_profiled": max(len(live(v)) for v in cs.values())}
     for c, v in cs.items():
+        v = live(v)
         e[c + "_mean"] = sum(v) / len(v)
     if k in dur:
-        e["mean_ns_unprofiled_trace"] = sum(dur[k]) / len(dur[k])
+        d = live(dur[k])
+        e["mean_ns_unprofiled_trace"] = sum(d) / len(d)
+        e["launches_traced"] = len(d)
     if "FETCH_SIZE_mean" in e:
         e["hbm_read_bytes_per_launch"] = 2.0 * 1024.0 * e["FETCH_SIZE_mean"]  # gfx950: x2 for wide coalesced reads
     if "WRITE_SIZE_mean" in e:
