@@ -543,3 +543,71 @@ def test_config5_shape_gates_chain_properties(amd, orc):
     # energy identity at the stationary point: with U = U*, deltaH = 0 exactly
     lat.U = lat.solve_Ustar()
     assert abs(lat.receipt()["deltaH_total"]) < 1e-6 * max(1.0, rec["anchor_pen_sum"])
+
+
+def test_concurrent_lattices_on_threads(amd, orc):
+    """The reference's service settles independent lattices on a thread pool (cloud/app/main.py:1030-1061): handles are
+    independent (own stream, no shared mutable state), ctypes drops the GIL, results must not interfere."""
+    import threading
+
+    rng = np.random.default_rng(21)
+    jobs = []
+    for t in range(6):
+        N, D, k = 300 + 50 * t, 24 + 8 * t, 5 + t
+        Y = rng.standard_normal((N, D)).astype(np.float32)
+        psi = rng.standard_normal(D).astype(np.float32)
+        ref = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True)
+        ref.set_query(psi)
+        ref.settle()
+        jobs.append((Y, psi, k, ref.U, ref.last["iters"], ref.deltaH()))
+    out = [None] * len(jobs)
+
+    def work(i):
+        Y, psi, k, *_ = jobs[i]
+        for _ in range(5):  # repeat to overlap with the other threads
+            lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+            lat.set_query(psi)
+            st = lat.settle()
+            out[i] = (lat.U.copy(), st["iters"], lat.receipt()["deltaH_total"])
+            lat.close()
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for (Y, psi, k, U, iters, dH), got in zip(jobs, out):
+        assert got is not None and got[1] == iters
+        assert relerr(got[0], U) < 2e-5
+        assert got[2] == pytest.approx(dH, rel=TOL)
+
+
+def test_config4_shape_on_one_gpu(amd):
+    """BASELINE config 4 shape (N=1M, D=384, k=16) on ONE GPU: size/indexing limits of the build and the solver
+    (the 8-GPU run shards exactly these arrays by row block / column slab)."""
+    rng = np.random.default_rng(4)
+    N, D, k = 1_000_000, 384, 16
+    Y = rng.standard_normal((N, D), dtype=np.float32)
+    psi = Y[:32].mean(axis=0)
+    psi = (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
+    lat = amd.Oscillink(Y, kneighbors=k)
+    nnz, max_deg, build_ms = lat.graph_stats()
+    assert 0 < nnz <= N * k and max_deg <= k
+    rp, col, a, w, sd = lat.graph_csr()
+    rows = np.repeat(np.arange(N), np.diff(rp))
+    # symmetry on a sample of edges: (j, i) exists with the same weight
+    pick = rng.choice(nnz, size=2000, replace=False)
+    for e in pick[:200]:
+        i, j = int(rows[e]), int(col[e])
+        seg = col[rp[j]: rp[j + 1]]
+        pos = np.searchsorted(seg, i)
+        assert pos < seg.size and seg[pos] == i and a[rp[j] + pos] == a[e]
+    lat.set_query(psi)
+    st = lat.settle(max_iters=12, tol=1e-3)
+    hist = lat.residual_history()
+    assert st["iters"] <= 8 and all(y < x for x, y in zip(hist, hist[1:]))
+    lat.set_receipt_detail("light")
+    rec = lat.receipt()
+    assert rec["deltaH_total"] >= -1e-2 and rec["meta"]["ustar_converged"]
+    print(f"config4 shape: build {build_ms:.0f} ms, nnz {nnz}, settle {st['t_ms']:.1f} ms / {st['iters']} it, "
+          f"ustar {rec['meta']['ustar_solve_ms']:.1f} ms")
