@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_rows_dot(const float* Yn, int32_t ldn, 
 // fragment addresses are byte-identical to the fp32 variant) and each (k16-step, tile) is ONE v_mfma_f32_32x32x16_f16
 // instead of four fp32 MFMAs.  Its scores only choose candidates; exact fp32 re-scoring follows (k_knn_rescore).
 // qrows != nullptr: the query rows are the nq rows listed there (per-row exact fallback), else rows are identity.
-template <int E, bool F16>
+template <int E, bool F16, bool QR>
 __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k, int32_t S,
                                               int32_t cols_per_split, float* cand_val, int32_t* cand_idx,
                                               int32_t rb_begin, int32_t rb_count, const int32_t* __restrict__ qrows,
@@ -90,7 +90,7 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
   const int rloc = (jx / S) * 8 + xcd, split = jx % S;
   const int rblk = rb_begin + rloc;
-  const int nrows = qrows ? nq : N;  // number of query rows
+  const int nrows = QR ? nq : N;  // number of query rows
   if (rloc >= rb_count || rblk * BM >= nrows) return;
   const int row0 = rblk * BM;
   const int cbeg = split * cols_per_split;
@@ -126,17 +126,17 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int pos = min(row0 + srow[q], nrows - 1);
-    a_ptr[q] = Yn + (size_t)(qrows ? qrows[pos] : pos) * ldn + sc4[q];
+    a_ptr[q] = Yn + (size_t)(QR ? qrows[pos] : pos) * ldn + sc4[q];
   }
 
   const int wrow_base = row0 + 32 * wave;  // query position of this wave's local row 0
-  // global row id of the query row each half-wave register g stands for (g&3)+8(g>>2)+4h
-  int grow_of[16];
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
+  // global row id of the query row register g of this half-wave stands for, local row (g&3)+8(g>>2)+4h
+  auto grow_at = [&](int g) -> int {
     const int pos = wrow_base + (g & 3) + 8 * (g >> 2) + 4 * h;
-    grow_of[g] = pos < nrows ? (qrows ? qrows[pos] : pos) : -1;
-  }
+    if (pos >= nrows) return -1;
+    if constexpr (QR) return qrows[pos];
+    else return pos;
+  };
 
   for (int ct = cbeg; ct < cend; ct += BN) {
     const float* b_ptr[4];
@@ -194,10 +194,10 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
     }
 
     // ---- running top-k update for this 32 x 128 slice -------------------------------------
-    const bool need_mask = (qrows != nullptr) || (ct + BN > cend) || (ct < wrow_base + 32 && ct + BN > wrow_base);
+    const bool need_mask = QR || (ct + BN > cend) || (ct < wrow_base + 32 && ct + BN > wrow_base);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const int grow = grow_of[g];  // global query row of this half
+      const int grow = grow_at(g);  // global query row of this half
       bool touched = false;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -277,7 +277,7 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
   constexpr int KC = 32 * E;
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
-    const int grow = grow_of[g];
+    const int grow = grow_at(g);
     if (grow >= 0) {
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -289,18 +289,19 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
   }
 }
 
-template <int E, bool F16>
+template <int E, bool F16, bool QR>
 __global__ __launch_bounds__(256, 2) void k_knn_topk(const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k,
                                                      int32_t S, int32_t cols_per_split, float* cand_val,
                                                      int32_t* cand_idx, int32_t rb_begin, int32_t rb_count,
                                                      const int32_t* __restrict__ qrows, int32_t nq) {
-  knn_topk_body<E, F16>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count, qrows, nq);
+  knn_topk_body<E, F16, QR>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count, qrows, nq);
 }
 // k in (64, 128]: 128 list registers per lane -> one wave per SIMD with the whole 512-entry register file
+template <bool QR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_knn_topk_wide(
     const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k, int32_t S, int32_t cols_per_split, float* cand_val,
     int32_t* cand_idx, int32_t rb_begin, int32_t rb_count, const int32_t* __restrict__ qrows, int32_t nq) {
-  knn_topk_body<4, false>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count, qrows, nq);
+  knn_topk_body<4, false, QR>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count, qrows, nq);
 }
 
 // fp16 image of 16*Yn for the prefilter (|Yn| <= 1, so no overflow; the scale keeps small entries out of the
@@ -560,16 +561,22 @@ void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, 
                      hipStream_t s) {
   if (p.rb_count <= 0) return;
   const dim3 grid((unsigned)(8 * ((p.rb_count + 7) / 8) * p.S)), block(256);
-#define OSC_KNN_ARGS Yop, ld, N, p.keep, p.S, p.cols_per_split, cand_val, cand_idx, p.rb_begin, p.rb_count, p.qrows, p.nq
+#define OSC_KNN_ARGS \
+  Yop, ld, N, p.keep, p.S, p.cols_per_split, cand_val, cand_idx, p.rb_begin, p.rb_count, p.qrows, p.nq
   if (p.f16) {
-    if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, true>), grid, block, 0, s, OSC_KNN_ARGS);
-    else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, true>), grid, block, 0, s, OSC_KNN_ARGS);
-    else if (p.E == 3) hipLaunchKernelGGL((k_knn_topk<3, true>), grid, block, 0, s, OSC_KNN_ARGS);
+    if (p.qrows) throw std::runtime_error("the prefilter kernel has no row-list variant");
+    if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
+    else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
+    else if (p.E == 3) hipLaunchKernelGGL((k_knn_topk<3, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
     else throw std::runtime_error("f16 prefilter supports at most 96 kept candidates");
+  } else if (p.qrows) {
+    if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, false, true>), grid, block, 0, s, OSC_KNN_ARGS);
+    else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, false, true>), grid, block, 0, s, OSC_KNN_ARGS);
+    else hipLaunchKernelGGL(k_knn_topk_wide<true>, grid, block, 0, s, OSC_KNN_ARGS);
   } else {
-    if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, false>), grid, block, 0, s, OSC_KNN_ARGS);
-    else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, false>), grid, block, 0, s, OSC_KNN_ARGS);
-    else hipLaunchKernelGGL(k_knn_topk_wide, grid, block, 0, s, OSC_KNN_ARGS);
+    if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, false, false>), grid, block, 0, s, OSC_KNN_ARGS);
+    else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, false, false>), grid, block, 0, s, OSC_KNN_ARGS);
+    else hipLaunchKernelGGL(k_knn_topk_wide<false>, grid, block, 0, s, OSC_KNN_ARGS);
   }
 #undef OSC_KNN_ARGS
   HIP_CHECK(hipGetLastError());
