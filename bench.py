@@ -190,23 +190,50 @@ def pmc_traffic(N, D, k, world):
 
 
 def cpu_baseline(lat, Y, psi, args):
-    """The CPU oracle (sparse flavour) on the same workload: ONE full-size settle with the device-built graph
-    injected (so the CPU leg times exactly the settle the GPU leg times), plus a 256-row sample of the kNN build."""
+    """The CPU oracle (sparse flavour: SciPy CSR SpMM + NumPy, oracle/oscillink_oracle.py) on the same workload, with
+    the device-built graph injected so the CPU leg times exactly the settle the GPU leg times.
+
+    The CG's columns are independent recurrences (per-column alpha/beta), so the port is run column-parallel on the
+    host cores: T threads each settle a D/T column slab for the iteration count of the full solve (tol=0 keeps every
+    slab at the same number of iterations, i.e. the same arithmetic as one full-width solve; SciPy/NumPy release the
+    GIL inside their kernels).  The single-thread full-width time is reported beside it.  The kNN build is sampled
+    on 256 rows x N columns and extrapolated."""
+    import concurrent.futures as cf
+
     import scipy.sparse as sp
 
     from oracle import oscillink_oracle as orc
 
     rowptr, col, a, _, _ = lat.graph_csr()
-    N = Y.shape[0]
+    N, D = Y.shape
     A = sp.csr_matrix((a, col, rowptr), shape=(N, N), dtype=np.float32)
     ref = orc.OracleLattice(Y, kneighbors=args.k, dense=False, graph=A)
     ref.set_query(psi)
     t0 = time.perf_counter()
     st = ref.settle(dt=1.0, max_iters=args.max_iters, tol=args.tol)
-    t_settle = time.perf_counter() - t0
+    t_single = time.perf_counter() - t0
+
+    threads = max(1, min(os.cpu_count() or 1, 64, D // 4))
+    bounds = np.linspace(0, D, threads + 1).astype(int)
+    slabs = []
+    for t in range(threads):
+        c0, c1 = int(bounds[t]), int(bounds[t + 1])
+        sub = orc.OracleLattice(np.ascontiguousarray(Y[:, c0:c1]), kneighbors=args.k, dense=False, graph=A)
+        sub.set_query(np.ascontiguousarray(psi[c0:c1]))
+        slabs.append(sub)
+
+    def run(sub):
+        return sub.settle(dt=1.0, max_iters=st["iters"], tol=0.0)
+
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(run, slabs))
+        t_par = time.perf_counter() - t0
+    err = max(float(np.abs(s.U - ref.U[:, int(bounds[i]):int(bounds[i + 1])]).max()) for i, s in enumerate(slabs))
+
     rows = min(256, N)
     t0 = time.perf_counter()
-    orc.knn_topk(Y[:rows] if N <= rows else Y, args.k, block=rows) if N <= rows else _knn_sample(orc, Y, args.k, rows)
+    _knn_sample(orc, Y, args.k, rows)
     t_knn = time.perf_counter() - t0
     try:
         import threadpoolctl
@@ -214,12 +241,15 @@ def cpu_baseline(lat, Y, psi, args):
         blas_threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
         blas_threads = os.cpu_count() or 1
-    return {"value": 1.0 / t_settle, "unit": "settles/s", "cores": 1, "kind": "port",
-            "sample": f"1 full-size settle (N={N}, D={Y.shape[1]}, {st['iters']} CG iterations, SciPy CSR SpMM + NumPy, "
-                      f"single thread) on the device-built graph; kNN build sampled on {rows} rows x {N} columns "
-                      f"({blas_threads} BLAS threads)",
-            "ms_per_settle": 1000.0 * t_settle, "cg_iters": st["iters"], "residual": st["res"],
-            "knn_rows_sampled": rows, "knn_sample_ms": 1000.0 * t_knn,
+    best = min(t_par, t_single)
+    return {"value": 1.0 / best, "unit": "settles/s", "cores": threads if t_par <= t_single else 1, "kind": "port",
+            "sample": f"1 full-size settle (N={N}, D={D}, {st['iters']} CG iterations) of the SciPy-CSR/NumPy oracle on the "
+                      f"device-built graph: best of single-thread full-width and column-parallel on {threads} threads "
+                      f"(value uses the faster: {'column-parallel' if t_par <= t_single else 'single-thread'}); kNN build "
+                      f"sampled on {rows} rows x {N} columns ({blas_threads} BLAS threads)",
+            "ms_per_settle": 1000.0 * best, "ms_per_settle_single_thread": 1000.0 * t_single,
+            "ms_per_settle_column_parallel": 1000.0 * t_par, "column_parallel_max_abs_diff": err,
+            "cg_iters": st["iters"], "residual": st["res"], "knn_rows_sampled": rows, "knn_sample_ms": 1000.0 * t_knn,
             "knn_build_extrapolated_ms": 1000.0 * t_knn * N / rows, "host_cores": os.cpu_count()}
 
 

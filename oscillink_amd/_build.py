@@ -13,12 +13,26 @@ HEADERS = ["common.hpp", "knn.hpp", "receipts.hpp", "small.hpp", os.path.join(".
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+STAMP = LIB + ".stamp"
+
+
+def _source_hash() -> str:
+    """Content hash of every input of the build (mtimes do not survive the copy to the GPU box)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES + HEADERS]:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode())
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return open(STAMP).read().strip() != _source_hash()
 
 
 def build_variant(name: str, defines: list[str]) -> str:
@@ -60,6 +74,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    with open(STAMP, "w") as f:
+        f.write(_source_hash())
     return LIB
 
 
