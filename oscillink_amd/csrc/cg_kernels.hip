@@ -21,6 +21,18 @@ namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming store (written once, not re-read by this kernel): keeps the gathered operand's lines in the caches
+// (measured on config 3: nontemporal streams took the settle from 8.71 to 8.37 ms)
+using v4f = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void st4_stream(float* p, float4 v) {
+  const v4f t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+// streaming load (read once per kernel)
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+  const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 __device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
   return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
@@ -184,12 +196,12 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
         o.w = cs * xs[ch].w - a.op.cW * acc[ch].w - a.op.cP * accp[ch].w;
         const size_t off = (size_t)row * ld + coff[ch];
         if (MODE == SPMM_AP) {
-          st4(a.OUT + off, o);
+          st4_stream(a.OUT + off, o);
           dot[ch] = mulacc4(xs[ch], o, dot[ch]);
         } else if (MODE == SPMM_DOT) {
           dot[ch] = mulacc4(xs[ch], o, dot[ch]);
         } else {  // INIT: r = b - A x0 ; z = r / (Md + eps) ; p = z ; rz = sum r.z   (solver.py:19-22)
-          const float4 u = ld4(a.U + off), y = ld4(a.Y + off);
+          const float4 u = ld4_stream(a.U + off), y = ld4_stream(a.Y + off);
           const float qb = a.op.rbB * Bi;
           float4 r, z;
           r.x = (a.op.rbU * u.x + a.op.rbY * y.x + qb * psi4[ch].x) - o.x;
@@ -197,8 +209,8 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
           r.z = (a.op.rbU * u.z + a.op.rbY * y.z + qb * psi4[ch].z) - o.z;
           r.w = (a.op.rbU * u.w + a.op.rbY * y.w + qb * psi4[ch].w) - o.w;
           z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
-          st4(a.OUT + off, xs[ch]);
-          st4(a.R + off, r);
+          st4_stream(a.OUT + off, xs[ch]);
+          st4_stream(a.R + off, r);
           st4(a.P + off, z);
           dot[ch] = mulacc4(r, z, dot[ch]);
         }
@@ -239,14 +251,14 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
     for (int ch = 0; ch < NCH; ++ch) {
       if (!cok[ch]) continue;
       const size_t off = (size_t)row * ld + coff[ch];
-      float4 x = ld4(a.X + off), p = ld4(a.P + off), r = ld4(a.R + off);
-      const float4 ap = ld4(a.AP + off);
+      float4 x = ld4_stream(a.X + off), p = ld4_stream(a.P + off), r = ld4_stream(a.R + off);
+      const float4 ap = ld4_stream(a.AP + off);
       x.x = fmaf(p.x, al[ch].x, x.x); x.y = fmaf(p.y, al[ch].y, x.y);
       x.z = fmaf(p.z, al[ch].z, x.z); x.w = fmaf(p.w, al[ch].w, x.w);
       r.x = fmaf(-ap.x, al[ch].x, r.x); r.y = fmaf(-ap.y, al[ch].y, r.y);
       r.z = fmaf(-ap.z, al[ch].z, r.z); r.w = fmaf(-ap.w, al[ch].w, r.w);
-      st4(a.X + off, x);
-      st4(a.R + off, r);
+      st4_stream(a.X + off, x);
+      st4_stream(a.R + off, r);
       rr[ch] = mulacc4(r, r, rr[ch]);
       const float4 z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
       rz[ch] = mulacc4(r, z, rz[ch]);
@@ -282,8 +294,8 @@ __global__ __launch_bounds__(256) void k_update_p(const UpdateArgs a) {
     for (int ch = 0; ch < NCH; ++ch) {
       if (!cok[ch]) continue;
       const size_t off = (size_t)row * ld + coff[ch];
-      const float4 r = ld4(a.R + off);
-      float4 p = ld4(a.P + off);
+      const float4 r = ld4_stream(a.R + off);
+      float4 p = ld4_stream(a.P + off);
       p.x = fmaf(p.x, be[ch].x, r.x * invMd); p.y = fmaf(p.y, be[ch].y, r.y * invMd);
       p.z = fmaf(p.z, be[ch].z, r.z * invMd); p.w = fmaf(p.w, be[ch].w, r.w * invMd);
       st4(a.P + off, p);
