@@ -98,6 +98,7 @@ struct osc_lattice {
   DevBuf<int32_t> knn_idx;
   int32_t knn_k = 0;
   int32_t knn_fallback_rows = 0;  // rows of the last build the prefilter could not prove and the exact kernel redid
+  bool knn_prefilter = false;     // the last build used the fp16 prefilter
   double build_ms = 0.0;
   int64_t nnz = 0;
   int32_t max_deg = 0;
@@ -330,6 +331,7 @@ void build_graph(L& h) {
   DevBuf<float> Yh;  // fp16 image, viewed as float slots
   const int32_t ldh = ((h.D + 63) / 64) * 64;
   h.knn_fallback_rows = 0;
+  h.knn_prefilter = prefilter;
   if (prefilter) {
     Yh.alloc((size_t)h.N * ldh / 2);
     launch_to_f16(Yn.p, ldn, Yh.p, ldh, h.N, h.D, h.stream);
@@ -819,6 +821,14 @@ int osc_graph_stats(osc_handle h, int64_t* nnz, int32_t* max_deg, double* build_
     if (nnz) *nnz = l.nnz;
     if (max_deg) *max_deg = l.max_deg;
     if (build_ms) *build_ms = l.build_ms;
+  });
+}
+
+int osc_build_info(osc_handle h, int32_t* prefilter, int32_t* fallback_rows, int64_t* small_solves) {
+  return guarded(h, [&](L& l) {
+    if (prefilter) *prefilter = l.knn_prefilter ? 1 : 0;
+    if (fallback_rows) *fallback_rows = l.knn_fallback_rows;
+    if (small_solves) *small_solves = l.small_solves;
   });
 }
 

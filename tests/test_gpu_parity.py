@@ -322,9 +322,13 @@ def test_prefilter_and_exact_knn_paths_agree_with_reference(amd, name, monkeypat
         rowptr, col, a, w, sd = lat.graph_csr()
         assert np.array_equal(rowptr, case["indptr"]) and np.array_equal(col, case["indices"]), mode
         assert np.allclose(a, case["A_data"], rtol=1e-5, atol=1e-8), mode
+        assert lat.build_info()["prefilter"] == (1 if mode == "prefilter" else 0)
+        assert lat.build_info()["fallback_rows"] == 0  # continuous data: every candidate list is proven
     monkeypatch.setenv("OSC_KNN_MODE", "prefilter")
     Yt = np.ones((300, 6), dtype=np.float32)
-    ties = amd.Oscillink(Yt, kneighbors=5, deterministic_k=True).A
+    tl = amd.Oscillink(Yt, kneighbors=5, deterministic_k=True)
+    assert tl.build_info() == {"prefilter": 1, "fallback_rows": 300, "small_solves": 0}  # nothing provable: all redone
+    ties = tl.A
     monkeypatch.setenv("OSC_KNN_MODE", "exact")
     assert np.array_equal(ties, amd.Oscillink(Yt, kneighbors=5, deterministic_k=True).A)
 
@@ -425,6 +429,7 @@ def test_full_config3_properties(amd, orc):
     psi = Y[:32].mean(axis=0)
     psi = (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
     lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+    assert lat.build_info()["prefilter"] == 1 and lat.build_info()["fallback_rows"] == 0
     rp, col, a, w, sd = lat.graph_csr()
     deg = np.diff(rp)
     assert deg.max() <= k and a.min() > 0
