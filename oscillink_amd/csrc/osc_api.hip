@@ -442,11 +442,12 @@ OpParams ustar_op(const L& h) {
 // Operator apply, optionally split into column slabs so the gathered operand slab (N x slab x 4 B) stays resident
 // in the 256 MB Infinity Cache while its rows are re-read ~deg times (MI355X_MICROARCH.md, Infinity Cache rule).
 int32_t auto_slab(const L& h, int32_t ncols) {
-  if (h.spmm_slab > 0) return h.spmm_slab;
-  if (h.spmm_slab < 0) return ncols;  // OSC_SPMM_SLAB=-1: never split
+  constexpr int32_t kMaxWindow = 2048;  // widest column window one launch covers (8 x 256 floats per row)
+  if (h.spmm_slab > 0) return std::min(h.spmm_slab, kMaxWindow);
+  if (h.spmm_slab < 0) return std::min(ncols, kMaxWindow);  // OSC_SPMM_SLAB=-1: split only when it must
   // keep the gathered slab (N x slab x 4 B) around 50 MB so it and the streams beside it stay inside 256 MB
   const double budget = 56.0 * 1024 * 1024;
-  if ((double)h.N * ncols * 4.0 <= 2.0 * budget) return ncols;
+  if ((double)h.N * ncols * 4.0 <= 2.0 * budget) return std::min(ncols, kMaxWindow);
   int32_t slab = 64;
   for (int32_t w : {128, 256, 384, 512, 768, 1024, 2048})
     if ((double)h.N * w * 4.0 <= budget) slab = w;
@@ -461,6 +462,17 @@ void spmm_slabbed(L& h, int mode, SpmmArgs sa, int grid, int iter = 0) {
     sa.c0 = s0;
     sa.c1 = std::min(c1, s0 + slab);
     launch_spmm(mode, sa, grid, h.stream);
+  }
+}
+
+// elementwise CG kernels cover at most 2048 columns per launch: wider states run as several column windows
+template <typename F>
+void for_windows(UpdateArgs ua, F&& launch) {
+  const int32_t c0 = ua.c0, c1 = ua.c1;
+  for (int32_t s0 = c0; s0 < c1; s0 += 2048) {
+    ua.c0 = s0;
+    ua.c1 = std::min(c1, s0 + 2048);
+    launch(ua);
   }
 }
 
@@ -614,13 +626,13 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     ua.gate_tol = tol;
     if (it > 1) {
       ProfScope ps(h, 2, it);
-      launch_update_p(ua, grid, h.stream);  // p = z + beta p of iteration it-1 (solver.py:32-36)
+      for_windows(ua, [&](const UpdateArgs& w) { launch_update_p(w, grid, h.stream); });  // p = z + beta p (solver.py:32-36)
     }
     spmm_slabbed(h, SPMM_AP, sa, grid, it);  // Ap and column sums of p.Ap
     launch_reduce_alpha(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
     {
       ProfScope ps(h, 1, it);
-      launch_update_xr(ua, grid, h.stream);
+      for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });
     }
     launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream);
     if (h.comm) {  // column-sharded: the stop test is the max over all shards (solver.py:29)

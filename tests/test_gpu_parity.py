@@ -616,3 +616,27 @@ def test_config4_shape_on_one_gpu(amd):
     assert rec["deltaH_total"] >= -1e-2 and rec["meta"]["ustar_converged"]
     print(f"config4 shape: build {build_ms:.0f} ms, nnz {nnz}, settle {st['t_ms']:.1f} ms / {st['iters']} it, "
           f"ustar {rec['meta']['ustar_solve_ms']:.1f} ms")
+
+
+@pytest.mark.parametrize("N,D,k", [(2, 3, 1), (3, 1, 2), (5, 2, 4), (17, 7, 3), (64, 2500, 5), (40, 4100, 6)])
+def test_tiny_and_very_wide_shapes(amd, orc, N, D, k, monkeypatch):
+    """Smallest lattices (N = 2, 3, 5; D = 1, 2, 3: pitch padding) and D beyond one 2048-column launch window, on
+    both CG paths."""
+    rng = np.random.default_rng(N * 1000 + D)
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    ref = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True)
+    ref.set_query(psi)
+    a_ = ref.settle(tol=1e-5, max_iters=30)
+    # (the reference squeezes a single column to 1-D, solver.py:31,37; the product keeps (N, 1))
+    ref.U = np.asarray(ref.U).reshape(N, D)
+    dH = orc.deltaH_trace(ref.U, np.asarray(ref.solve_Ustar()).reshape(N, D), ref.M_mul)
+    for small in ("1", "0"):
+        monkeypatch.setenv("OSC_SMALL_PATH", small)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        assert np.allclose(lat.A, ref.A, rtol=1e-5, atol=1e-8)
+        lat.set_query(psi)
+        b_ = lat.settle(tol=1e-5, max_iters=30)
+        assert a_["iters"] == b_["iters"], small
+        assert relerr(lat.U, ref.U) < 2e-5, small
+        assert lat.receipt()["deltaH_total"] == pytest.approx(dH, rel=TOL, abs=1e-6), small
