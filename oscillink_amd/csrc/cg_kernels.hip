@@ -85,9 +85,12 @@ __device__ __forceinline__ void block_fold(float4 (&dot)[NCH], float* red /*[4][
   }
 }
 
+#ifndef OSC_SPMM_U1
+#define OSC_SPMM_U1 2
+#endif
 template <int NCH>
-struct Unroll {
-  static constexpr int U = NCH <= 3 ? 4 : (NCH <= 6 ? 2 : 1);
+struct Unroll {  // neighbour rows fetched per batch (all loads in flight together)
+  static constexpr int U = NCH == 1 ? OSC_SPMM_U1 : (NCH <= 3 ? 4 : (NCH <= 6 ? 2 : 1));
 };
 
 // ---------------------------------------------------------------------------------------------
