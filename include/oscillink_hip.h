@@ -111,6 +111,8 @@ int osc_settle(osc_handle h, float dt, int32_t max_iters, float tol, int32_t pre
  * U* stays resident on the device for osc_deltaH / receipts; Ustar_out (N x D) may be NULL. */
 int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out, int32_t* iters, float* res,
                     double* ms);
+/* 1 iff a U* of the current state (graph, psi, gates, lams, chain) is resident on the device */
+int osc_has_ustar(osc_handle h, int32_t* yes);
 /* copy the resident U* (N x D) to the host; OSC_E_STATE if no solve happened since the last state change */
 int osc_get_ustar(osc_handle h, float* out);
 /* residual after every iteration of the last solve (solver.py:29), n <= cap entries written */

@@ -1002,10 +1002,10 @@ int osc_set_lams(osc_handle h, float lamG, float lamC, float lamQ) {
     if (!(lamG > 0)) throw Invalid("lamG must be > 0 for SPD");
     if (lamC < 0) throw Invalid("lamC must be >= 0");
     if (lamQ < 0) throw Invalid("lamQ must be >= 0");
+    if (l.lamG != lamG || l.lamC != lamC || l.lamQ != lamQ) l.have_ustar = false;  // U* belongs to the old lams
     l.lamG = lamG;
     l.lamC = lamC;
     l.lamQ = lamQ;
-    l.have_ustar = false;
   });
 }
 
@@ -1093,6 +1093,12 @@ int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out
       download_rows(l, Ustar_out, l.Ustar.p);
       sync(l);
     }
+  });
+}
+
+int osc_has_ustar(osc_handle h, int32_t* yes) {
+  return guarded(h, [&](L& l) {
+    if (yes) *yes = l.have_ustar ? 1 : 0;
   });
 }
 

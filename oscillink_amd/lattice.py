@@ -382,7 +382,8 @@ class OscillinkLattice:
     # ------------------------------------------------------------------ U* (lattice.py:232-296)
     def solve_Ustar(self, tol: float = 1e-4, max_iters: int = 64, use_cache: bool = True) -> np.ndarray:
         sig = self._signature()
-        if use_cache and self._Ustar_sig == sig and self._device_ustar_sig == sig:
+        if use_cache and self._Ustar_sig == sig and self._device_ustar_sig == sig and (
+                self._Ustar_cache is not None or self._device_has_ustar()):
             self.stats["ustar_cache_hits"] += 1
             self._log("ustar_cache_hit", {"signature": sig})
             if self._Ustar_cache is None:  # solved on the device for a receipt: fetch the rows on first host use
@@ -423,11 +424,16 @@ class OscillinkLattice:
     def _ensure_device_ustar(self) -> None:
         """U* resident on the device for the receipt kernels (same cache/stat semantics as solve_Ustar())."""
         sig = self._signature()
-        if self._Ustar_sig == sig and self._device_ustar_sig == sig:
+        if self._Ustar_sig == sig and self._device_ustar_sig == sig and self._device_has_ustar():
             self.stats["ustar_cache_hits"] += 1
             self._log("ustar_cache_hit", {"signature": sig})
             return
         self._solve_ustar_device(sig, 1e-4, 64, True)
+
+    def _device_has_ustar(self) -> bool:
+        yes = C.c_int32(0)
+        self._call("osc_has_ustar", C.byref(yes))
+        return bool(yes.value)
 
     def _host_ustar(self) -> np.ndarray:
         self._ensure_device_ustar()

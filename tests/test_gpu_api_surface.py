@@ -1,0 +1,248 @@
+"""Behavioural tests of the drop-in Python surface on the GPU, written against the behaviours the reference's own core
+tests pin (SURVEY.md section 4 lists them: tests/test_diffusion_gates.py, test_receipt_gating_stats.py,
+test_lattice_state_and_dynamics.py, test_new_enhancements.py, test_ustar_convergence_meta.py, test_spd_and_deltaH.py,
+test_lattice_receipt_and_start_modes.py, test_api_surface.py, test_perf_smoke.py).  Same names, arguments and error
+behaviour as `oscillink.OscillinkLattice`; every number comes from the HIP path."""
+import io
+import json
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import oscillink_amd
+
+    return oscillink_amd
+
+
+def _lattice(amd, N=40, D=12, k=5, seed=0, **kw):
+    rng = np.random.default_rng(seed)
+    Y = rng.normal(size=(N, D)).astype(np.float32)
+    psi = Y[:6].mean(axis=0)
+    psi = (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
+    lat = amd.OscillinkLattice(Y, kneighbors=k, **kw)
+    lat.set_query(psi)
+    return lat
+
+
+def test_public_names_and_alias(amd):
+    assert amd.Oscillink is amd.OscillinkLattice
+    for name in ("verify_receipt", "verify_receipt_mode", "compute_diffusion_gates", "json_line_logger"):
+        assert hasattr(amd, name)
+    lat = _lattice(amd)
+    for attr in ("Y", "U", "N", "D", "A", "L_sym", "sqrt_deg", "B_diag", "psi", "lamG", "lamC", "lamQ", "lamP", "L_path",
+                 "A_path", "last", "stats", "_kneighbors", "_chain_nodes"):
+        assert hasattr(lat, attr), attr
+    assert lat.L_path is None and lat.A_path is None and lat.last == {"iters": 0, "res": None, "t_ms": None}
+    assert lat.A.shape == (lat.N, lat.N) and lat.L_sym.shape == (lat.N, lat.N) and lat.sqrt_deg.shape == (lat.N,)
+    assert np.allclose(np.diag(lat.L_sym), 1.0)  # zero-diagonal adjacency: diag(L) = 1 (graph.py:86-93)
+
+
+def test_spd_energy_is_nonnegative_with_chain(amd):
+    lat = _lattice(amd, N=80, D=64, k=6, seed=1)
+    lat.add_chain([0, 3, 5, 9, 12], lamP=0.2)
+    lat.settle(dt=1.0, max_iters=8, tol=1e-3)
+    assert lat.receipt()["deltaH_total"] >= -1e-5
+
+
+def test_receipt_shape_and_convergence_meta(amd):
+    lat = _lattice(amd)
+    st = lat.settle(max_iters=4)
+    assert set(st) == {"iters", "res", "t_ms"} and st["iters"] >= 1 and st["t_ms"] >= 0
+    r = lat.receipt()
+    assert set(r) == {"version", "deltaH_total", "coh_drop_sum", "anchor_pen_sum", "query_term_sum", "cg_iters",
+                      "residual", "t_ms", "null_points", "meta"}
+    m = r["meta"]
+    for key in ("ustar_cached", "ustar_solves", "ustar_cache_hits", "ustar_converged", "ustar_res", "ustar_iters",
+                "ustar_solve_ms", "graph_build_ms", "last_settle_ms", "avg_degree", "edge_density", "gates_min",
+                "gates_max", "gates_mean", "gates_uniform", "state_sig", "receipt_detail", "null_points_summary"):
+        assert key in m, key
+    assert m["ustar_solves"] >= 1 and m["ustar_res"] >= 0 and m["ustar_iters"] >= 1
+    assert r["cg_iters"] == st["iters"] and m["avg_degree"] == pytest.approx(np.sum(lat.A > 0) / lat.N)
+    # receipt before any settle: None placeholders read as 0 (lattice.py:433-436)
+    fresh = _lattice(amd, seed=3)
+    r0 = fresh.receipt()
+    assert r0["cg_iters"] == 0 and r0["residual"] == 0.0 and r0["t_ms"] == 0.0
+
+
+def test_light_and_full_receipt_modes(amd):
+    lat = _lattice(amd, N=60, D=16, k=5, seed=4)
+    lat.settle()
+    full = lat.receipt()
+    lat.set_receipt_detail("light")
+    light = lat.receipt()
+    assert light["meta"]["receipt_detail"] == "light" and full["meta"]["receipt_detail"] == "full"
+    assert light["coh_drop_sum"] == 0.0 and light["anchor_pen_sum"] == 0.0 and light["null_points"] == []
+    assert light["deltaH_total"] == pytest.approx(full["deltaH_total"], rel=1e-6)
+    assert full["anchor_pen_sum"] > 0
+
+
+def test_warm_start_inertia_and_cold_start_move_the_state(amd):
+    lat = _lattice(amd, N=50, D=10, k=4, seed=5)
+    lat.settle(max_iters=3)
+    U1 = lat.U.copy()
+    lat.settle(max_iters=3, warm_start=True, inertia=0.5)
+    U2 = lat.U.copy()
+    assert not np.allclose(U1, U2)
+    lat.settle(max_iters=3, warm_start=False)
+    assert lat.U.shape == U1.shape and np.isfinite(lat.U).all()
+
+
+def test_refresh_and_cache_counters(amd):
+    lat = _lattice(amd, N=25, D=12, k=4, seed=6)
+    lat.receipt()
+    before = lat.stats["ustar_solves"]
+    lat.refresh_Ustar()
+    assert lat.stats["ustar_solves"] == before + 1
+    hits = lat.stats["ustar_cache_hits"]
+    a = lat.solve_Ustar()
+    b = lat.solve_Ustar()
+    assert a is b and lat.stats["ustar_cache_hits"] == hits + 2  # returned U* is the cached array itself
+    lat.set_gates(np.full(lat.N, 0.5, dtype=np.float32))  # any state change invalidates the cache
+    lat.solve_Ustar()
+    assert lat.stats["ustar_solves"] == before + 2
+
+
+def test_callbacks_logger_and_swallowed_exceptions(amd):
+    lat = _lattice(amd, N=18, D=10, k=3, seed=7)
+    seen = {}
+
+    def cb(lattice, stats):
+        seen["iters"] = stats["iters"]
+        seen["same"] = lattice is lat
+
+    def bad(lattice, stats):
+        raise RuntimeError("callbacks must not break settle")
+
+    lat.add_settle_callback(cb)
+    lat.add_settle_callback(bad)
+    lat.settle(max_iters=3)
+    assert seen == {"iters": lat.last["iters"], "same": True}
+    lat.remove_settle_callback(cb)
+    lat.remove_settle_callback(cb)  # removing twice is a no-op
+    buf = io.StringIO()
+    lat.set_logger(amd.json_line_logger(stream=buf))
+    lat.settle(max_iters=2, tol=1e-3, warm_start=False)
+    lat.receipt()
+    lat.add_chain([0, 1, 2])
+    lat.clear_chain()
+    lat.rebuild_graph(kneighbors=4)
+    events = [json.loads(line)["event"] for line in buf.getvalue().strip().splitlines()]
+    for ev in ("settle", "receipt", "ustar_solve", "add_chain", "clear_chain", "rebuild_graph", "invalidate_cache"):
+        assert ev in events, ev
+    lat.set_logger(lambda ev, payload: 1 / 0)  # logger exceptions are swallowed too
+    lat.settle(max_iters=1)
+    events.clear()
+    lat.set_logger(lambda ev, payload: events.append(ev))
+    lat.settle(max_iters=1, tol=1e-12)  # far from tol after 1 iteration -> convergence warning event
+    assert "settle_convergence_warn" in events
+
+
+def test_dynamics_snapshot_when_enabled(amd, monkeypatch):
+    lat = _lattice(amd, N=30, D=8, k=4, seed=8)
+    monkeypatch.setenv("OSCILLINK_RECEIPT_DYNAMICS", "1")
+    lat.settle(max_iters=3, tol=1e-3, warm_start=False)
+    dyn = lat.receipt()["meta"]["dynamics"]
+    for key in ("temperature", "step_deltaH", "viscosity_step", "flow_total", "top_flows", "radius", "move2_mean",
+                "move2_max"):
+        assert key in dyn
+    assert dyn["temperature"] > 0 and dyn["radius"] >= 0 and len(dyn["top_flows"]) <= 16
+    monkeypatch.delenv("OSCILLINK_RECEIPT_DYNAMICS")
+    assert "dynamics" not in lat.receipt()["meta"]
+
+
+def test_bundle_and_chain_receipt_structure(amd):
+    lat = _lattice(amd, N=30, D=8, k=4, seed=9)
+    lat.settle()
+    b = lat.bundle(k=3, alpha=0.6)
+    assert len(b) == 3 and {"id", "score", "align"} <= set(b[0]) and len({x["id"] for x in b}) == 3
+    assert lat.bundle(k=0) == [] and len(lat.bundle(k=100)) == lat.N
+    chain = [0, 2, 5, 9]
+    lat.add_chain(chain, lamP=0.25)
+    cr = lat.chain_receipt(chain, z_th=10.0)
+    assert isinstance(cr["verdict"], bool) and len(cr["edges"]) == len(chain) - 1
+    assert set(cr["weakest_link"]) == {"k", "edge", "zscore"} and "coherence_gain" in cr
+    for e in cr["edges"]:
+        assert set(e) == {"k", "edge", "z_struct", "z_path", "r_struct", "r_path"}
+
+
+def test_gating_stats_uniform_and_diffusion(amd):
+    rng = np.random.default_rng(2)
+    Y = rng.normal(size=(60, 24)).astype(np.float32)
+    psi = rng.normal(size=(24,)).astype(np.float32)
+    lat = amd.OscillinkLattice(Y, kneighbors=6)
+    lat.set_query(psi)
+    lat.settle()
+    m = lat.receipt()["meta"]
+    assert m["gates_min"] == m["gates_max"] == m["gates_mean"] == 1.0 and m["gates_uniform"] is True
+    gates = amd.compute_diffusion_gates(Y, psi, kneighbors=6, beta=1.0, gamma=0.15, neighbor_seed=42)
+    lat.set_query(psi, gates=gates)
+    lat.settle()
+    m = lat.receipt()["meta"]
+    assert 0.0 <= m["gates_min"] < m["gates_max"] <= 1.0 + 1e-6 and m["gates_uniform"] is False
+
+
+def test_diffusion_gate_properties(amd):
+    rng = np.random.default_rng(42)
+    Y = rng.normal(size=(60, 32)).astype(np.float32)
+    psi = rng.normal(size=(32,)).astype(np.float32)
+    g = amd.compute_diffusion_gates(Y, psi, kneighbors=5, beta=1.2, gamma=0.15, neighbor_seed=123)
+    assert g.shape == (60,) and g.dtype == np.float32 and g.min() >= 0.0 and g.max() <= 1.0 and np.var(g) > 0
+    assert np.array_equal(g, amd.compute_diffusion_gates(Y, psi, kneighbors=5, beta=1.2, gamma=0.15, neighbor_seed=123))
+    # rows near psi get larger gates than unrelated rows
+    rng = np.random.default_rng(7)
+    base = rng.normal(size=(16,)).astype(np.float32)
+    q = base / (np.linalg.norm(base) + 1e-12)
+    Yc = np.vstack([q + 0.01 * rng.normal(size=(10, 16)), rng.normal(size=(10, 16))]).astype(np.float32)
+    gc = amd.compute_diffusion_gates(Yc, q, kneighbors=4, gamma=0.2, beta=1.0, deterministic_k=True)
+    assert gc[:10].mean() > gc[10:].mean()
+    # direct (served by CG to round-off) and cg agree; unclamped output is raw h
+    gd = amd.compute_diffusion_gates(Y, psi, kneighbors=5, gamma=0.15, method="direct")
+    gi = amd.compute_diffusion_gates(Y, psi, kneighbors=5, gamma=0.15, method="cg", tol=1e-6)
+    assert np.allclose(gd, gi, atol=5e-5)
+    for bad in (dict(gamma=0.0), dict(kneighbors=0), dict(similarity="dot")):
+        with pytest.raises(ValueError):
+            amd.compute_diffusion_gates(Y, psi, **bad)
+    with pytest.raises(ValueError):
+        amd.compute_diffusion_gates(Y, psi[:5])
+    with pytest.raises(ValueError):
+        amd.compute_diffusion_gates(Y[0], psi)
+
+
+def test_attribute_assignment_is_honoured(amd):
+    """lamG/lamC/lamQ/lamP, psi, B_diag and U are plain attributes in the reference; assigning them must take effect."""
+    rng = np.random.default_rng(11)
+    Y = rng.normal(size=(70, 20)).astype(np.float32)
+    psi = rng.normal(size=(20,)).astype(np.float32)
+    a = amd.OscillinkLattice(Y, kneighbors=5, lamC=0.9, lamQ=2.0, deterministic_k=True)
+    a.set_query(psi)
+    b = amd.OscillinkLattice(Y, kneighbors=5, deterministic_k=True)
+    b.psi = psi
+    b.lamC, b.lamQ = 0.9, 2.0
+    a.settle()
+    b.settle()
+    assert np.array_equal(a.U, b.U) and a._signature() == b._signature()
+    b.B_diag = np.linspace(0.1, 1.0, 70).astype(np.float32)
+    a.set_gates(np.linspace(0.1, 1.0, 70).astype(np.float32))
+    b.U = a.U
+    assert np.array_equal(a.solve_Ustar(), b.solve_Ustar())
+    with pytest.raises(ValueError):
+        b.U = np.zeros((3, 3), dtype=np.float32)
+
+
+def test_small_lattice_latency_budget(amd):
+    """The reference guards settle+receipt < 1500 ms at N=64 (tests/test_perf_smoke.py:8-20); on the GPU the same
+    calls are sub-millisecond -- keep a generous 50 ms guard against accidental host-side regressions."""
+    lat = _lattice(amd, N=64, D=32, k=6, seed=12)
+    lat.settle()
+    lat.receipt()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        lat.settle(max_iters=6, tol=1e-3)
+        lat.receipt()
+    assert (time.perf_counter() - t0) / 10 < 0.05
