@@ -640,3 +640,69 @@ def test_tiny_and_very_wide_shapes(amd, orc, N, D, k, monkeypatch):
         assert a_["iters"] == b_["iters"], small
         assert relerr(lat.U, ref.U) < 2e-5, small
         assert lat.receipt()["deltaH_total"] == pytest.approx(dH, rel=TOL, abs=1e-6), small
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_operation_sequences_track_the_oracle(amd, orc, seed):
+    """State-machine check: a seeded random sequence of the public calls (queries, gates, chains, lams, settles with
+    every start mode, U* refreshes, receipts, graph rebuilds) is applied to the product and to the oracle; after every
+    step the settled state, the iteration count and deltaH must agree.  Guards the host-side cache/invalidations."""
+    rng = np.random.default_rng(100 + seed)
+    N, D, k = int(rng.integers(40, 400)), int(rng.integers(3, 70)), int(rng.integers(2, 9))
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    ref = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True)
+    lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+    assert np.allclose(lat.A, ref.A, rtol=1e-5, atol=1e-8)
+    lat.set_receipt_detail("light")
+    for step in range(30):
+        op = int(rng.integers(0, 9))
+        if op == 0:
+            psi = rng.standard_normal(D).astype(np.float32)
+            ref.set_query(psi)
+            lat.set_query(psi)
+        elif op == 1:
+            g = rng.uniform(0.0, 1.0, N).astype(np.float32)
+            ref.set_gates(g)
+            lat.set_gates(g)
+        elif op == 2:
+            chain = rng.integers(0, N, size=int(rng.integers(2, 7))).tolist()
+            w = rng.uniform(0.2, 2.0, len(chain) - 1).tolist() if rng.random() < 0.5 else None
+            lp = float(rng.choice([0.0, 0.2, 0.7]))
+            ref.add_chain(chain, lamP=lp, weights=w)
+            lat.add_chain(chain, lamP=lp, weights=w)
+        elif op == 3:
+            ref.clear_chain()
+            lat.clear_chain()
+        elif op == 4:
+            lc, lq = float(rng.uniform(0.0, 1.5)), float(rng.uniform(0.0, 5.0))
+            ref.lamC, ref.lamQ = lc, lq
+            lat.lamC, lat.lamQ = lc, lq
+        elif op == 5:
+            kw = [dict(), dict(warm_start=False), dict(inertia=float(rng.uniform(0.1, 0.9))),
+                  dict(dt=float(rng.uniform(0.2, 2.0))), dict(precond="none", max_iters=25),
+                  dict(tol=1e-5, max_iters=40)][int(rng.integers(0, 6))]
+            a_ = ref.settle(**kw)
+            b_ = lat.settle(**kw)
+            assert a_["iters"] == b_["iters"], (step, kw)
+        elif op == 6:
+            lat.refresh_Ustar()
+        elif op == 7 and step % 3 == 0:
+            k2 = int(rng.integers(2, 9))
+            lat.rebuild_graph(kneighbors=k2)
+            ref = _rebuild_oracle(orc, ref, k2)
+        # every step ends with a receipt on both sides
+        assert relerr(lat.U, ref.U) < 5e-5, (step, op)
+        dH = ref.deltaH()
+        got = lat.receipt()["deltaH_total"]
+        assert got == pytest.approx(dH, rel=2e-4, abs=2e-4 * max(1.0, abs(dH))), (step, op)
+
+
+def _rebuild_oracle(orc, old, k):
+    new = orc.OracleLattice(old.Y, kneighbors=k, deterministic_k=True)
+    new.U = old.U.copy()
+    new.set_query(old.psi, gates=old.B_diag)
+    new.lamG, new.lamC, new.lamQ = old.lamG, old.lamC, old.lamQ
+    if old._chain_nodes is not None:
+        new.A_path, new.W_path, new.L_path = old.A_path, old.W_path, old.L_path
+        new.lamP, new._chain_nodes = old.lamP, old._chain_nodes
+    return new
