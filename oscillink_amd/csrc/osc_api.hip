@@ -204,10 +204,18 @@ void use_device(L& h) { HIP_CHECK(hipSetDevice(h.device)); }
 void sync(L& h) { HIP_CHECK(hipStreamSynchronize(h.stream)); }
 
 void upload_rows(L& h, float* dst, const float* src) {  // N x D host -> N x ld device
+  if (h.ld == h.D) {  // no row padding: one contiguous copy (much faster than the strided form from pageable memory)
+    HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)h.N * h.D * 4, hipMemcpyHostToDevice, h.stream));
+    return;
+  }
   HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)h.ld * 4, src, (size_t)h.D * 4, (size_t)h.D * 4, (size_t)h.N,
                              hipMemcpyHostToDevice, h.stream));
 }
 void download_rows(L& h, float* dst, const float* src) {
+  if (h.ld == h.D) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)h.N * h.D * 4, hipMemcpyDeviceToHost, h.stream));
+    return;
+  }
   HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)h.D * 4, src, (size_t)h.ld * 4, (size_t)h.D * 4, (size_t)h.N,
                              hipMemcpyDeviceToHost, h.stream));
 }

@@ -98,7 +98,7 @@ class OscillinkLattice:
         self._chain_weights: Optional[list[float]] = None
         self.last: dict[str, Any] = {"iters": 0, "res": None, "t_ms": None}
 
-        self._U_host: Optional[np.ndarray] = self.Y.copy()  # device U == Y right after create
+        self._U_host: Optional[np.ndarray] = None  # host mirror of the device U, fetched on first read
         self._csr = None  # (rowptr, col, a, w, sqrt_deg) host cache
         self._state_version = 0
         self._sig_cache: Optional[tuple] = None
