@@ -45,8 +45,12 @@ def main():
     ap.add_argument("--tol", type=float, default=1e-3)
     ap.add_argument("--max-iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=["column", "row"], default="column",
+                    help="multi-GPU CG partitioning: column slabs (one all-reduce(max) per iteration, default) or "
+                         "row blocks (halo exchange of p + all-reduces of D-vectors, the north-star wording)")
     args = ap.parse_args()
 
+    os.environ["OSC_SHARD"] = args.shard
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,13 +125,14 @@ def main():
     c0, c1 = C.c_int32(0), C.c_int32(0)
     lat._call("osc_comm_shard", C.byref(c0), C.byref(c1))
     d_local = int(c1.value - c0.value)
+    n_local = N // world if (args.shard == "row" and launched) else N  # rows this rank applies the operator to
     # The dominant kernel is the operator apply (CG matvec).  It is launched as column slabs (k_spmm<32,1,0> at
     # config 3: 6 slabs of 128 columns); the library times each apply (all its slab launches) with one HIP-event pair
     # on its own stream.  Algorithmic bytes of ONE apply on this rank: read X once, write the
     # result once, ELL col + val, rowptr/B/diag per row; per launch = per apply / slabs.
     slab = 128 if N * d_local * 4 > 2 * 56 * 1024 * 1024 else d_local
     slabs = max(1, (d_local + slab - 1) // slab)
-    bytes_apply = 8.0 * N * d_local + 8.0 * nnz + 12.0 * N
+    bytes_apply = 8.0 * n_local * d_local + (8.0 * nnz + 12.0 * N) * (n_local / N)
     apply_ms = total_ms.value / max(1, launches.value)
     bytes_mv = bytes_apply / slabs
     mv_ms = apply_ms / slabs
@@ -151,7 +156,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"config3: N={N} D={D} k={k} fp32 settle(dt=1,max_iters={args.max_iters},tol={args.tol})",
                    "N": N, "D": D, "k": k, "nnz": nnz, "max_degree": max_deg,
-                   "parallelism": "single" if world == 1 else f"column-sharded CG x{world}",
+                   "parallelism": "single" if not launched else f"{args.shard}-sharded CG x{world}",
                    "cg_iters_per_settle": iters_total / args.steps, "residual": last["res"]},
         "lattice_create_ms": graph_build_ms,  # first call in the process: HIP context + code objects + upload + build
         "graph_build_device_ms": dev_build_ms,

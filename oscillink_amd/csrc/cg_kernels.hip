@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
   for (int ch = 0; ch < NCH; ++ch) dot[ch] = f4(0.f);
 
   const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
-  for (int64_t rb = ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
+  for (int64_t rb = a.row0 + ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
     int row = (int)rb + sub;
     const bool rok = row < a.N;
     if (!rok) row = (int)a.N - 1;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
     rz[ch] = f4(0.f);
   }
   const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
-  for (int64_t rb = ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
+  for (int64_t rb = a.row0 + ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
     const int row = (int)rb + sub;
     if (row >= a.N) continue;
     float invMd = 1.f;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_update_p(const UpdateArgs a) {
     be[ch] = cok[ch] ? ld4(a.beta + coff[ch]) : f4(0.f);
   }
   const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
-  for (int64_t rb = ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
+  for (int64_t rb = a.row0 + ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
     const int row = (int)rb + sub;
     if (row >= a.N) continue;
     float invMd = 1.f;
@@ -391,10 +391,36 @@ __global__ __launch_bounds__(1024) void k_reduce_beta(const float* part_rr, cons
 }
 
 __global__ __launch_bounds__(1024) void k_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1,
-                                                     double* out_cols) {
+                                                     double* out_cols, Gate gt) {
+  if (gt.p != nullptr && *gt.p <= gt.tol) return;
   double t[1];
   int col;
   if (reduce_cols<1>(part, nullptr, nb, ld, c0, c1, t, col)) out_cols[col] = t[0];
+}
+
+// finish steps of the row-sharded CG (sums already complete across ranks)
+__global__ void k_finish_init(const double* sums, int32_t c0, int32_t c1, double* rz) {
+  const int col = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (col < c1) rz[col] = sums[col];
+}
+__global__ void k_finish_alpha(const double* sums, int32_t c0, int32_t c1, const double* rz, float* alpha, Gate gt) {
+  if (gt.p != nullptr && *gt.p <= gt.tol) return;
+  const int col = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (col < c1) alpha[col] = (float)(rz[col] / (sums[col] + 1e-18));
+}
+__global__ __launch_bounds__(256) void k_finish_beta(const double* srr, const double* srz, int32_t c0, int32_t c1,
+                                                     double* rz, float* beta, uint32_t* res_bits, Gate gt) {
+  if (gt.p != nullptr && *gt.p <= gt.tol) return;
+  const int col = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  float resc = 0.f;
+  if (col < c1) {
+    resc = (float)sqrt(srr[col]);
+    beta[col] = (float)(srz[col] / (rz[col] + 1e-18));
+    rz[col] = srz[col];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) resc = fmaxf(resc, __shfl_xor(resc, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(res_bits, __float_as_uint(resc));
 }
 
 __global__ __launch_bounds__(256) void k_axpby(float* out, const float* a, float ca, const float* b, float cb,
@@ -489,7 +515,28 @@ void launch_reduce_beta(const float* part_rr, const float* part_rz, int nb, int3
   HIP_CHECK(hipGetLastError());
 }
 void launch_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_sum, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part, nb, ld, c0, c1, out_cols);
+  hipLaunchKernelGGL(k_reduce_sum, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part, nb, ld, c0, c1, out_cols,
+                     Gate{nullptr, 0.f});
+  HIP_CHECK(hipGetLastError());
+}
+void launch_reduce_sum_gated(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols, Gate g,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_sum, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part, nb, ld, c0, c1, out_cols, g);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_finish_init(const double* sums, int32_t c0, int32_t c1, double* rz, hipStream_t s) {
+  hipLaunchKernelGGL(k_finish_init, dim3((c1 - c0 + 255) / 256), dim3(256), 0, s, sums, c0, c1, rz);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_finish_alpha(const double* sums, int32_t c0, int32_t c1, const double* rz, float* alpha, Gate g,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(k_finish_alpha, dim3((c1 - c0 + 255) / 256), dim3(256), 0, s, sums, c0, c1, rz, alpha, g);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_finish_beta(const double* sums_rr, const double* sums_rz, int32_t c0, int32_t c1, double* rz, float* beta,
+                        uint32_t* res_bits_slot, Gate g, hipStream_t s) {
+  hipLaunchKernelGGL(k_finish_beta, dim3((c1 - c0 + 255) / 256), dim3(256), 0, s, sums_rr, sums_rz, c0, c1, rz, beta,
+                     res_bits_slot, g);
   HIP_CHECK(hipGetLastError());
 }
 void launch_axpby(float* out, const float* a, float ca, const float* b, float cb, int64_t n, hipStream_t s) {

@@ -86,7 +86,8 @@ struct SpmmArgs {
   const float* B;     // [N]
   const float* psi;   // [ld]
   float* part;        // [grid][ld] column partial sums of the mode's dot product
-  int64_t N;
+  int64_t N;          // end of the row range this launch works on (rows [row0, N))
+  int64_t row0;       // first row (0 except in row-sharded multi-GPU runs)
   int32_t ld;         // row pitch in floats (multiple of 4)
   int32_t c0, c1;     // column window [c0, c1), multiples of 4
   // speculative-launch gate: the kernel is a no-op when *gate <= gate_tol (the CG already converged; the host
@@ -106,7 +107,8 @@ struct UpdateArgs {
   float* part_rr;      // [grid][ld]
   float* part_rz;      // [grid][ld]
   OpParams op;
-  int64_t N;
+  int64_t N;      // rows [row0, N)
+  int64_t row0;
   int32_t ld, c0, c1;
   const float* gate;  // see SpmmArgs
   float gate_tol;
@@ -131,5 +133,13 @@ void launch_reduce_beta(const float* part_rr, const float* part_rz, int nb, int3
 void launch_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols,
                        hipStream_t s);
 void launch_axpby(float* out, const float* a, float ca, const float* b, float cb, int64_t n, hipStream_t s);
+// row-sharded CG: the column sums are completed across ranks (all-reduce of fp64 sums) before these finish steps
+void launch_finish_init(const double* sums, int32_t c0, int32_t c1, double* rz, hipStream_t s);
+void launch_finish_alpha(const double* sums, int32_t c0, int32_t c1, const double* rz, float* alpha, Gate g,
+                         hipStream_t s);
+void launch_finish_beta(const double* sums_rr, const double* sums_rz, int32_t c0, int32_t c1, double* rz, float* beta,
+                        uint32_t* res_bits_slot, Gate g, hipStream_t s);
+void launch_reduce_sum_gated(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols, Gate g,
+                             hipStream_t s);
 
 }  // namespace osc

@@ -128,6 +128,9 @@ struct osc_lattice {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
   bool u_sharded = false;  // U holds only this rank's columns (after a sharded settle)
+  int shard_mode = 0;      // 0 = column-sharded CG (default), 1 = row-sharded CG (north-star wording; OSC_SHARD=row)
+  int fake_row_shards = 0; // test hook (OSC_ROW_FAKE_SHARDS=V): V row shards on this one GPU, collectives local
+  DevBuf<double> sums;     // [2][ld] completed column sums of the row-sharded CG
   DevBuf<float> comm_buf;
   // profiling
   bool prof_on = false;
@@ -569,7 +572,11 @@ bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, 
   return true;
 }
 
+CgResult run_cg_rows(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol);
+bool row_mode(const L& h);
+
 CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol) {
+  if (row_mode(h) && b.ld == h.ld) return run_cg_rows(h, op, b, with_path, max_iters, tol);
   {
     CgResult small{};
     if (run_cg_small(h, op, b, with_path, max_iters, tol, small)) return small;
@@ -696,6 +703,172 @@ void gather_columns(L& h, float* arr) {
   }
 }
 
+// ---- row-sharded CG (BASELINE north_star wording) --------------------------------------------------------------
+// Rank r owns rows [N r/G, N (r+1)/G) of every N x D array and of the lattice graph.  Per iteration: the local rows of
+// the search direction p are exchanged so every rank holds all of p for the neighbour gathers ("halo": on i.i.d.
+// anchors ~all rows are somebody's neighbour, so the halo is the whole array), and the column sums (p.Ap, then
+// [r.r, r.z]) are completed with all-reduces of fp64 D-vectors before alpha / beta / the residual are formed.
+struct RowShard {
+  int64_t r0, r1;
+};
+
+std::vector<RowShard> row_shards(const L& h) {
+  std::vector<RowShard> v;
+  if (h.comm) {
+    v.push_back({h.N * h.rank / h.world, h.N * (h.rank + 1) / h.world});
+  } else {
+    const int V = std::max(1, h.fake_row_shards);
+    for (int s = 0; s < V; ++s) v.push_back({h.N * s / V, h.N * (s + 1) / V});
+  }
+  return v;
+}
+
+// make every rank's copy of `arr` complete: each rank broadcasts its own row block (grouped, in place)
+void exchange_rows(L& h, float* arr, int32_t ld) {
+  if (!h.comm) return;  // (a 1-rank communicator still runs the calls: that is how one GPU exercises this path)
+  if (ncclGroupStart() != ncclSuccess) throw CommError("ncclGroupStart failed");
+  for (int r = 0; r < h.world; ++r) {
+    const int64_t a = h.N * r / h.world, b = h.N * (r + 1) / h.world;
+    if (b <= a) continue;
+    float* blk = arr + (size_t)a * ld;
+    if (ncclBroadcast(blk, blk, (size_t)(b - a) * ld, ncclFloat, r, h.comm, h.stream) != ncclSuccess)
+      throw CommError("ncclBroadcast(row block) failed");
+  }
+  if (ncclGroupEnd() != ncclSuccess) throw CommError("ncclGroupEnd failed");
+}
+
+void allreduce_sums(L& h, double* buf, size_t n) {
+  if (!h.comm) return;
+  if (ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, h.comm, h.stream) != ncclSuccess)
+    throw CommError("ncclAllReduce(column sums) failed");
+}
+
+CgResult run_cg_rows(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol) {
+  const std::vector<RowShard> shards = row_shards(h);
+  const int V = (int)shards.size();
+  const int grid = cg_grid(h);
+  const size_t pn = (size_t)V * grid * b.ld;  // one block of partial rows per local shard
+  if (h.part0.n < pn) h.part0.alloc(pn);
+  if (h.part1.n < pn) h.part1.alloc(pn);
+  h.sums.alloc((size_t)2 * b.ld);
+  double* s0 = h.sums.p;
+  double* s1 = h.sums.p + b.ld;
+  HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, ((size_t)max_iters + 2) * 4, h.stream));
+  if (h.res_host_n < (size_t)max_iters + 2) {
+    if (h.res_host) (void)hipHostFree(h.res_host);
+    h.res_host = nullptr;
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h.res_host), ((size_t)max_iters + 2) * 4, hipHostMallocDefault));
+    h.res_host_n = (size_t)max_iters + 2;
+  }
+  while (h.iter_events.size() < (size_t)max_iters + 2) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h.iter_events.push_back(e);
+  }
+  const float* res_dev = reinterpret_cast<const float*>(h.res_bits.p);
+  SpmmArgs sa{};
+  sa.g = graph_view(h, with_path);
+  sa.op = op;
+  sa.B = b.B;
+  sa.psi = b.psi;
+  sa.ld = b.ld;
+  sa.c0 = b.c0;
+  sa.c1 = b.c1;
+  UpdateArgs ua{};
+  ua.X = b.X;
+  ua.R = b.R;
+  ua.P = b.P;
+  ua.AP = b.AP;
+  ua.B = b.B;
+  ua.alpha = h.alpha.p;
+  ua.beta = h.beta.p;
+  ua.op = op;
+  ua.ld = b.ld;
+  ua.c0 = b.c0;
+  ua.c1 = b.c1;
+  auto for_shards_spmm = [&](int mode, int iter) {
+    for (int s = 0; s < V; ++s) {
+      sa.row0 = shards[(size_t)s].r0;
+      sa.N = shards[(size_t)s].r1;
+      sa.part = h.part0.p + (size_t)s * grid * b.ld;
+      spmm_slabbed(h, mode, sa, grid, iter);
+    }
+  };
+  // r = b - A x0 ; z ; p ; rz
+  sa.X = b.x0;
+  sa.OUT = b.X;
+  sa.R = b.R;
+  sa.P = b.P;
+  sa.U = b.rhsU;
+  sa.Y = b.rhsY;
+  sa.gate = nullptr;
+  for_shards_spmm(SPMM_INIT, 0);
+  launch_reduce_sum(h.part0.p, V * grid, b.ld, b.c0, b.c1, s0, h.stream);
+  allreduce_sums(h, s0 + b.c0, (size_t)(b.c1 - b.c0));
+  launch_finish_init(s0, b.c0, b.c1, h.rz.p, h.stream);
+  exchange_rows(h, b.P, b.ld);
+  sa.X = b.P;
+  sa.OUT = b.AP;
+
+  auto enqueue_iter = [&](int it) {
+    const Gate g{it > 1 ? res_dev + (it - 1) : nullptr, tol};
+    sa.gate = g.p;
+    sa.gate_tol = tol;
+    ua.gate = g.p;
+    ua.gate_tol = tol;
+    if (it > 1) {
+      for (int s = 0; s < V; ++s) {
+        ua.row0 = shards[(size_t)s].r0;
+        ua.N = shards[(size_t)s].r1;
+        ProfScope ps(h, 2, it);
+        for_windows(ua, [&](const UpdateArgs& w) { launch_update_p(w, grid, h.stream); });
+      }
+      exchange_rows(h, b.P, b.ld);  // the halo exchange of this iteration
+    }
+    for_shards_spmm(SPMM_AP, it);
+    launch_reduce_sum_gated(h.part0.p, V * grid, b.ld, b.c0, b.c1, s0, g, h.stream);
+    allreduce_sums(h, s0 + b.c0, (size_t)(b.c1 - b.c0));
+    launch_finish_alpha(s0, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
+    for (int s = 0; s < V; ++s) {
+      ua.row0 = shards[(size_t)s].r0;
+      ua.N = shards[(size_t)s].r1;
+      ua.part_rr = h.part0.p + (size_t)s * grid * b.ld;
+      ua.part_rz = h.part1.p + (size_t)s * grid * b.ld;
+      ProfScope ps(h, 1, it);
+      for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });
+    }
+    launch_reduce_sum_gated(h.part0.p, V * grid, b.ld, b.c0, b.c1, s0, g, h.stream);
+    launch_reduce_sum_gated(h.part1.p, V * grid, b.ld, b.c0, b.c1, s1, g, h.stream);
+    allreduce_sums(h, s0, (size_t)2 * b.ld);  // [r.r | r.z] in one message
+    launch_finish_beta(s0, s1, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream);
+    HIP_CHECK(hipMemcpyAsync(h.res_host + it, h.res_bits.p + it, 4, hipMemcpyDeviceToHost, h.stream));
+    HIP_CHECK(hipEventRecord(h.iter_events[(size_t)it], h.stream));
+  };
+
+  h.history.clear();
+  CgResult out{max_iters, 0.f};
+  const size_t prof_mark = h.prof_pending.size();
+  enqueue_iter(1);
+  for (int it = 1; it <= max_iters; ++it) {
+    if (it < max_iters) enqueue_iter(it + 1);
+    HIP_CHECK(hipEventSynchronize(h.iter_events[(size_t)it]));
+    const float res = h.res_host[it];
+    h.history.push_back(res);
+    out.res = res;
+    if ((double)res <= (double)tol) {
+      out.iters = it;
+      break;
+    }
+  }
+  exchange_rows(h, b.X, b.ld);  // every rank leaves with the whole solution
+  sync(h);
+  for (size_t i = prof_mark; i < h.prof_pending.size(); ++i)
+    if (h.prof_pending[i].iter > out.iters) h.prof_pending[i].which = -1;
+  return out;
+}
+
+bool row_mode(const L& h) { return h.shard_mode == 1 && (h.comm != nullptr || h.fake_row_shards > 1); }
+
 void require_graph(L& h) {
   if (!h.have_graph) throw StateError("no lattice graph: build it (osc_create build_graph=1) or inject one (osc_set_csr)");
 }
@@ -792,6 +965,8 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_SPMM_SLAB")) h->spmm_slab = atoi(e) < 0 ? -1 : (atoi(e) / 4) * 4;
     if (const char* e = getenv("OSC_GRID_CAP")) h->grid_cap = std::max(1, atoi(e));
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
+    if (const char* e = getenv("OSC_SHARD")) h->shard_mode = !strcmp(e, "row") ? 1 : 0;
+    if (const char* e = getenv("OSC_ROW_FAKE_SHARDS")) h->fake_row_shards = std::max(0, atoi(e));
     const size_t n = (size_t)N * h->ld;
     for (DevBuf<float>* b : {&h->Y, &h->U, &h->X, &h->R, &h->P, &h->AP, &h->Ustar}) b->alloc(n);
     HIP_CHECK(hipMemsetAsync(h->Y.p, 0, n * 4, h->stream));
@@ -1034,7 +1209,7 @@ int osc_set_U(osc_handle h, const float* U) {
     if (U) {
       upload_rows(l, l.U.p, U);
       l.u_sharded = false;
-    } else if (l.comm && l.world > 1) {  // column-sharded: only this rank's slab takes part in the next solve
+    } else if (l.comm && l.world > 1 && l.shard_mode == 0) {  // column-sharded: only this rank's slab is needed
       HIP_CHECK(hipMemcpy2DAsync(l.U.p + l.c0, (size_t)l.ld * 4, l.Y.p + l.c0, (size_t)l.ld * 4,
                                  (size_t)(l.c1 - l.c0) * 4, (size_t)l.N, hipMemcpyDeviceToDevice, l.stream));
       l.u_sharded = true;
@@ -1070,7 +1245,7 @@ int osc_settle(osc_handle h, float dt, int32_t max_iters, float tol, int32_t pre
     // when x0 aliases AP the INIT pass reads it completely before the first SPMM_AP launch writes AP: same stream
     const CgResult r = run_cg(l, op, b, path_active(l), max_iters, tol);
     l.U.swap(l.X);  // U <- U+ (lattice.py:206)
-    if (l.comm && l.world > 1) {
+    if (l.comm && l.world > 1 && l.shard_mode == 0) {
       // the swapped-in buffer only holds this rank's columns; the others are refreshed lazily by osc_get_U.
       l.u_sharded = true;
     }
@@ -1092,7 +1267,7 @@ int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out
     CgBuffers b{l.Y.p, l.X.p, l.R.p, l.P.p, l.AP.p, l.U.p, l.Y.p, l.B.p, l.psi.p, l.ld, l.c0, l.c1};
     const CgResult r = run_cg(l, op, b, path_active(l), max_iters, tol);
     l.Ustar.swap(l.X);
-    gather_columns(l, l.Ustar.p);  // receipts read whole rows of U*
+    if (l.shard_mode == 0) gather_columns(l, l.Ustar.p);  // receipts read whole rows of U* (row mode: already whole)
     l.have_ustar = true;
     if (ms) *ms = now_ms() - t0;
     if (iters) *iters = r.iters;
@@ -1215,14 +1390,27 @@ int osc_deltaH(osc_handle h, double* dH) {
     sa.X = l.P.p;
     sa.B = l.B.p;
     sa.psi = l.psi.p;
-    sa.part = l.part0.p;
-    sa.N = l.N;
     sa.ld = l.ld;
     sa.c0 = l.c0;
     sa.c1 = l.c1;
     sa.gate = nullptr;
-    spmm_slabbed(l, SPMM_DOT, sa, grid);
-    launch_reduce_sum(l.part0.p, grid, l.ld, l.c0, l.c1, l.colsum.p, l.stream);
+    int nb = grid;
+    if (row_mode(l)) {  // each rank (or fake shard) sums its own rows; the scalar is all-reduced below
+      const std::vector<RowShard> shards = row_shards(l);
+      nb = (int)shards.size() * grid;
+      if (l.part0.n < (size_t)nb * l.ld) l.part0.alloc((size_t)nb * l.ld);
+      for (size_t si = 0; si < shards.size(); ++si) {
+        sa.row0 = shards[si].r0;
+        sa.N = shards[si].r1;
+        sa.part = l.part0.p + si * grid * l.ld;
+        spmm_slabbed(l, SPMM_DOT, sa, grid);
+      }
+    } else {
+      sa.part = l.part0.p;
+      sa.N = l.N;
+      spmm_slabbed(l, SPMM_DOT, sa, grid);
+    }
+    launch_reduce_sum(l.part0.p, nb, l.ld, l.c0, l.c1, l.colsum.p, l.stream);
     std::vector<double> cs((size_t)l.ld, 0.0);
     HIP_CHECK(hipMemcpyAsync(cs.data() + l.c0, l.colsum.p + l.c0, (size_t)(l.c1 - l.c0) * 8, hipMemcpyDeviceToHost,
                              l.stream));
@@ -1399,6 +1587,10 @@ int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world)
     const int32_t lo = (int32_t)((int64_t)q * rank / world), hi = (int32_t)((int64_t)q * (rank + 1) / world);
     l.c0 = lo * 4;
     l.c1 = hi * 4;
+    if (l.shard_mode == 1) {  // row-sharded CG: every rank works on all columns of its row block
+      l.c0 = 0;
+      l.c1 = l.ld;
+    }
     if (l.c1 <= l.c0) throw Invalid("osc_comm_init: more ranks than 4-column groups");
     {
       ncclUniqueId uid;

@@ -73,6 +73,93 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_rows(rank, world, port, q):
+    """Row-sharded protocol (north-star wording): local rows only, p exchanged every iteration (all-gather of row
+    blocks), all-reduce(sum) of the D-vectors p.Ap and [r.r | r.z]."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oscillink_oracle as orc
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.default_rng(1)
+    N, D, k = 301, 24, 6
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    lat = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True, dense=False)
+    lat.set_query(psi)
+    lat.add_chain([3, 8, 1], lamP=0.2)
+    r0, r1 = N * rank // world, N * (rank + 1) // world
+    counts = [N * (r + 1) // world - N * r // world for r in range(world)]
+    dt, tol, max_iters = 1.0, 1e-3, 12
+    W, Wp, B = lat.W.tocsr()[r0:r1], lat.W_path.tocsr()[r0:r1], lat.B_diag[r0:r1, None]
+
+    def gather_rows(loc):  # the halo exchange: every rank ends up with all rows (blocks padded to equal size)
+        cmax = max(counts)
+        mine = torch.zeros((cmax, D), dtype=torch.float32)
+        mine[: loc.shape[0]] = torch.from_numpy(np.ascontiguousarray(loc, dtype=np.float32))
+        parts = [torch.zeros((cmax, D), dtype=torch.float32) for _ in counts]
+        dist.all_gather(parts, mine)
+        return np.concatenate([t.numpy()[:c] for t, c in zip(parts, counts)], axis=0)
+
+    def allsum(v):
+        t = torch.from_numpy(np.asarray(v, dtype=np.float64).copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+
+    def A_rows(full):  # rows [r0, r1) of A @ full
+        loc = full[r0:r1]
+        L = loc - W @ full
+        Lp = loc - Wp @ full
+        return loc + dt * (lat.lamG * loc + lat.lamC * L + lat.lamQ * (B * loc) + lat.lamP * Lp)
+
+    b = (lat.U + dt * lat._rhs())[r0:r1]
+    Md = (1.0 + dt * lat._diag_base())[r0:r1, None] + 1e-12
+    x = lat.U[r0:r1].copy()
+    r = b - A_rows(lat.U)
+    z = r / Md
+    p = z.copy()
+    rz = allsum((r * z).sum(axis=0))
+    iters = max_iters
+    for it in range(1, max_iters + 1):
+        Ap = A_rows(gather_rows(p))
+        alpha = rz / (allsum((p * Ap).sum(axis=0)) + 1e-18)
+        x = x + p * alpha
+        r = r - Ap * alpha
+        z = r / Md
+        both = allsum(np.concatenate([(r * r).sum(axis=0), (r * z).sum(axis=0)]))
+        res = float(np.sqrt(both[:D]).max())
+        if res <= tol:
+            iters = it
+            break
+        p = z + p * (both[D:] / (rz + 1e-18))
+        rz = both[D:]
+    full = lat.settle(dt=dt, max_iters=max_iters, tol=tol)
+    err = float(np.linalg.norm(x - lat.U[r0:r1]) / np.linalg.norm(lat.U[r0:r1]))
+    q.put((rank, iters == full["iters"] and err < 1e-6 and abs(res - full["res"]) <= 2e-2 * full["res"], iters, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_row_sharded_cg_two_ranks_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rows, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, iters, err in got:
+        assert ok, (rank, iters, err)
+
+
 @pytest.mark.timeout(300)
 def test_column_sharded_cg_two_ranks_gloo():
     import torch.multiprocessing as mp

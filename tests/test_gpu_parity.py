@@ -333,6 +333,24 @@ def test_prefilter_and_exact_knn_paths_agree_with_reference(amd, name, monkeypat
     assert np.array_equal(ties, amd.Oscillink(Yt, kneighbors=5, deterministic_k=True).A)
 
 
+@pytest.mark.parametrize("name", ["c2_n1200_d128_k16", "g1_n400_d64_k6_chain8", "gates_chain_n333_d50_k7"])
+@pytest.mark.parametrize("shards", ["2", "3", "8"])
+def test_row_sharded_cg_on_fake_ranks_matches_reference(amd, name, shards, monkeypatch):
+    """Row-sharded CG (the BASELINE north-star partitioning): OSC_ROW_FAKE_SHARDS runs the per-rank row ranges one
+    after another on this GPU (the RCCL exchanges become no-ops because all rows share one memory), which exercises the
+    row-range kernels and the cross-shard completion of the column sums.  Same fixtures, same tolerances."""
+    monkeypatch.setenv("OSC_SHARD", "row")
+    monkeypatch.setenv("OSC_ROW_FAKE_SHARDS", shards)
+    case = load_case(name)
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
+    lat.set_graph_csr(*_csr_from_case(case))
+    _configure(lat, case, rc, psi)
+    _check_solves(lat, case, rc, tol_u=2e-5)
+    assert lat.build_info()["small_solves"] == 0  # the sharded driver ran, not the one-launch path
+
+
 def test_row_block_sharded_knn_passes_equal_single_pass(amd, monkeypatch):
     """The multi-GPU lattice build shards 128-row blocks over ranks; OSC_KNN_FAKE_SHARDS runs the per-rank passes one
     after another on this GPU.  The assembled graph must equal the single-pass build bit for bit."""
