@@ -26,6 +26,7 @@ from . import _native as nat
 __version__ = "0.1.13+mi355x.1"
 
 _DENSE_VIEW_LIMIT = 20000  # N above which dense N x N views are refused (1.6 GB at fp32)
+_DENSE_EXPORT_LIMIT = 4096  # N up to which export_state / save_state also write the reference's dense `A`
 
 
 class OscillinkLattice:
@@ -785,7 +786,12 @@ class OscillinkLattice:
             "provenance": self._provenance(),
         }
         if include_graph:
-            state["A"] = self.A.tolist()
+            # the reference stores the dense N x N adjacency; that stays readable up to the dense-view limit, and the
+            # sparse triplet is always written (and preferred by from_state) so large lattices persist too
+            rowptr, col, a, _, _ = self._host_csr()
+            state["A_csr"] = {"indptr": rowptr.tolist(), "indices": col.tolist(), "data": a.tolist()}
+            if self.N <= _DENSE_EXPORT_LIMIT:
+                state["A"] = self.A.tolist()
         if include_chain and self._chain_nodes is not None:
             pairs = set()
             for t in range(len(self._chain_nodes) - 1):
@@ -805,10 +811,13 @@ class OscillinkLattice:
             state = self.export_state(include_graph=False, include_chain=include_chain)
             arrays: dict[str, np.ndarray] = {"Y": self.Y, "psi": self._psi, "B_diag": self._B}
             if include_graph:
-                arrays["A"] = self.A
+                rowptr, col, a, _, _ = self._host_csr()
+                arrays.update(A_indptr=rowptr, A_indices=col, A_data=a)
+                if self.N <= _DENSE_EXPORT_LIMIT:
+                    arrays["A"] = self.A
             if include_chain and self._chain_nodes is not None:
                 arrays["chain_nodes"] = np.array(self._chain_nodes, dtype=np.int32)
-            for key in ["Y", "psi", "B_diag", "A", "chain_nodes"]:
+            for key in ["Y", "psi", "B_diag", "A", "A_csr", "chain_nodes"]:
                 state.pop(key, None)
             np.savez_compressed(path, __meta__=np.array(json.dumps(state, sort_keys=True)), **arrays)
         else:
@@ -821,7 +830,9 @@ class OscillinkLattice:
             state["Y"] = data["Y"].astype(np.float32)
             state["psi"] = data["psi"].astype(np.float32)
             state["B_diag"] = data["B_diag"].astype(np.float32)
-            if "A" in data.files:
+            if "A_indptr" in data.files:
+                state["A_csr"] = {"indptr": data["A_indptr"], "indices": data["A_indices"], "data": data["A_data"]}
+            elif "A" in data.files:
                 state["A"] = data["A"].astype(np.float32)
             if "chain_nodes" in data.files:
                 state["chain_nodes"] = data["chain_nodes"].astype(int).tolist()
@@ -831,13 +842,18 @@ class OscillinkLattice:
     def from_state(cls, state: dict[str, Any]) -> "OscillinkLattice":
         Y = np.array(state["Y"], dtype=np.float32)
         params = state.get("params", {})
-        have_A = "A" in state and np.asarray(state["A"]).shape == (Y.shape[0], Y.shape[0])
+        have_csr = "A_csr" in state
+        have_A = have_csr or ("A" in state and np.asarray(state["A"]).shape == (Y.shape[0], Y.shape[0]))
         lat = cls(Y, kneighbors=state.get("kneighbors", 6), lamG=params.get("lamG", 1.0), lamC=params.get("lamC", 0.5),
                   lamQ=params.get("lamQ", 4.0), deterministic_k=state.get("deterministic_k", False),
                   neighbor_seed=state.get("neighbor_seed"), _build_graph=not have_A)
         psi = np.array(state.get("psi", np.zeros(Y.shape[1], dtype=np.float32)), dtype=np.float32)
         B = np.array(state.get("B_diag", np.ones(Y.shape[0], dtype=np.float32)), dtype=np.float32)
-        if have_A:  # stored adjacency overrides a rebuild (lattice.py:709-713)
+        if have_csr:  # sparse triplet written by this package
+            g = state["A_csr"]
+            lat.set_graph_csr(np.asarray(g["indptr"], dtype=np.int64), np.asarray(g["indices"], dtype=np.int32),
+                              np.asarray(g["data"], dtype=np.float32))
+        elif have_A:  # the reference's dense adjacency overrides a rebuild (lattice.py:709-713)
             lat.A = np.array(state["A"], dtype=np.float32)
         lat.set_query(psi, gates=B)
         lamP = params.get("lamP", 0.0)

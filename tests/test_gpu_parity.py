@@ -287,6 +287,12 @@ def test_ustar_cache_rebuild_and_persistence(amd, tmp_path):
         assert lat2._signature() == sig
         lat2.settle()
         assert lat2.receipt()["deltaH_total"] == pytest.approx(r1["deltaH_total"], rel=1e-2)
+    # the reference's own format (dense A only) is still read, and a large lattice persists through the CSR triplet
+    st = lat.export_state()
+    dense_only = {k_: v for k_, v in st.items() if k_ != "A_csr"}
+    assert amd.OscillinkLattice.from_state(dense_only)._signature() == sig
+    csr_only = {k_: v for k_, v in st.items() if k_ != "A"}
+    assert amd.OscillinkLattice.from_state(csr_only)._signature() == sig
     lat.rebuild_graph(kneighbors=7)  # tests/test_lattice_receipt_and_start_modes.py:63-71
     lat.receipt()
     assert lat.stats["ustar_solves"] == solves + 1
