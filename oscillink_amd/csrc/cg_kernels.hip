@@ -118,11 +118,28 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) dot[ch] = f4(0.f);
 
-  const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
-  for (int64_t rb = a.row0 + ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
+  // XCD-aware row order.  Workgroups b and b+8 share an XCD (round-robin dispatch): XCD x = b % 8 takes the x-th
+  // eighth of the row range and its workgroups sweep that eighth together, 4*RPW rows per workgroup per step, so at any
+  // moment the rows in flight on one XCD form a narrow contiguous window.  On lattices whose row order has locality
+  // (clustered anchors) the neighbours of the window are inside it and their rows are re-read from that XCD's 4 MB L2
+  // instead of from the fabric; on unstructured graphs the order is irrelevant.  (gridDim.x is a multiple of 8 or < 8.)
+  const int64_t span = a.N - a.row0;
+  int64_t rbeg, rend, rstep;
+  if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {
+    const int64_t per_xcd = ((span + 7) / 8 + 4 * RPW - 1) / (4 * RPW) * (4 * RPW);
+    const int64_t x0 = a.row0 + (int64_t)(blockIdx.x & 7) * per_xcd;
+    rend = min(a.N, x0 + per_xcd);
+    rbeg = x0 + (int64_t)(blockIdx.x >> 3) * 4 * RPW;
+    rstep = (int64_t)(gridDim.x >> 3) * 4 * RPW;
+  } else {
+    rbeg = a.row0 + (int64_t)blockIdx.x * 4 * RPW;
+    rend = a.N;
+    rstep = (int64_t)gridDim.x * 4 * RPW;
+  }
+  for (int64_t rb = rbeg + (int64_t)wave * RPW; rb < rend; rb += rstep) {
     int row = (int)rb + sub;
-    const bool rok = row < a.N;
-    if (!rok) row = (int)a.N - 1;
+    const bool rok = row < rend;
+    if (!rok) row = (int)rend - 1;
     if constexpr (LPR == 64) row = __builtin_amdgcn_readfirstlane(row);
     int deg = rok ? a.g.deg[row] : 0;
     if constexpr (LPR == 64) deg = __builtin_amdgcn_readfirstlane(deg);
@@ -244,10 +261,10 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
     rr[ch] = f4(0.f);
     rz[ch] = f4(0.f);
   }
-  const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
-  for (int64_t rb = a.row0 + ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
+  const int64_t rend = a.N;  // streaming kernels: plain grid-stride over the row range
+  for (int64_t rb = a.row0 + ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < rend; rb += (int64_t)gridDim.x * 4 * RPW) {
     const int row = (int)rb + sub;
-    if (row >= a.N) continue;
+    if (row >= rend) continue;
     float invMd = 1.f;
     if (a.op.precond) invMd = 1.f / (fmaf(a.op.md_B, a.B[row], a.op.md_const) + 1e-12f);
 #pragma unroll
@@ -287,10 +304,10 @@ __global__ __launch_bounds__(256) void k_update_p(const UpdateArgs a) {
     cok[ch] = coff[ch] < a.c1;
     be[ch] = cok[ch] ? ld4(a.beta + coff[ch]) : f4(0.f);
   }
-  const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
-  for (int64_t rb = a.row0 + ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += wstride) {
+  const int64_t rend = a.N;  // streaming kernels: plain grid-stride over the row range
+  for (int64_t rb = a.row0 + ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < rend; rb += (int64_t)gridDim.x * 4 * RPW) {
     const int row = (int)rb + sub;
-    if (row >= a.N) continue;
+    if (row >= rend) continue;
     float invMd = 1.f;
     if (a.op.precond) invMd = 1.f / (fmaf(a.op.md_B, a.B[row], a.op.md_const) + 1e-12f);
 #pragma unroll

@@ -235,7 +235,11 @@ void ensure_cg_scratch(L& h, int max_iters) {
 }
 
 // one grid for every CG kernel of a handle, so all column partial buffers have the same number of rows
-int cg_grid(const L& h) { return (int)std::max<int64_t>(1, std::min<int64_t>((h.N + 3) / 4, h.grid_cap)); }
+int cg_grid(const L& h) {
+  int64_t g = std::max<int64_t>(1, std::min<int64_t>((h.N + 3) / 4, h.grid_cap));
+  if (g >= 8) g &= ~(int64_t)7;  // multiple of 8: the operator apply maps workgroups to XCDs by blockIdx % 8
+  return (int)g;
+}
 
 GraphView graph_view(L& h, bool with_path) {
   GraphView g{};
