@@ -96,6 +96,7 @@ int osc_set_chain(osc_handle h, const int32_t* chain, const float* weights_or_nu
 int osc_clear_chain(osc_handle h);                      /* lattice.py:151-157 */
 int osc_set_lams(osc_handle h, float lamG, float lamC, float lamQ);
 int osc_get_U(osc_handle h, float* out);                /* N x D */
+int osc_get_Y(osc_handle h, float* out);                /* N x D: the device's private copy of the anchors */
 int osc_set_U(osc_handle h, const float* U_or_null);    /* NULL -> U = Y (device copy) */
 
 /* ---- solves --------------------------------------------------------------------------------- */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "osc_clear_chain": (C.c_int, [Handle]),
     "osc_set_lams": (C.c_int, [Handle, C.c_float, C.c_float, C.c_float]),
     "osc_get_U": (C.c_int, [Handle, c_f32p]),
+    "osc_get_Y": (C.c_int, [Handle, c_f32p]),
     "osc_set_U": (C.c_int, [Handle, c_f32p]),
     "osc_settle": (C.c_int, [Handle, C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_float, c_i32p, c_f32p,
                              c_f64p]),

@@ -1208,6 +1208,14 @@ int osc_get_U(osc_handle h, float* out) {
   });
 }
 
+int osc_get_Y(osc_handle h, float* out) {
+  return guarded(h, [&](L& l) {
+    if (!out) throw Invalid("osc_get_Y: out is NULL");
+    download_rows(l, out, l.Y.p);
+    sync(l);
+  });
+}
+
 int osc_set_U(osc_handle h, const float* U) {
   return guarded(h, [&](L& l) {
     if (U) {

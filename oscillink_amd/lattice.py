@@ -58,8 +58,11 @@ class OscillinkLattice:
             if val < 0:
                 raise ValueError(f"{name} must be >= 0")
         self._h = None
-        self.Y: np.ndarray = np.ascontiguousarray(Y, dtype=np.float32).copy()
-        self.N, self.D = self.Y.shape
+        # The reference keeps a private float32 copy of the anchors (lattice.py:54).  Here that copy lives on the
+        # device (osc_create uploads the caller's array); the host-side `Y` attribute is fetched on first read.
+        Yc = np.ascontiguousarray(Y, dtype=np.float32)
+        self._Y_host: Optional[np.ndarray] = None
+        self.N, self.D = Yc.shape
         k_eff = min(int(kneighbors), max(1, self.N - 1))
         self._kneighbors = k_eff
         self._deterministic_k = bool(deterministic_k)
@@ -77,7 +80,7 @@ class OscillinkLattice:
         # comm = (ncclUniqueId bytes, rank, world): one process per GPU.  The graph is then built row-block-sharded
         # (all-gather of the top-k lists) and the CG runs column-sharded (one all-reduce(max) per iteration).
         build_now = bool(_build_graph) and comm is None
-        rc = L.osc_create(nat.f32(self.Y), self.N, self.D, k_eff, self._row_cap_val, int(self._deterministic_k),
+        rc = L.osc_create(nat.f32(Yc), self.N, self.D, k_eff, self._row_cap_val, int(self._deterministic_k),
                           -1 if neighbor_seed is None else int(neighbor_seed), self._device, int(build_now),
                           C.byref(h))
         nat.check(rc, None, "osc_create")
@@ -134,6 +137,14 @@ class OscillinkLattice:
         nat.check(getattr(nat.lib(), name)(self._h, *args), self._h, name)
 
     # ------------------------------------------------------------------ array attributes
+    @property
+    def Y(self) -> np.ndarray:
+        if self._Y_host is None:
+            out = np.empty((self.N, self.D), dtype=np.float32)
+            self._call("osc_get_Y", nat.f32(out))
+            self._Y_host = out
+        return self._Y_host
+
     @property
     def U(self) -> np.ndarray:
         if self._U_host is None:
