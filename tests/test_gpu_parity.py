@@ -730,3 +730,34 @@ def _rebuild_oracle(orc, old, k):
         new.A_path, new.W_path, new.L_path = old.A_path, old.W_path, old.L_path
         new.lamP, new._chain_nodes = old.lamP, old._chain_nodes
     return new
+
+
+def test_random_shapes_prefilter_vs_exact_vs_oracle(amd, orc, monkeypatch):
+    """Differential sweep over ragged shapes (N not a multiple of the 128-row tile, D not a multiple of 4/32/64, k across
+    the list-width classes): the fp16-prefilter build, the all-fp32 build and (for the smaller ones) the oracle must
+    produce the same lattice."""
+    rng = np.random.default_rng(2024)
+    shapes = [(int(rng.integers(2, 2600)), int(rng.integers(1, 260)), int(rng.integers(1, 66))) for _ in range(28)]
+    shapes += [(129, 33, 32), (257, 65, 33), (1025, 31, 64), (4097, 20, 7), (640, 64, 80), (127, 5, 126)]
+    for N, D, k in shapes:
+        Y = rng.standard_normal((N, D)).astype(np.float32)
+        graphs = {}
+        for mode in ("prefilter", "exact"):
+            monkeypatch.setenv("OSC_KNN_MODE", mode)
+            lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+            graphs[mode] = lat.graph_csr()
+            lat.close()
+        a, b = graphs["prefilter"], graphs["exact"]
+        same = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        if not same:  # only a genuine near-tie (gap below fp32 summation noise) may differ between the two paths
+            ea = set(zip(np.repeat(np.arange(N), np.diff(a[0])).tolist(), a[1].tolist()))
+            eb = set(zip(np.repeat(np.arange(N), np.diff(b[0])).tolist(), b[1].tolist()))
+            assert len(ea ^ eb) <= 4, (N, D, k, len(ea ^ eb))
+        else:
+            assert np.allclose(a[2], b[2], rtol=2e-5, atol=1e-8), (N, D, k)
+        if N <= 900:
+            ref = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True)
+            r, c, w = orc._edges(ref.A)
+            eo = set(zip(r.tolist(), c.tolist()))
+            eb = set(zip(np.repeat(np.arange(N), np.diff(b[0])).tolist(), b[1].tolist()))
+            assert len(eo ^ eb) <= 4, (N, D, k, len(eo ^ eb))
