@@ -73,6 +73,11 @@ int osc_graph_stats(osc_handle h, int64_t* nnz, int32_t* max_deg, double* build_
  * one-launch small-lattice CG since creation */
 int osc_build_info(osc_handle h, int32_t* prefilter, int32_t* fallback_rows, int64_t* small_solves);
 
+/* internal row order of the last graph: reordered != 0 -> the rows are stored in BFS (locality-preserving) order, which
+ * is invisible at this API (every call speaks the caller's row ids); clustering = sampled local clustering
+ * coefficient that decided it (OSC_REORDER=0/1 overrides the automatic choice) */
+int osc_order_info(osc_handle h, int32_t* reordered, double* clustering);
+
 /* CSR view of the graph for `.A`, `.L_sym`, `_signature()` (lattice.py:729-744) and export_state
  * (:582-624).  rowptr has N+1 entries; col/a/w have nnz entries, columns ascending within a row;
  * a = capped adjacency A_ij (> 0), w = A_ij / (sqrt_deg_i sqrt_deg_j); sqrt_deg has N entries.

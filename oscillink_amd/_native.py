@@ -35,6 +35,7 @@ SIGNATURES = {
     "osc_rebuild_graph": (C.c_int, [Handle, C.c_int32, C.c_float, C.c_int32, C.c_int64]),
     "osc_graph_stats": (C.c_int, [Handle, c_i64p, c_i32p, c_f64p]),
     "osc_build_info": (C.c_int, [Handle, c_i32p, c_i32p, c_i64p]),
+    "osc_order_info": (C.c_int, [Handle, c_i32p, c_f64p]),
     "osc_get_csr": (C.c_int, [Handle, c_i64p, c_i32p, c_f32p, c_f32p, c_f32p]),
     "osc_set_csr": (C.c_int, [Handle, c_i64p, c_i32p, c_f32p]),
     "osc_get_knn_lists": (C.c_int, [Handle, c_i32p, c_f32p, c_i32p]),

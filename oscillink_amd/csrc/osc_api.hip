@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "knn.hpp"
 #include "receipts.hpp"
+#include "perm.hpp"
 #include "small.hpp"
 
 using namespace osc;
@@ -102,7 +103,15 @@ struct osc_lattice {
   double build_ms = 0.0;
   int64_t nnz = 0;
   int32_t max_deg = 0;
-  // chain prior
+  // internal row order (empty = identity): API row i lives at device row inv_h[i]; perm_h[new] = old
+  int reorder = -1;        // OSC_REORDER: 0 never, 1 always, unset = auto (when the graph is clustered enough to pay)
+  double clustering = 0.0;  // sampled local clustering coefficient of the last graph
+  bool reordered = false;
+  std::vector<int32_t> perm_h, inv_h;
+  DevBuf<int32_t> perm_d, inv_d;
+  // chain prior (kept in API ids on the host so it can be re-installed after a re-order)
+  std::vector<int32_t> chain_nodes;
+  std::vector<float> chain_w;
   bool chain_present = false;
   float lamP = 0.0f;
   int32_t prows = 0, pwidth = 0;
@@ -223,6 +232,23 @@ void download_rows(L& h, float* dst, const float* src) {
                              hipMemcpyDeviceToHost, h.stream));
 }
 
+// per-row host vector that came back in device row order -> API row order (in place)
+void to_api_order(const L& h, float* v) {
+  if (h.perm_h.empty() || !v) return;
+  std::vector<float> t(v, v + h.N);
+  for (int64_t i = 0; i < h.N; ++i) v[h.perm_h[(size_t)i]] = t[(size_t)i];
+}
+
+// N x D device array (device row order) -> host array in API row order; AP is scratch between solves
+void download_api_order(L& h, float* dst, const float* src) {
+  if (!h.perm_h.empty()) {
+    launch_move_rows(h.AP.p, src, h.perm_d.p, h.N, h.ld, true, h.stream);  // AP[perm[i]] = src[i]
+    src = h.AP.p;
+  }
+  download_rows(h, dst, src);
+  sync(h);
+}
+
 void ensure_cg_scratch(L& h, int max_iters) {
   const size_t pn = (size_t)h.grid_cap * h.ld;
   h.part0.alloc(pn);
@@ -287,8 +313,169 @@ void alloc_ell(L& h, int32_t width) {
   HIP_CHECK(hipMemsetAsync(h.deg.p, 0, (size_t)h.N * 4, h.stream));
 }
 
+bool permuted(const L& h) { return !h.perm_h.empty(); }
+
+// path Laplacian structures from the stored chain (graph.py:96-111), in the handle's current row order
+void install_chain(L& l) {
+  if (!l.chain_present) return;
+  const int32_t len = (int32_t)l.chain_nodes.size();
+  auto id = [&](int32_t v) { return permuted(l) ? l.inv_h[(size_t)v] : v; };
+  // path adjacency, duplicate edges keep the max weight (graph.py:102-109)
+  std::map<std::pair<int32_t, int32_t>, float> adj;
+  for (int t = 0; t + 1 < len; ++t) {
+    const int32_t i = id(l.chain_nodes[(size_t)t]), j = id(l.chain_nodes[(size_t)t + 1]);
+    const float w = l.chain_w.empty() ? 1.0f : l.chain_w[(size_t)t];
+    auto put = [&](int32_t r, int32_t c) {
+      auto it = adj.find({r, c});
+      if (it == adj.end()) adj[{r, c}] = std::max(0.0f, w);
+      else it->second = std::max(it->second, w);
+    };
+    put(i, j);
+    put(j, i);
+  }
+  // normalized_laplacian(A_path) (graph.py:86-93): only rows that own an entry differ from identity
+  std::map<int32_t, float> dsum;
+  for (auto& kv : adj) dsum[kv.first.first] += kv.second;
+  std::map<int32_t, int32_t> slot;
+  for (auto& kv : dsum) slot.emplace(kv.first, (int32_t)slot.size());
+  std::map<int32_t, int32_t> cnt;
+  int32_t pwidth = 1;
+  for (auto& kv : adj) pwidth = std::max(pwidth, ++cnt[kv.first.first]);
+  const int32_t prows = (int32_t)slot.size();
+  std::vector<int32_t> hslot((size_t)l.N, -1), hcol((size_t)prows * pwidth, 0), hdeg((size_t)prows, 0);
+  std::vector<float> hw((size_t)prows * pwidth, 0.f);
+  auto sd = [&](int32_t r) {
+    auto it = dsum.find(r);
+    return std::sqrt(std::max(it == dsum.end() ? 0.0f : it->second, 1e-12f));
+  };
+  for (auto& kv : slot) hslot[(size_t)kv.first] = kv.second;
+  for (auto& kv : adj) {
+    const int32_t r = kv.first.first, c = kv.first.second, sl = slot[r];
+    const int32_t e = hdeg[(size_t)sl]++;
+    hcol[(size_t)sl * pwidth + e] = c;
+    hw[(size_t)sl * pwidth + e] = (kv.second * (1.0f / sd(r))) * (1.0f / sd(c));
+  }
+  l.path_slot.alloc((size_t)l.N);
+  l.pcol.alloc(hcol.size());
+  l.pw.alloc(hw.size());
+  l.pdeg.alloc(hdeg.size());
+  HIP_CHECK(hipMemcpyAsync(l.path_slot.p, hslot.data(), hslot.size() * 4, hipMemcpyHostToDevice, l.stream));
+  HIP_CHECK(hipMemcpyAsync(l.pcol.p, hcol.data(), hcol.size() * 4, hipMemcpyHostToDevice, l.stream));
+  HIP_CHECK(hipMemcpyAsync(l.pw.p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, l.stream));
+  HIP_CHECK(hipMemcpyAsync(l.pdeg.p, hdeg.data(), hdeg.size() * 4, hipMemcpyHostToDevice, l.stream));
+  sync(l);
+  l.prows = prows;
+  l.pwidth = pwidth;
+}
+
+// move every row-indexed device array between two row orders: new row i takes old row from[i]; ids -> relabel[id]
+void move_state(L& l, const int32_t* from_d, const int32_t* relabel_d) {
+  const size_t n = (size_t)l.N * l.ld;
+  for (DevBuf<float>* b : {&l.Y, &l.U}) {  // AP is scratch between solves
+    launch_move_rows(l.AP.p, b->p, from_d, l.N, l.ld, false, l.stream);
+    HIP_CHECK(hipMemcpyAsync(b->p, l.AP.p, n * 4, hipMemcpyDeviceToDevice, l.stream));
+  }
+  DevBuf<float> t1;
+  t1.alloc((size_t)l.N);
+  for (DevBuf<float>* b : {&l.B, &l.sqrt_deg}) {
+    launch_move_f32(t1.p, b->p, from_d, l.N, false, l.stream);
+    HIP_CHECK(hipMemcpyAsync(b->p, t1.p, (size_t)l.N * 4, hipMemcpyDeviceToDevice, l.stream));
+  }
+  const size_t ne = (size_t)l.N * l.width;
+  DevBuf<int32_t> col2, deg2;
+  DevBuf<float> a2, w2;
+  col2.alloc(ne);
+  a2.alloc(ne);
+  w2.alloc(ne);
+  deg2.alloc((size_t)l.N);
+  launch_permute_ell(l.ell_col.p, l.ell_a.p, l.ell_w.p, l.deg.p, from_d, relabel_d, l.width, l.N, col2.p, a2.p, w2.p,
+                     deg2.p, l.stream);
+  sync(l);
+  l.ell_col.swap(col2);
+  l.ell_a.swap(a2);
+  l.ell_w.swap(w2);
+  l.deg.swap(deg2);
+  l.ell_t_ready = false;
+  l.have_ustar = false;
+  l.u_sharded = false;
+}
+
+void drop_order(L& l) {  // back to the API's row order
+  if (!permuted(l)) return;
+  move_state(l, l.inv_d.p, l.perm_d.p);
+  l.perm_h.clear();
+  l.inv_h.clear();
+  install_chain(l);
+}
+
+void apply_order(L& l, const std::vector<int32_t>& perm) {  // perm[new] = old ; state must be in API order
+  l.perm_h = perm;
+  l.inv_h.assign((size_t)l.N, 0);
+  for (int64_t i = 0; i < l.N; ++i) l.inv_h[(size_t)perm[(size_t)i]] = (int32_t)i;
+  l.perm_d.alloc((size_t)l.N);
+  l.inv_d.alloc((size_t)l.N);
+  HIP_CHECK(hipMemcpyAsync(l.perm_d.p, l.perm_h.data(), (size_t)l.N * 4, hipMemcpyHostToDevice, l.stream));
+  HIP_CHECK(hipMemcpyAsync(l.inv_d.p, l.inv_h.data(), (size_t)l.N * 4, hipMemcpyHostToDevice, l.stream));
+  move_state(l, l.perm_d.p, l.inv_d.p);
+  install_chain(l);
+}
+
+// breadth-first order over the lattice graph (components in order of their smallest node): neighbours end up
+// within a narrow band of rows, which is what the XCD-local L2 of the operator apply can hold
+std::vector<int32_t> bfs_order(L& l) {
+  const size_t ne = (size_t)l.N * l.width;
+  std::vector<int32_t> col(ne), deg((size_t)l.N);
+  HIP_CHECK(hipMemcpyAsync(col.data(), l.ell_col.p, ne * 4, hipMemcpyDeviceToHost, l.stream));
+  HIP_CHECK(hipMemcpyAsync(deg.data(), l.deg.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+  sync(l);
+  std::vector<int32_t> order;
+  order.reserve((size_t)l.N);
+  std::vector<char> seen((size_t)l.N, 0);
+  for (int64_t start = 0; start < l.N; ++start) {
+    if (seen[(size_t)start]) continue;
+    seen[(size_t)start] = 1;
+    size_t head = order.size();
+    order.push_back((int32_t)start);
+    while (head < order.size()) {
+      const int32_t u = order[head++];
+      const int32_t* cu = col.data() + (size_t)u * l.width;
+      for (int e = 0; e < deg[(size_t)u]; ++e) {
+        const int32_t v = cu[e];
+        if (!seen[(size_t)v]) {
+          seen[(size_t)v] = 1;
+          order.push_back(v);
+        }
+      }
+    }
+  }
+  return order;
+}
+
+// Re-order the rows when it pays: the BFS + state move cost a few ms at N = 100k and buy ~1.5x on the operator apply
+// of a clustered lattice, nothing on an unstructured one.  Auto mode decides on a sampled clustering coefficient.
+void maybe_reorder(L& l) {
+  l.reordered = false;
+  l.clustering = 0.0;
+  if (l.reorder == 0 || l.comm != nullptr || l.N < 2) return;
+  if (l.reorder < 0) {
+    if (l.N < 8192 || l.nnz == 0) return;  // small lattices run out of LDS / L2 anyway
+    DevBuf<unsigned long long> cnt;
+    cnt.alloc(2);
+    HIP_CHECK(hipMemsetAsync(cnt.p, 0, 16, l.stream));
+    launch_clustering_sample(l.ell_col.p, l.deg.p, l.width, l.N, 1024, cnt.p, l.stream);
+    unsigned long long hc[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(hc, cnt.p, 16, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+    l.clustering = hc[1] ? (double)hc[0] / (double)hc[1] : 0.0;
+    if (l.clustering < 0.05) return;
+  }
+  apply_order(l, bfs_order(l));
+  l.reordered = true;
+}
+
 void build_graph(L& h) {
   const double t0 = now_ms();
+  drop_order(h);  // the build works on the API's row order
   const int32_t N = (int32_t)h.N;
   h.k_eff = std::min<int32_t>(h.k_eff, std::max<int32_t>(1, N - 1));  // lattice.py:60
   h.have_ustar = false;
@@ -417,6 +604,7 @@ void build_graph(L& h) {
                            h.sqrt_deg.p, h.stream);
   graph_counts(h);  // synchronises
   h.have_graph = true;
+  maybe_reorder(h);
   h.build_ms = now_ms() - t0;
 }
 
@@ -969,6 +1157,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_SPMM_SLAB")) h->spmm_slab = atoi(e) < 0 ? -1 : (atoi(e) / 4) * 4;
     if (const char* e = getenv("OSC_GRID_CAP")) h->grid_cap = std::max(1, atoi(e));
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
+    if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_SHARD")) h->shard_mode = !strcmp(e, "row") ? 1 : 0;
     if (const char* e = getenv("OSC_ROW_FAKE_SHARDS")) h->fake_row_shards = std::max(0, atoi(e));
     const size_t n = (size_t)N * h->ld;
@@ -1031,6 +1220,13 @@ int osc_build_info(osc_handle h, int32_t* prefilter, int32_t* fallback_rows, int
   });
 }
 
+int osc_order_info(osc_handle h, int32_t* reordered, double* clustering) {
+  return guarded(h, [&](L& l) {
+    if (reordered) *reordered = l.reordered ? 1 : 0;
+    if (clustering) *clustering = l.clustering;
+  });
+}
+
 int osc_get_csr(osc_handle h, int64_t* rowptr, int32_t* col, float* a, float* w, float* sqrt_deg) {
   return guarded(h, [&](L& l) {
     require_graph(l);
@@ -1043,14 +1239,26 @@ int osc_get_csr(osc_handle h, int64_t* rowptr, int32_t* col, float* a, float* w,
     HIP_CHECK(hipMemcpyAsync(hd.data(), l.deg.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     if (sqrt_deg) HIP_CHECK(hipMemcpyAsync(sqrt_deg, l.sqrt_deg.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     sync(l);
+    std::vector<float> hsd;
+    if (sqrt_deg && permuted(l)) {  // downloaded in device order above: put it back into API order
+      hsd.assign(sqrt_deg, sqrt_deg + l.N);
+      for (int64_t i = 0; i < l.N; ++i) sqrt_deg[l.perm_h[(size_t)i]] = hsd[(size_t)i];
+    }
     int64_t pos = 0;
-    for (int64_t i = 0; i < l.N; ++i) {
-      if (rowptr) rowptr[i] = pos;
+    std::vector<std::pair<int32_t, size_t>> ent;  // (API column id, ELL slot) of one row, sorted by column
+    for (int64_t r = 0; r < l.N; ++r) {  // r = API row
+      const int64_t i = permuted(l) ? l.inv_h[(size_t)r] : r;  // device row
+      if (rowptr) rowptr[r] = pos;
+      ent.clear();
       for (int e = 0; e < hd[(size_t)i]; ++e) {
         const size_t o = (size_t)i * l.width + e;
-        if (col) col[pos] = hc[o];
-        if (a) a[pos] = ha[o];
-        if (w) w[pos] = hw[o];
+        ent.emplace_back(permuted(l) ? l.perm_h[(size_t)hc[o]] : hc[o], o);
+      }
+      if (permuted(l)) std::sort(ent.begin(), ent.end());
+      for (auto& pe : ent) {
+        if (col) col[pos] = pe.first;
+        if (a) a[pos] = ha[pe.second];
+        if (w) w[pos] = hw[pe.second];
         ++pos;
       }
     }
@@ -1061,6 +1269,11 @@ int osc_get_csr(osc_handle h, int64_t* rowptr, int32_t* col, float* a, float* w,
 int osc_set_csr(osc_handle h, const int64_t* rowptr, const int32_t* col, const float* a) {
   return guarded(h, [&](L& l) {
     if (!rowptr || rowptr[0] != 0) throw Invalid("osc_set_csr: rowptr[0] must be 0");
+    if (l.have_graph) drop_order(l);  // the injected ids are API ids
+    else {
+      l.perm_h.clear();
+      l.inv_h.clear();
+    }
     int64_t width = 1;
     for (int64_t i = 0; i < l.N; ++i) {
       if (rowptr[i + 1] < rowptr[i]) throw Invalid("osc_set_csr: rowptr must be non-decreasing");
@@ -1092,6 +1305,7 @@ int osc_set_csr(osc_handle h, const int64_t* rowptr, const int32_t* col, const f
     l.have_graph = true;
     l.have_ustar = false;
     l.knn_k = 0;
+    maybe_reorder(l);
   });
 }
 
@@ -1112,6 +1326,12 @@ int osc_set_query(osc_handle h, const float* psi, const float* gates) {
       HIP_CHECK(hipMemsetAsync(l.psi.p, 0, (size_t)l.ld * 4, l.stream));
       HIP_CHECK(hipMemcpyAsync(l.psi.p, psi, (size_t)l.D * 4, hipMemcpyHostToDevice, l.stream));
     }
+    std::vector<float> gp;
+    if (gates && permuted(l)) {
+      gp.resize((size_t)l.N);
+      for (int64_t i = 0; i < l.N; ++i) gp[(size_t)i] = gates[l.perm_h[(size_t)i]];
+      gates = gp.data();
+    }
     if (gates) HIP_CHECK(hipMemcpyAsync(l.B.p, gates, (size_t)l.N * 4, hipMemcpyHostToDevice, l.stream));
     sync(l);
     l.have_ustar = false;
@@ -1124,53 +1344,11 @@ int osc_set_chain(osc_handle h, const int32_t* chain, const float* weights, int3
     if (len < 2 || !chain) throw Invalid("chain must contain at least two indices");
     for (int i = 0; i < len; ++i)
       if (chain[i] < 0 || chain[i] >= l.N) throw Invalid("chain indices out of bounds");
-    // path adjacency, duplicate edges keep the max weight (graph.py:102-109)
-    std::map<std::pair<int32_t, int32_t>, float> adj;
-    for (int t = 0; t + 1 < len; ++t) {
-      const int32_t i = chain[t], j = chain[t + 1];
-      const float w = weights ? weights[t] : 1.0f;
-      auto put = [&](int32_t r, int32_t c) {
-        auto it = adj.find({r, c});
-        if (it == adj.end()) adj[{r, c}] = std::max(0.0f, w);
-        else it->second = std::max(it->second, w);
-      };
-      put(i, j);
-      put(j, i);
-    }
-    // normalized_laplacian(A_path) (graph.py:86-93): only rows that own an entry differ from identity
-    std::map<int32_t, float> dsum;
-    for (auto& kv : adj) dsum[kv.first.first] += kv.second;
-    std::map<int32_t, int32_t> slot;
-    for (auto& kv : dsum) slot.emplace(kv.first, (int32_t)slot.size());
-    std::map<int32_t, int32_t> cnt;
-    int32_t pwidth = 1;
-    for (auto& kv : adj) pwidth = std::max(pwidth, ++cnt[kv.first.first]);
-    const int32_t prows = (int32_t)slot.size();
-    std::vector<int32_t> hslot((size_t)l.N, -1), hcol((size_t)prows * pwidth, 0), hdeg((size_t)prows, 0);
-    std::vector<float> hw((size_t)prows * pwidth, 0.f);
-    auto sd = [&](int32_t r) {
-      auto it = dsum.find(r);
-      return std::sqrt(std::max(it == dsum.end() ? 0.0f : it->second, 1e-12f));
-    };
-    for (auto& kv : slot) hslot[(size_t)kv.first] = kv.second;
-    for (auto& kv : adj) {
-      const int32_t r = kv.first.first, c = kv.first.second, s = slot[r];
-      const int32_t e = hdeg[(size_t)s]++;
-      hcol[(size_t)s * pwidth + e] = c;
-      hw[(size_t)s * pwidth + e] = (kv.second * (1.0f / sd(r))) * (1.0f / sd(c));
-    }
-    l.path_slot.alloc((size_t)l.N);
-    l.pcol.alloc(hcol.size());
-    l.pw.alloc(hw.size());
-    l.pdeg.alloc(hdeg.size());
-    HIP_CHECK(hipMemcpyAsync(l.path_slot.p, hslot.data(), hslot.size() * 4, hipMemcpyHostToDevice, l.stream));
-    HIP_CHECK(hipMemcpyAsync(l.pcol.p, hcol.data(), hcol.size() * 4, hipMemcpyHostToDevice, l.stream));
-    HIP_CHECK(hipMemcpyAsync(l.pw.p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, l.stream));
-    HIP_CHECK(hipMemcpyAsync(l.pdeg.p, hdeg.data(), hdeg.size() * 4, hipMemcpyHostToDevice, l.stream));
-    sync(l);
-    l.prows = prows;
-    l.pwidth = pwidth;
+    l.chain_nodes.assign(chain, chain + len);
+    if (weights) l.chain_w.assign(weights, weights + (len - 1));
+    else l.chain_w.clear();
     l.chain_present = true;
+    install_chain(l);
     l.lamP = lamP;
     l.have_ustar = false;
   });
@@ -1203,23 +1381,26 @@ int osc_get_U(osc_handle h, float* out) {
       gather_columns(l, l.U.p);
       l.u_sharded = false;
     }
-    download_rows(l, out, l.U.p);
-    sync(l);
+    download_api_order(l, out, l.U.p);
   });
 }
 
 int osc_get_Y(osc_handle h, float* out) {
   return guarded(h, [&](L& l) {
     if (!out) throw Invalid("osc_get_Y: out is NULL");
-    download_rows(l, out, l.Y.p);
-    sync(l);
+    download_api_order(l, out, l.Y.p);
   });
 }
 
 int osc_set_U(osc_handle h, const float* U) {
   return guarded(h, [&](L& l) {
     if (U) {
-      upload_rows(l, l.U.p, U);
+      if (permuted(l)) {  // API order -> device order through the scratch array
+        upload_rows(l, l.AP.p, U);
+        launch_move_rows(l.U.p, l.AP.p, l.perm_d.p, l.N, l.ld, false, l.stream);
+      } else {
+        upload_rows(l, l.U.p, U);
+      }
       l.u_sharded = false;
     } else if (l.comm && l.world > 1 && l.shard_mode == 0) {  // column-sharded: only this rank's slab is needed
       HIP_CHECK(hipMemcpy2DAsync(l.U.p + l.c0, (size_t)l.ld * 4, l.Y.p + l.c0, (size_t)l.ld * 4,
@@ -1284,10 +1465,7 @@ int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out
     if (ms) *ms = now_ms() - t0;
     if (iters) *iters = r.iters;
     if (res) *res = r.res;
-    if (Ustar_out) {
-      download_rows(l, Ustar_out, l.Ustar.p);
-      sync(l);
-    }
+    if (Ustar_out) download_api_order(l, Ustar_out, l.Ustar.p);
   });
 }
 
@@ -1301,8 +1479,7 @@ int osc_get_ustar(osc_handle h, float* out) {
   return guarded(h, [&](L& l) {
     if (!out) throw Invalid("osc_get_ustar: out is NULL");
     if (!l.have_ustar) throw StateError("osc_get_ustar: no resident U* (call osc_solve_ustar first)");
-    download_rows(l, out, l.Ustar.p);
-    sync(l);
+    download_api_order(l, out, l.Ustar.p);
   });
 }
 
@@ -1333,6 +1510,12 @@ int osc_cg_single_rhs(osc_handle h, float gamma, const float* s, float tol, int3
     }
     psi0.alloc(ld1);
     HIP_CHECK(hipMemsetAsync(psi0.p, 0, ld1 * 4, l.stream));
+    std::vector<float> sp;
+    if (permuted(l)) {  // API order -> device order
+      sp.resize((size_t)l.N);
+      for (int64_t i = 0; i < l.N; ++i) sp[(size_t)i] = s[l.perm_h[(size_t)i]];
+      s = sp.data();
+    }
     HIP_CHECK(hipMemcpy2DAsync(S.p, ld1 * 4, s, 4, 4, (size_t)l.N, hipMemcpyHostToDevice, l.stream));
     OpParams op{};
     op.cs_const = 1.0f + gamma;  // (L_sym + gamma I) x = (1 + gamma) x - W x
@@ -1359,6 +1542,7 @@ int osc_cg_single_rhs(osc_handle h, float gamma, const float* s, float tol, int3
     l.comm = saved;
     HIP_CHECK(hipMemcpy2DAsync(h_out, 4, X.p, ld1 * 4, 4, (size_t)l.N, hipMemcpyDeviceToHost, l.stream));
     sync(l);
+    to_api_order(l, h_out);
     if (iters) *iters = r.iters;
     if (res) *res = r.res;
   });
@@ -1384,6 +1568,7 @@ int osc_cosine_to(osc_handle h, const float* psi, float* out) {
     launch_rows_dot(Yn.p, ldn, q.p, o.p, l.N, l.D, l.stream);
     HIP_CHECK(hipMemcpyAsync(out, o.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     sync(l);
+    to_api_order(l, out);
   });
 }
 
@@ -1442,6 +1627,22 @@ int osc_deltaH(osc_handle h, double* dH) {
   });
 }
 
+// null-point candidates per device row -> compact list in API row order (the reference walks rows 0..N-1)
+static int32_t compact_nulls(const L& l, const std::vector<int32_t>& hj, const std::vector<float>& hz,
+                             const std::vector<float>& hr, int32_t* i_out, int32_t* j_out, float* z_out, float* r_out) {
+  int32_t n = 0;
+  for (int64_t r = 0; r < l.N; ++r) {  // r = API row
+    const size_t i = (size_t)(l.perm_h.empty() ? r : l.inv_h[(size_t)r]);
+    if (hj[i] < 0) continue;
+    if (i_out) i_out[n] = (int32_t)r;
+    if (j_out) j_out[n] = l.perm_h.empty() ? hj[i] : l.perm_h[(size_t)hj[i]];
+    if (z_out) z_out[n] = hz[i];
+    if (r_out) r_out[n] = hr[i];
+    ++n;
+  }
+  return n;
+}
+
 static void receipt_rows(L& l, float z_th, DevBuf<float>& coh, DevBuf<float>& an, DevBuf<float>& qu,
                          DevBuf<int32_t>& nj, DevBuf<float>& nz, DevBuf<float>& nr, bool want_comp, bool want_null) {
   ReceiptArgs a{};
@@ -1461,6 +1662,7 @@ static void receipt_rows(L& l, float z_th, DevBuf<float>& coh, DevBuf<float>& an
   a.N = (int32_t)l.N;
   a.D = l.D;
   a.ld = l.ld;
+  a.api_id = permuted(l) ? l.perm_d.p : nullptr;
   if (want_comp) {
     coh.alloc((size_t)l.N);
     an.alloc((size_t)l.N);
@@ -1491,6 +1693,9 @@ int osc_receipt_components(osc_handle h, float* coh, float* anchor, float* query
     if (anchor) HIP_CHECK(hipMemcpyAsync(anchor, a.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     if (query) HIP_CHECK(hipMemcpyAsync(query, q.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     sync(l);
+    to_api_order(l, coh);
+    to_api_order(l, anchor);
+    to_api_order(l, query);
   });
 }
 
@@ -1509,16 +1714,7 @@ int osc_null_points(osc_handle h, float z_th, int32_t* i_out, int32_t* j_out, fl
     HIP_CHECK(hipMemcpyAsync(hz.data(), nz.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     HIP_CHECK(hipMemcpyAsync(hr.data(), nr.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     sync(l);
-    int32_t n = 0;
-    for (int64_t i = 0; i < l.N; ++i) {
-      if (hj[(size_t)i] < 0) continue;
-      if (i_out) i_out[n] = (int32_t)i;
-      if (j_out) j_out[n] = hj[(size_t)i];
-      if (z_out) z_out[n] = hz[(size_t)i];
-      if (r_out) r_out[n] = hr[(size_t)i];
-      ++n;
-    }
-    *count = n;
+    *count = compact_nulls(l, hj, hz, hr, i_out, j_out, z_out, r_out);
   });
 }
 
@@ -1540,16 +1736,10 @@ int osc_receipt_rows(osc_handle h, float z_th, float* coh, float* anchor, float*
     HIP_CHECK(hipMemcpyAsync(hz.data(), nz.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     HIP_CHECK(hipMemcpyAsync(hr.data(), nr.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     sync(l);
-    int32_t n = 0;
-    for (int64_t i = 0; i < l.N; ++i) {
-      if (hj[(size_t)i] < 0) continue;
-      if (i_out) i_out[n] = (int32_t)i;
-      if (j_out) j_out[n] = hj[(size_t)i];
-      if (z_out) z_out[n] = hz[(size_t)i];
-      if (r_out) r_out[n] = hr[(size_t)i];
-      ++n;
-    }
-    *count = n;
+    to_api_order(l, coh);
+    to_api_order(l, anchor);
+    to_api_order(l, query);
+    *count = compact_nulls(l, hj, hz, hr, i_out, j_out, z_out, r_out);
   });
 }
 

@@ -1,0 +1,17 @@
+#pragma once
+#include "common.hpp"
+
+namespace osc {
+
+// scatter == false: out[i] = in[map[i]] ; scatter == true: out[map[i]] = in[i]
+void launch_move_rows(float* out, const float* in, const int32_t* map, int64_t N, int32_t ld, bool scatter,
+                      hipStream_t s);
+void launch_move_f32(float* out, const float* in, const int32_t* map, int64_t N, bool scatter, hipStream_t s);
+void launch_permute_ell(const int32_t* col_in, const float* a_in, const float* w_in, const int32_t* deg_in,
+                        const int32_t* from, const int32_t* relabel, int32_t width, int64_t N, int32_t* col_out,
+                        float* a_out, float* w_out, int32_t* deg_out, hipStream_t s);
+
+void launch_clustering_sample(const int32_t* col, const int32_t* deg, int32_t width, int64_t N, int32_t nsample,
+                              unsigned long long* counts, hipStream_t s);
+
+}  // namespace osc

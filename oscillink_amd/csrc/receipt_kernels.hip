@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
       const float R = a.lamC * w * du;
       s1 += (double)R;
       s2 += (double)R * (double)R;
-      if (R > rmax) {  // strict: ties keep the smallest column (first argmax)
+      // first argmax in the reference's column order: strict >, ties to the smaller API column id
+      bool take = R > rmax;
+      if (!take && R == rmax && R > 0.f && a.api_id != nullptr && jmax >= 0) take = a.api_id[j] < a.api_id[jmax];
+      if (take) {
         rmax = R;
         jmax = j;
       }

@@ -21,6 +21,7 @@ struct ReceiptArgs {
   float* null_z;
   float* null_r;
   int32_t N, D, ld;
+  const int32_t* api_id;  // device row -> API row id (nullptr = identity); ties of the argmax go to the smaller API id
 };
 
 void launch_receipt_rows(const ReceiptArgs& a, hipStream_t s);

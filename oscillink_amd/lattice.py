@@ -215,10 +215,14 @@ class OscillinkLattice:
         return int(nnz.value), int(mx.value), float(ms.value)
 
     def build_info(self) -> dict[str, int]:
-        """How the device paths ran: {'prefilter', 'fallback_rows', 'small_solves'} (diagnostic; not in the reference)."""
+        """How the device paths ran: kNN prefilter use / fallback rows, one-launch solves, internal row re-order and the
+        sampled clustering coefficient that decided it (diagnostic; not in the reference)."""
         pf, fb, ss = C.c_int32(0), C.c_int32(0), C.c_int64(0)
         self._call("osc_build_info", C.byref(pf), C.byref(fb), C.byref(ss))
-        return {"prefilter": int(pf.value), "fallback_rows": int(fb.value), "small_solves": int(ss.value)}
+        ro, cc = C.c_int32(0), C.c_double(0.0)
+        self._call("osc_order_info", C.byref(ro), C.byref(cc))
+        return {"prefilter": int(pf.value), "fallback_rows": int(fb.value), "small_solves": int(ss.value),
+                "reordered": int(ro.value), "clustering": float(cc.value)}
 
     def graph_csr(self):
         """Sparse lattice graph: (rowptr int64 (N+1), col int32, A float32 (capped adjacency), W float32, sqrt_deg)."""

@@ -333,7 +333,8 @@ def test_prefilter_and_exact_knn_paths_agree_with_reference(amd, name, monkeypat
     monkeypatch.setenv("OSC_KNN_MODE", "prefilter")
     Yt = np.ones((300, 6), dtype=np.float32)
     tl = amd.Oscillink(Yt, kneighbors=5, deterministic_k=True)
-    assert tl.build_info() == {"prefilter": 1, "fallback_rows": 300, "small_solves": 0}  # nothing provable: all redone
+    bi = tl.build_info()
+    assert (bi["prefilter"], bi["fallback_rows"], bi["small_solves"]) == (1, 300, 0)  # nothing provable: all redone
     ties = tl.A
     monkeypatch.setenv("OSC_KNN_MODE", "exact")
     assert np.array_equal(ties, amd.Oscillink(Yt, kneighbors=5, deterministic_k=True).A)
@@ -761,3 +762,39 @@ def test_random_shapes_prefilter_vs_exact_vs_oracle(amd, orc, monkeypatch):
             eo = set(zip(r.tolist(), c.tolist()))
             eb = set(zip(np.repeat(np.arange(N), np.diff(b[0])).tolist(), b[1].tolist()))
             assert len(eo ^ eb) <= 4, (N, D, k, len(eo ^ eb))
+
+
+def test_internal_row_order_is_invisible(amd, orc, monkeypatch):
+    """Clustered anchors in shuffled order: the automatic BFS re-order kicks in (sampled clustering coefficient), an
+    i.i.d. lattice stays as it is, and every API result is identical to the run with re-ordering disabled."""
+    rng = np.random.default_rng(77)
+    N, D, k, C_ = 9000, 48, 12, 90
+    centers = rng.standard_normal((C_, D)).astype(np.float32)
+    Y = (centers[np.repeat(np.arange(C_), N // C_)] + 0.3 * rng.standard_normal((N, D))).astype(np.float32)
+    Y = Y[rng.permutation(N)]
+    psi = rng.standard_normal(D).astype(np.float32)
+    gates = rng.uniform(0.1, 1.0, N).astype(np.float32)
+    out = {}
+    for mode in ("auto", "0"):
+        if mode == "auto":
+            monkeypatch.delenv("OSC_REORDER", raising=False)
+        else:
+            monkeypatch.setenv("OSC_REORDER", mode)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        bi = lat.build_info()
+        assert bi["reordered"] == (1 if mode == "auto" else 0), bi
+        lat.set_query(psi, gates=gates)
+        lat.add_chain([5, 700, 4242, 8999, 12], lamP=0.3)
+        st = lat.settle()
+        rec = lat.receipt()
+        out[mode] = (lat.graph_csr(), lat.U.copy(), st["iters"], rec["deltaH_total"], rec["coh_drop_sum"],
+                     [n["edge"] for n in rec["null_points"]], lat._signature(), lat.Y.copy(), lat.sqrt_deg.copy())
+    a, b = out["auto"], out["0"]
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x, y) if x.dtype.kind == "i" else np.allclose(x, y, rtol=1e-6)
+    assert relerr(a[1], b[1]) < 1e-5 and a[2] == b[2]
+    assert a[3] == pytest.approx(b[3], rel=1e-4) and a[4] == pytest.approx(b[4], rel=1e-4)
+    assert a[5] == b[5] and a[6] == b[6]
+    assert np.array_equal(a[7], Y) and np.array_equal(b[7], Y) and np.allclose(a[8], b[8], rtol=1e-6)
+    iid = amd.Oscillink(rng.standard_normal((9000, 48)).astype(np.float32), kneighbors=k)
+    assert iid.build_info()["reordered"] == 0 and iid.build_info()["clustering"] < 0.05
