@@ -257,7 +257,21 @@ void ensure_cg_scratch(L& h, int max_iters) {
   h.beta.alloc(h.ld);
   h.rz.alloc(h.ld);
   h.colsum.alloc(h.ld);
-  if (h.res_bits.n < (size_t)max_iters + 2) h.res_bits.alloc((size_t)max_iters + 2);
+  // sized for solve_Ustar's default 64 iterations from the start: a settle(12) followed by a U* solve must not pay
+  // for re-allocating the residual slots, their pinned mirror and the per-iteration events
+  const size_t slots = (size_t)std::max(max_iters, 64) + 2;
+  if (h.res_bits.n < slots) h.res_bits.alloc(slots);
+  if (h.res_host_n < slots) {
+    if (h.res_host) (void)hipHostFree(h.res_host);
+    h.res_host = nullptr;
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h.res_host), slots * 4, hipHostMallocDefault));
+    h.res_host_n = slots;
+  }
+  while (h.iter_events.size() < slots) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h.iter_events.push_back(e);
+  }
 }
 
 // one grid for every CG kernel of a handle, so all column partial buffers have the same number of rows
