@@ -130,16 +130,15 @@ def main():
     # config 3: 6 slabs of 128 columns); the library times each apply (all its slab launches) with one HIP-event pair
     # on its own stream.  Algorithmic bytes of ONE apply on this rank: read X once, write the
     # result once, ELL col + val, rowptr/B/diag per row; per launch = per apply / slabs.
-    slab = 128 if N * d_local * 4 > 2 * 56 * 1024 * 1024 else d_local
-    slabs = max(1, (d_local + slab - 1) // slab)
+    plan = lat.build_info()
+    slabs = max(1, plan["apply_launches"])
+    spmm_kernel = "k_spmm<8, 1, 0>" if plan["apply_xs_workgroups"] else None
     bytes_apply = 8.0 * n_local * d_local + (8.0 * nnz + 12.0 * N) * (n_local / N)
     apply_ms = total_ms.value / max(1, launches.value)
     bytes_mv = bytes_apply / slabs
     mv_ms = apply_ms / slabs
     achieved = bytes_mv / (mv_ms * 1e-3) / 1e9 if mv_ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(N, D, k, world)
-    if traffic is not None:
-        traffic /= slabs
+    traffic, traffic_src = pmc_traffic(N, D, k, world, spmm_kernel)
 
     out = {
         "metric": "settles/sec",
@@ -160,7 +159,9 @@ def main():
                    "cg_iters_per_settle": iters_total / args.steps, "residual": last["res"]},
         "lattice_create_ms": graph_build_ms,  # first call in the process: HIP context + code objects + upload + build
         "graph_build_device_ms": dev_build_ms,
-        "roofline": {"bound": "hbm", "kernel": "k_spmm (operator apply / CG matvec; one column-slab launch)",
+        "roofline": {"bound": "hbm",
+                     "kernel": ("k_spmm<8,1,AP> (operator apply / CG matvec; one launch, XCD-affine 32-column slabs)"
+                                if spmm_kernel else "k_spmm (operator apply / CG matvec; one column-slab launch)"),
                      "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
@@ -178,19 +179,17 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(N, D, k, world):
-    """HBM bytes per operator apply from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; gfx950 read-side
-    x2 correction applied by scripts/summarize_profile.py).  The apply is launched as column slabs of 128
-    (k_spmm<32, 1, 0>), so the per-launch PMC mean is multiplied by the slab count.  Only valid for the profiled
-    workload (config 3, one GPU)."""
-    if (N, D, k, world) != (100_000, 768, 32, 1):
+def pmc_traffic(N, D, k, world, kernel):
+    """HBM/fabric bytes per LAUNCH of the operator-apply kernel from the committed rocprofv3 PMC passes (FETCH_SIZE,
+    WRITE_SIZE; gfx950 read-side x2 correction applied by scripts/summarize_profile.py).  Only valid for the profiled
+    workload (config 3, one GPU) and the kernel the profile was taken with."""
+    if (N, D, k, world) != (100_000, 768, 32, 1) or kernel is None:
         return None, None
     path = os.path.join(ROOT, "profiles", "r01_pmc.json")
     if os.path.exists(path):
-        e = json.load(open(path)).get("k_spmm<32, 1, 0>")
+        e = json.load(open(path)).get(kernel)
         if e and "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
-            slabs = (D + 127) // 128
-            return slabs * (e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]), "profiles/r01_pmc.json"
+            return e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"], "profiles/r01_pmc.json"
     return None, None
 
 

@@ -78,6 +78,11 @@ int osc_build_info(osc_handle h, int32_t* prefilter, int32_t* fallback_rows, int
  * coefficient that decided it (OSC_REORDER=0/1 overrides the automatic choice) */
 int osc_order_info(osc_handle h, int32_t* reordered, double* clustering);
 
+/* how one operator apply (the CG matvec over this handle's column window) is launched: launches = kernel launches per
+ * apply, slab_cols = columns each launch covers, xs_workgroups = 0 for sequential column slabs swept by the whole
+ * chip, > 0 for one launch of XCD-affine 32-column slabs with that many workgroups per XCD (measurement aid) */
+int osc_spmm_plan(osc_handle h, int32_t* launches, int32_t* slab_cols, int32_t* xs_workgroups);
+
 /* CSR view of the graph for `.A`, `.L_sym`, `_signature()` (lattice.py:729-744) and export_state
  * (:582-624).  rowptr has N+1 entries; col/a/w have nnz entries, columns ascending within a row;
  * a = capped adjacency A_ij (> 0), w = A_ij / (sqrt_deg_i sqrt_deg_j); sqrt_deg has N entries.

@@ -88,6 +88,9 @@ __device__ __forceinline__ void block_fold(float4 (&dot)[NCH], float* red /*[4][
 #ifndef OSC_SPMM_U1
 #define OSC_SPMM_U1 2
 #endif
+#ifndef OSC_SPMM_U8
+#define OSC_SPMM_U8 2  // 8 lanes per row (xs mode): 8 rows per wave, 2 neighbour rows of each in flight (4 and 8: slower)
+#endif
 template <int NCH>
 struct Unroll {  // neighbour rows fetched per batch (all loads in flight together)
   static constexpr int U = NCH == 1 ? OSC_SPMM_U1 : (NCH <= 3 ? 4 : (NCH <= 6 ? 2 : 1));
@@ -98,19 +101,28 @@ template <int LPR, int NCH, int MODE>
 __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
   constexpr int RPW = 64 / LPR;
   constexpr int CPW = NCH * LPR * 4;
-  constexpr int U = Unroll<NCH>::U;
+  constexpr int U = LPR == 8 ? OSC_SPMM_U8 : Unroll<NCH>::U;
   __shared__ __attribute__((aligned(16))) float red[4 * CPW];
   if (a.gate != nullptr && *a.gate <= a.gate_tol) return;  // converged earlier: speculative launch is a no-op
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, lr = lane % LPR;
   const int32_t ld = a.ld;
+  const bool xs = a.xs != 0;  // workgroup-uniform
+  if (xs) {  // this workgroup's row of part[][] is summed over every column by the reduce kernels: clear the columns
+             // of the slabs other XCDs own (block_fold's leading barrier orders this against the folds below)
+    for (int c = a.c0 + threadIdx.x; c < a.c1; c += 256) a.part[(size_t)blockIdx.x * ld + c] = 0.f;
+    if ((int)(blockIdx.x >> 3) >= a.xs) return;  // a.xs workgroups per XCD do the work
+  }
+  // slab loop: one pass over [c0, c1) normally; in xs mode the slabs x, x+8, ... of this workgroup's XCD
+  for (int32_t sc0 = xs ? a.c0 + (int32_t)(blockIdx.x & 7) * CPW : a.c0; sc0 < a.c1; sc0 += xs ? 8 * CPW : (1 << 30)) {
+  const int32_t sc1 = xs ? min(a.c1, sc0 + CPW) : a.c1;
   int coff[NCH];
   bool cok[NCH];
   float4 psi4[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    coff[ch] = a.c0 + (ch * LPR + lr) * 4;
-    cok[ch] = coff[ch] < a.c1;
+    coff[ch] = sc0 + (ch * LPR + lr) * 4;
+    cok[ch] = coff[ch] < sc1;
     psi4[ch] = f4(0.f);
     if (MODE == SPMM_INIT && cok[ch]) psi4[ch] = ld4(a.psi + coff[ch]);
   }
@@ -125,7 +137,11 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
   // instead of from the fabric; on unstructured graphs the order is irrelevant.  (gridDim.x is a multiple of 8 or < 8.)
   const int64_t span = a.N - a.row0;
   int64_t rbeg, rend, rstep;
-  if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {
+  if (xs) {  // every row, shared among the workgroups of this XCD
+    rbeg = a.row0 + (int64_t)(blockIdx.x >> 3) * 4 * RPW;
+    rend = a.N;
+    rstep = (int64_t)a.xs * 4 * RPW;
+  } else if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {
     const int64_t per_xcd = ((span + 7) / 8 + 4 * RPW - 1) / (4 * RPW) * (4 * RPW);
     const int64_t x0 = a.row0 + (int64_t)(blockIdx.x & 7) * per_xcd;
     rend = min(a.N, x0 + per_xcd);
@@ -157,30 +173,43 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
     }
     const int32_t* crow = a.g.col + (size_t)row * a.g.width;
     const float* wrow = a.g.w + (size_t)row * a.g.width;
-    for (int e0 = 0; e0 < maxdeg; e0 += LPR) {
-      const int e = e0 + lr;
-      int cj = row;
-      float wj = 0.f;
-      if (e < deg) {
-        cj = crow[e];
-        wj = wrow[e];
-      }
-      const int cnt = min(LPR, maxdeg - e0);
-      for (int t = 0; t < cnt; t += U) {
-        float4 v[U][NCH];
-        float wv[U];
+    // edge lists are fetched NBF batches of LPR entries at a time (all index loads of a row in flight together: with
+    // 8 lanes per row a 32-wide ELL row is four batches, and one exposed index latency instead of four)
+    constexpr int NBF = LPR == 8 ? 4 : 1;
+    for (int e0 = 0; e0 < maxdeg; e0 += LPR * NBF) {
+      int cjb[NBF];
+      float wjb[NBF];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = bcast_i<LPR>(cj, sub, t + u);  // t+u <= LPR-1: cnt <= LPR and LPR % U == 0
-          wv[u] = bcast_f<LPR>(wj, sub, t + u);
-          const float* xj = a.X + (size_t)j * ld;
-#pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) v[u][ch] = cok[ch] ? ld4(xj + coff[ch]) : f4(0.f);
+      for (int b = 0; b < NBF; ++b) {
+        const int e = e0 + b * LPR + lr;
+        cjb[b] = row;
+        wjb[b] = 0.f;
+        if (e < deg) {
+          cjb[b] = crow[e];
+          wjb[b] = wrow[e];
         }
+      }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+      for (int b = 0; b < NBF; ++b) {
+        const int cnt = min(LPR, maxdeg - e0 - b * LPR);  // <= 0: nothing left (the loop below does not run)
+        const int cj = cjb[b];
+        const float wj = wjb[b];
+        for (int t = 0; t < cnt; t += U) {
+          float4 v[U][NCH];
+          float wv[U];
 #pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fma4(wv[u], v[u][ch], acc[ch]);
+          for (int u = 0; u < U; ++u) {
+            const int j = bcast_i<LPR>(cj, sub, t + u);  // t+u <= LPR-1: cnt <= LPR and LPR % U == 0
+            wv[u] = bcast_f<LPR>(wj, sub, t + u);
+            const float* xj = a.X + (size_t)j * ld;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) v[u][ch] = cok[ch] ? ld4(xj + coff[ch]) : f4(0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) acc[ch] = fma4(wv[u], v[u][ch], acc[ch]);
+        }
       }
     }
     // chain prior rows (a handful): second tiny ELL addressed through path_slot
@@ -237,7 +266,8 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
       }
     }
   }
-  block_fold<LPR, NCH>(dot, red, a.part, ld, a.c0, a.c1);
+  block_fold<LPR, NCH>(dot, red, a.part, ld, sc0, sc1);
+  }  // slab loop
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -486,6 +516,14 @@ int spmm_grid(int64_t N, int32_t ncols) {
 }
 
 void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s) {
+  if (a.xs != 0) {  // XCD-affine 32-column slabs: 8 lanes per row
+    if (grid < 8 || (grid & 7) != 0 || a.xs > grid / 8) throw std::runtime_error("xs mode needs a grid that is a multiple of 8");
+    if (mode == SPMM_AP) hipLaunchKernelGGL((k_spmm<8, 1, SPMM_AP>), dim3(grid), dim3(256), 0, s, a);
+    else if (mode == SPMM_INIT) hipLaunchKernelGGL((k_spmm<8, 1, SPMM_INIT>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_spmm<8, 1, SPMM_DOT>), dim3(grid), dim3(256), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const Shape sh = pick_shape(a.c1 - a.c0);
 #define CALL(L, C)                                                                                   \
   do {                                                                                               \

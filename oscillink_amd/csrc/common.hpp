@@ -94,6 +94,10 @@ struct SpmmArgs {
   // enqueues one iteration ahead of its residual read-back).  nullptr = always run.
   const float* gate;
   float gate_tol;
+  // xs > 0: XCD-affine narrow slabs.  The window [c0, c1) is cut into 32-column slabs (one 128-byte line per row);
+  // the first xs workgroups of XCD x (blockIdx % 8 == x) own slabs x, x+8, ... and sweep ALL rows for them, so the
+  // slab an XCD gathers from (N x 128 B) competes for that XCD's 4 MB L2 alone instead of with seven other slabs.
+  int32_t xs;
 };
 
 struct UpdateArgs {

@@ -221,8 +221,11 @@ class OscillinkLattice:
         self._call("osc_build_info", C.byref(pf), C.byref(fb), C.byref(ss))
         ro, cc = C.c_int32(0), C.c_double(0.0)
         self._call("osc_order_info", C.byref(ro), C.byref(cc))
+        ln, sc, xw = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._call("osc_spmm_plan", C.byref(ln), C.byref(sc), C.byref(xw))
         return {"prefilter": int(pf.value), "fallback_rows": int(fb.value), "small_solves": int(ss.value),
-                "reordered": int(ro.value), "clustering": float(cc.value)}
+                "reordered": int(ro.value), "clustering": float(cc.value), "apply_launches": int(ln.value),
+                "apply_slab_cols": int(sc.value), "apply_xs_workgroups": int(xw.value)}
 
     def graph_csr(self):
         """Sparse lattice graph: (rowptr int64 (N+1), col int32, A float32 (capped adjacency), W float32, sqrt_deg)."""

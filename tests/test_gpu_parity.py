@@ -798,3 +798,44 @@ def test_internal_row_order_is_invisible(amd, orc, monkeypatch):
     assert np.array_equal(a[7], Y) and np.array_equal(b[7], Y) and np.allclose(a[8], b[8], rtol=1e-6)
     iid = amd.Oscillink(rng.standard_normal((9000, 48)).astype(np.float32), kneighbors=k)
     assert iid.build_info()["reordered"] == 0 and iid.build_info()["clustering"] < 0.05
+
+
+@pytest.mark.parametrize("name", ["c2_n1200_d128_k16", "g1_n400_d64_k6_chain8", "gates_chain_n333_d50_k7"])
+@pytest.mark.parametrize("nb", ["1", "3", "96"])
+def test_xcd_affine_slab_apply_matches_reference(amd, name, nb, monkeypatch):
+    """OSC_SPMM_XS=1 forces the XCD-affine 32-column-slab operator apply (chosen automatically only for 32k..131k rows)
+    onto the small fixtures, including a width that is not a multiple of 32 (D = 50) and a chain prior; OSC_SMALL_PATH=0
+    keeps the general multi-launch CG in play.  Same fixtures, same tolerances, same iteration counts."""
+    monkeypatch.setenv("OSC_SPMM_XS", "1")
+    monkeypatch.setenv("OSC_XS_NB", nb)
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    case = load_case(name)
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
+    lat.set_graph_csr(*_csr_from_case(case))
+    _configure(lat, case, rc, psi)
+    info = lat.build_info()
+    assert info["apply_launches"] == 1 and info["apply_xs_workgroups"] >= 1
+    _check_solves(lat, case, rc, tol_u=2e-5)
+    assert lat.build_info()["small_solves"] == 0
+
+
+def test_xcd_affine_slab_apply_is_the_default_only_in_its_window(amd, monkeypatch):
+    rng = np.random.default_rng(5)
+    small = amd.Oscillink(rng.standard_normal((4096, 256)).astype(np.float32), kneighbors=8)
+    assert small.build_info()["apply_xs_workgroups"] == 0  # too few rows: the gathered operand sits in cache anyway
+    big = amd.Oscillink(rng.standard_normal((40000, 256)).astype(np.float32), kneighbors=8)
+    bi = big.build_info()
+    assert bi["apply_xs_workgroups"] > 0 and bi["apply_launches"] == 1
+    psi = rng.standard_normal(256).astype(np.float32)
+    big.set_query(psi)
+    a = big.settle(max_iters=12, tol=1e-3)
+    # the same lattice with the mode switched off: identical iteration count, states equal to fp32 reduction-order noise
+    monkeypatch.setenv("OSC_SPMM_XS", "0")
+    off = amd.Oscillink(big.Y, kneighbors=8)
+    assert off.build_info()["apply_xs_workgroups"] == 0
+    off.set_query(psi)
+    b = off.settle(max_iters=12, tol=1e-3)
+    assert a["iters"] == b["iters"]
+    assert relerr(big.U, off.U) < 1e-5
