@@ -482,6 +482,9 @@ __global__ __launch_bounds__(256) void k_axpby(float* out, const float* a, float
 struct Shape {
   int lpr, nch;
 };
+// lanes per row x float4 chunks per lane.  Exact-fit shapes for 96 / 192 / 384 columns (the per-rank windows of D = 768
+// on 8 / 4 / 2 GPUs: <8,3>, <16,3>, <32,3>) were measured and are no faster than the padded ones below (the apply is
+// bound by the gathered bytes, not by idle lanes), so they are not instantiated.
 inline Shape pick_shape(int ncols) {
   if (ncols <= 64) return {16, 1};
   if (ncols <= 128) return {32, 1};

@@ -1201,6 +1201,15 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_SHARD")) h->shard_mode = !strcmp(e, "row") ? 1 : 0;
     if (const char* e = getenv("OSC_ROW_FAKE_SHARDS")) h->fake_row_shards = std::max(0, atoi(e));
+    if (const char* e = getenv("OSC_FAKE_COL_SHARD")) {  // "r/w": work on rank r's column slab of w, no communicator
+      int r = 0, w = 1;                                   // (measurement hook: one rank's share of a column-sharded solve)
+      if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) {
+        const int32_t q = h->ld / 4;
+        h->c0 = (int32_t)((int64_t)q * r / w) * 4;
+        h->c1 = (int32_t)((int64_t)q * (r + 1) / w) * 4;
+        if (h->c1 <= h->c0) throw Invalid("OSC_FAKE_COL_SHARD: more ranks than 4-column groups");
+      }
+    }
     const size_t n = (size_t)N * h->ld;
     for (DevBuf<float>* b : {&h->Y, &h->U, &h->X, &h->R, &h->P, &h->AP, &h->Ustar}) b->alloc(n);
     HIP_CHECK(hipMemsetAsync(h->Y.p, 0, n * 4, h->stream));
