@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
     if ((int)(blockIdx.x >> 3) >= a.xs) return;  // a.xs workgroups per XCD do the work
   }
   // slab loop: one pass over [c0, c1) normally; in xs mode the slabs x, x+8, ... of this workgroup's XCD
-  for (int32_t sc0 = xs ? a.c0 + (int32_t)(blockIdx.x & 7) * CPW : a.c0; sc0 < a.c1; sc0 += xs ? 8 * CPW : (1 << 30)) {
+  const int xgroups = xs ? a.xs_groups : 1, xgrp = (int)(blockIdx.x & 7) % xgroups, xpart = (int)(blockIdx.x & 7) / xgroups;
+  for (int32_t sc0 = xs ? a.c0 + xgrp * CPW : a.c0; sc0 < a.c1; sc0 += xs ? xgroups * CPW : (1 << 30)) {
   const int32_t sc1 = xs ? min(a.c1, sc0 + CPW) : a.c1;
   int coff[NCH];
   bool cok[NCH];
@@ -137,9 +138,10 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
   // instead of from the fabric; on unstructured graphs the order is irrelevant.  (gridDim.x is a multiple of 8 or < 8.)
   const int64_t span = a.N - a.row0;
   int64_t rbeg, rend, rstep;
-  if (xs) {  // every row, shared among the workgroups of this XCD
-    rbeg = a.row0 + (int64_t)(blockIdx.x >> 3) * 4 * RPW;
-    rend = a.N;
+  if (xs) {  // the rows of this XCD's part, shared among its workgroups
+    const int64_t parts = 8 / xgroups;
+    rbeg = a.row0 + span * xpart / parts + (int64_t)(blockIdx.x >> 3) * 4 * RPW;
+    rend = a.row0 + span * (xpart + 1) / parts;
     rstep = (int64_t)a.xs * 4 * RPW;
   } else if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {
     const int64_t per_xcd = ((span + 7) / 8 + 4 * RPW - 1) / (4 * RPW) * (4 * RPW);
@@ -520,7 +522,8 @@ int spmm_grid(int64_t N, int32_t ncols) {
 
 void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s) {
   if (a.xs != 0) {  // XCD-affine 32-column slabs: 8 lanes per row
-    if (grid < 8 || (grid & 7) != 0 || a.xs > grid / 8) throw std::runtime_error("xs mode needs a grid that is a multiple of 8");
+    if (grid < 8 || (grid & 7) != 0 || a.xs > grid / 8 || a.xs_groups < 1 || 8 % a.xs_groups != 0)
+      throw std::runtime_error("xs mode needs a grid that is a multiple of 8 and 1, 2, 4 or 8 slab groups");
     if (mode == SPMM_AP) hipLaunchKernelGGL((k_spmm<8, 1, SPMM_AP>), dim3(grid), dim3(256), 0, s, a);
     else if (mode == SPMM_INIT) hipLaunchKernelGGL((k_spmm<8, 1, SPMM_INIT>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_spmm<8, 1, SPMM_DOT>), dim3(grid), dim3(256), 0, s, a);

@@ -94,10 +94,13 @@ struct SpmmArgs {
   // enqueues one iteration ahead of its residual read-back).  nullptr = always run.
   const float* gate;
   float gate_tol;
-  // xs > 0: XCD-affine narrow slabs.  The window [c0, c1) is cut into 32-column slabs (one 128-byte line per row);
-  // the first xs workgroups of XCD x (blockIdx % 8 == x) own slabs x, x+8, ... and sweep ALL rows for them, so the
-  // slab an XCD gathers from (N x 128 B) competes for that XCD's 4 MB L2 alone instead of with seven other slabs.
+  // xs > 0: XCD-affine narrow slabs.  The window [c0, c1) is cut into 32-column slabs (one 128-byte line per row).
+  // The eight XCDs (x = blockIdx % 8) form xs_groups slab groups of 8 / xs_groups XCDs each: group g = x % xs_groups
+  // owns slabs g, g + xs_groups, ... and its XCDs split the rows among themselves (part x / xs_groups); the first xs
+  // workgroups of each XCD do the work.  The slab an XCD gathers from (N x 128 B) then competes for that XCD's 4 MB
+  // L2 alone instead of with the other slabs of the window.  xs_groups = gcd(8, number of slabs): always balanced.
   int32_t xs;
+  int32_t xs_groups;
 };
 
 struct UpdateArgs {

@@ -676,18 +676,22 @@ int32_t auto_slab(const L& h, int32_t ncols) {
 // XCD-affine 32-column slabs (SpmmArgs::xs): one launch covers the window; returns the workgroups per XCD to use, 0 = no.
 // Pays when the gathered operand is far larger than an XCD's L2 and the graph has no row locality to exploit: each
 // XCD then keeps 4 MB / (N x 128 B) of ITS slab in L2 (31 % at N = 100k) instead of 4 MB / (N x 512 B) of a slab all
-// eight share.  Needs 128-byte-aligned rows, enough slabs to load the eight XCDs evenly, and the eight slabs in flight
-// (8 x N x 128 B) inside the Infinity Cache: measured 1.11 vs 1.26 ms per apply at N = 100k, D = 768; no gain at
-// N = 200k, D = 1536 (205 MB in flight); 36 % slower at N = 1M, D = 384.
+// eight share.  With fewer than 8 slabs (or a count that is not a multiple of 8) the XCDs pair up: gcd(8, slabs) slab
+// groups, the XCDs of a group split the rows.  Needs 128-byte-aligned rows and the slabs in flight (groups x N x 128 B)
+// inside the Infinity Cache: measured 1.11 vs 1.26 ms per apply at N = 100k, D = 768; no gain at N = 200k, D = 1536
+// (205 MB in flight); 36 % slower at N = 1M, D = 384.
+int xs_groups(int32_t ncols) {
+  const int nsl = (ncols + 31) / 32;
+  return (nsl % 8 == 0) ? 8 : (nsl % 4 == 0) ? 4 : (nsl % 2 == 0) ? 2 : 1;
+}
 int xs_plan(const L& h, int32_t ncols, int grid) {
   if (grid < 8 || (grid & 7) != 0) return 0;
   const int nb = std::max(1, std::min(grid / 8, h.xs_nb));
   if (h.spmm_xs == 0) return 0;
   if (h.spmm_xs == 1) return nb;
   if (h.spmm_slab != 0 || h.reordered || (h.ld & 31) != 0 || (h.c0 & 31) != 0) return 0;
-  if (h.N < 32768 || h.N > 131072 || ncols < 256) return 0;
-  const int nsl = (ncols + 31) / 32;
-  if ((double)((nsl + 7) / 8 * 8) / nsl > 1.15) return 0;
+  if (h.N < 32768 || ncols < 96) return 0;
+  if ((double)xs_groups(ncols) * (double)h.N * 128.0 > 128.0 * 1024 * 1024) return 0;
   return nb;
 }
 
@@ -696,6 +700,7 @@ void spmm_slabbed(L& h, int mode, SpmmArgs sa, int grid, int iter = 0) {
   ProfScope ps(h, 0, iter);
   if (const int nb = xs_plan(h, c1 - c0, grid)) {
     sa.xs = nb;
+    sa.xs_groups = xs_groups(c1 - c0);
     launch_spmm(mode, sa, grid, h.stream);
     return;
   }
