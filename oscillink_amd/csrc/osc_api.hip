@@ -119,6 +119,7 @@ struct osc_lattice {
   DevBuf<float> pw;
   // CG scratch
   int grid_cap = 1024;
+  int32_t dcols = 0;      // D rounded up to 4: the columns the kernels work on (ld >= dcols is the row pitch)
   int32_t spmm_slab = 0;  // 0 = whole window per launch
   int spmm_xs = -1;        // XCD-affine narrow slabs: -1 auto, 0 off, 1 on (OSC_SPMM_XS)
   int xs_nb = 96;          // workgroups per XCD in that mode (OSC_XS_NB): 3 per CU measured best (2: 1.37, 4: 1.15 ms vs 1.11)
@@ -750,7 +751,7 @@ struct CgResult {
 // lattice does not fit that path (or its barrier timed out) and the general path must run.
 bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol,
                   CgResult& out) {
-  if (!h.small_path || h.comm != nullptr || b.c0 != 0 || b.c1 != b.ld || max_iters > 4096) return false;
+  if (!h.small_path || h.comm != nullptr || b.c0 != 0 || b.c1 != h.dcols || b.ld != h.dcols || max_iters > 4096) return false;
   const int C = small_pick_cols((int32_t)h.N, b.ld);
   if (C <= 0) return false;
   const size_t nslots = (size_t)max_iters + 2;
@@ -920,7 +921,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
 // Collective: every rank must call it.
 void gather_columns(L& h, float* arr) {
   if (!h.comm || h.world <= 1) return;
-  const int32_t q = h.ld / 4;
+  const int32_t q = h.dcols / 4;
   int32_t wmax = 0;
   for (int r = 0; r < h.world; ++r) wmax = std::max(wmax, (int32_t)(((int64_t)q * (r + 1) / h.world - (int64_t)q * r / h.world) * 4));
   h.comm_buf.alloc((size_t)h.N * wmax);
@@ -1191,9 +1192,24 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     h->stream = acquire_stream(device);
     h->N = N;
     h->D = D;
-    h->ld = ((D + 3) / 4) * 4;
+    h->dcols = ((D + 3) / 4) * 4;
+    h->ld = h->dcols;
+    // Row pitch.  Gathered rows that straddle 128-byte lines cost the operator apply (stand-alone: pitch 772 vs 768
+    // floats, 1.5-2.2 vs 1.06 ms; in the library at D = 1000: 12.2 ms per settle at pitch 1000, 10.7 at 1024), and a
+    // pitch that is a multiple of 4 KB piles the rows of a column slab onto few L2 channels (D = 1000: 9.7 ms at pitch
+    // 1056; 768 -> 800 changes nothing), so large lattices get line-aligned rows plus one line when the pitch would
+    // be a multiple of 4 KB; small ones keep the dense pitch (their state lives in LDS / L2 anyway).
+    // OSC_LD overrides (multiple of 4, >= D).
+    if ((int64_t)N * D >= (int64_t)1 << 22) {
+      h->ld = ((D + 31) / 32) * 32;
+      if ((h->ld * 4) % 4096 == 0) h->ld += 32;
+    }
+    if (const char* e = getenv("OSC_LD")) {
+      const int v = atoi(e);
+      if (v >= h->dcols && v % 4 == 0) h->ld = v;
+    }
     h->c0 = 0;
-    h->c1 = h->ld;
+    h->c1 = h->dcols;
     h->k_eff = (int32_t)std::min<int64_t>(k, std::max<int64_t>(1, N - 1));
     h->row_cap = row_cap;
     h->deterministic = deterministic;
@@ -1209,7 +1225,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_FAKE_COL_SHARD")) {  // "r/w": work on rank r's column slab of w, no communicator
       int r = 0, w = 1;                                   // (measurement hook: one rank's share of a column-sharded solve)
       if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) {
-        const int32_t q = h->ld / 4;
+        const int32_t q = h->dcols / 4;
         h->c0 = (int32_t)((int64_t)q * r / w) * 4;
         h->c1 = (int32_t)((int64_t)q * (r + 1) / w) * 4;
         if (h->c1 <= h->c0) throw Invalid("OSC_FAKE_COL_SHARD: more ranks than 4-column groups");
@@ -1851,13 +1867,13 @@ int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world)
     l.rank = rank;
     l.world = world;
     // column slabs in units of 4 floats, as even as possible
-    const int32_t q = l.ld / 4;
+    const int32_t q = l.dcols / 4;
     const int32_t lo = (int32_t)((int64_t)q * rank / world), hi = (int32_t)((int64_t)q * (rank + 1) / world);
     l.c0 = lo * 4;
     l.c1 = hi * 4;
     if (l.shard_mode == 1) {  // row-sharded CG: every rank works on all columns of its row block
       l.c0 = 0;
-      l.c1 = l.ld;
+      l.c1 = l.dcols;
     }
     if (l.c1 <= l.c0) throw Invalid("osc_comm_init: more ranks than 4-column groups");
     {
