@@ -41,6 +41,15 @@ __device__ __forceinline__ float4 mulacc4(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
 
+// offset of (row, col) in a slab-major array of `rows` rows (32-column slabs)
+__device__ __forceinline__ size_t blk_off(int64_t rows, int row, int col) {
+  return ((size_t)(col >> 5) * (size_t)rows + (size_t)row) * 32 + (size_t)(col & 31);
+}
+// offset of the float4 at (row, col) of the search direction P of an update kernel
+__device__ __forceinline__ size_t p_off(const UpdateArgs& a, int row, int col) {
+  return a.pblk ? blk_off(a.pblk, row, col) : (size_t)row * a.ld + col;
+}
+
 template <int LPR>
 __device__ __forceinline__ int bcast_i(int v, int sub, int t) {
   if constexpr (LPR == 64) {
@@ -166,11 +175,15 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o, 64));
     }
-    const float* xrow = a.X + (size_t)row * ld;
+    // operand addressing: row-major, or slab-major in xs mode (one slab per pass: the slab base is loop-invariant)
+    const bool xb = LPR == 8 && a.xblk != 0;
+    const float* xbase = xb ? a.X + (size_t)(sc0 >> 5) * (size_t)a.xblk * 32 + lr * 4 : a.X + coff[0];
+    const size_t xpitch = xb ? 32 : (size_t)ld;
+    const float* xrow = xbase + (size_t)row * xpitch;
     float4 xs[NCH], acc[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      xs[ch] = cok[ch] ? ld4(xrow + coff[ch]) : f4(0.f);
+      xs[ch] = cok[ch] ? ld4(xrow + (coff[ch] - coff[0])) : f4(0.f);
       acc[ch] = f4(0.f);
     }
     const int32_t* crow = a.g.col + (size_t)row * a.g.width;
@@ -203,9 +216,9 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
           for (int u = 0; u < U; ++u) {
             const int j = bcast_i<LPR>(cj, sub, t + u);  // t+u <= LPR-1: cnt <= LPR and LPR % U == 0
             wv[u] = bcast_f<LPR>(wj, sub, t + u);
-            const float* xj = a.X + (size_t)j * ld;
+            const float* xj = xbase + (size_t)j * xpitch;
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) v[u][ch] = cok[ch] ? ld4(xj + coff[ch]) : f4(0.f);
+            for (int ch = 0; ch < NCH; ++ch) v[u][ch] = cok[ch] ? ld4(xj + (coff[ch] - coff[0])) : f4(0.f);
           }
 #pragma unroll
           for (int u = 0; u < U; ++u)
@@ -225,10 +238,10 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
         for (int e = 0; e < pd; ++e) {
           const int j = a.g.pcol[(size_t)ps * a.g.pwidth + e];
           const float w = a.g.pw[(size_t)ps * a.g.pwidth + e];
-          const float* xj = a.X + (size_t)j * ld;
+          const float* xj = xbase + (size_t)j * xpitch;
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch)
-            if (cok[ch]) accp[ch] = fma4(w, ld4(xj + coff[ch]), accp[ch]);
+            if (cok[ch]) accp[ch] = fma4(w, ld4(xj + (coff[ch] - coff[0])), accp[ch]);
         }
       }
     }
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
           z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
           st4_stream(a.OUT + off, xs[ch]);
           st4_stream(a.R + off, r);
-          st4(a.P + off, z);
+          st4(a.P + (LPR == 8 && a.pblk != 0 ? blk_off(a.pblk, row, coff[ch]) : off), z);
           dot[ch] = mulacc4(r, z, dot[ch]);
         }
       }
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
     for (int ch = 0; ch < NCH; ++ch) {
       if (!cok[ch]) continue;
       const size_t off = (size_t)row * ld + coff[ch];
-      float4 x = ld4_stream(a.X + off), p = ld4_stream(a.P + off), r = ld4_stream(a.R + off);
+      float4 x = ld4_stream(a.X + off), p = ld4_stream(a.P + p_off(a, row, coff[ch])), r = ld4_stream(a.R + off);
       const float4 ap = ld4_stream(a.AP + off);
       x.x = fmaf(p.x, al[ch].x, x.x); x.y = fmaf(p.y, al[ch].y, x.y);
       x.z = fmaf(p.z, al[ch].z, x.z); x.w = fmaf(p.w, al[ch].w, x.w);
@@ -346,11 +359,12 @@ __global__ __launch_bounds__(256) void k_update_p(const UpdateArgs a) {
     for (int ch = 0; ch < NCH; ++ch) {
       if (!cok[ch]) continue;
       const size_t off = (size_t)row * ld + coff[ch];
+      const size_t poff = p_off(a, row, coff[ch]);
       const float4 r = ld4_stream(a.R + off);
-      float4 p = ld4_stream(a.P + off);
+      float4 p = ld4_stream(a.P + poff);
       p.x = fmaf(p.x, be[ch].x, r.x * invMd); p.y = fmaf(p.y, be[ch].y, r.y * invMd);
       p.z = fmaf(p.z, be[ch].z, r.z * invMd); p.w = fmaf(p.w, be[ch].w, r.w * invMd);
-      st4(a.P + off, p);
+      st4(a.P + poff, p);
     }
   }
 }

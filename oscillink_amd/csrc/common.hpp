@@ -101,6 +101,11 @@ struct SpmmArgs {
   // L2 alone instead of with the other slabs of the window.  xs_groups = gcd(8, number of slabs): always balanced.
   int32_t xs;
   int32_t xs_groups;
+  // Slab-major ("blocked") layout of the CG search direction, xs mode only: element (row, col) of an array stored
+  // that way sits at ((col / 32) * rows + row) * 32 + col % 32, so the 32-column slab an XCD gathers from is one
+  // contiguous N x 128 B range (even spread over the L2 channels; no 3 KB row stride).  xblk != 0: the operand X is
+  // stored that way (value = rows per slab = N); pblk != 0: INIT writes its P output that way.
+  int64_t xblk, pblk;
 };
 
 struct UpdateArgs {
@@ -119,6 +124,7 @@ struct UpdateArgs {
   int32_t ld, c0, c1;
   const float* gate;  // see SpmmArgs
   float gate_tol;
+  int64_t pblk;  // != 0: P is stored slab-major with this many rows per slab (see SpmmArgs)
 };
 
 struct Gate {

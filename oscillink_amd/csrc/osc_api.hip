@@ -122,7 +122,8 @@ struct osc_lattice {
   int32_t dcols = 0;      // D rounded up to 4: the columns the kernels work on (ld >= dcols is the row pitch)
   int32_t spmm_slab = 0;  // 0 = whole window per launch
   int spmm_xs = -1;        // XCD-affine narrow slabs: -1 auto, 0 off, 1 on (OSC_SPMM_XS)
-  int xs_nb = 96;          // workgroups per XCD in that mode (OSC_XS_NB): 3 per CU measured best (2: 1.37, 4: 1.15 ms vs 1.11)
+  bool p_blocked = true;   // slab-major search direction in xs mode (OSC_P_BLOCKED=0 keeps it row-major)
+  int xs_nb = 0;           // workgroups per XCD in that mode; 0 = automatic (OSC_XS_NB)
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
   DevBuf<uint32_t> res_bits, arrive;  // arrive: per-iteration barrier counters (+1 status word) of the one-launch path
@@ -687,7 +688,7 @@ int xs_groups(int32_t ncols) {
 }
 int xs_plan(const L& h, int32_t ncols, int grid) {
   if (grid < 8 || (grid & 7) != 0) return 0;
-  const int nb = std::max(1, std::min(grid / 8, h.xs_nb));
+  const int nb = std::max(1, std::min(grid / 8, h.xs_nb > 0 ? h.xs_nb : 96));
   if (h.spmm_xs == 0) return 0;
   if (h.spmm_xs == 1) return nb;
   if (h.spmm_slab != 0 || h.reordered || (h.ld & 31) != 0 || (h.c0 & 31) != 0) return 0;
@@ -700,7 +701,9 @@ void spmm_slabbed(L& h, int mode, SpmmArgs sa, int grid, int iter = 0) {
   const int32_t c0 = sa.c0, c1 = sa.c1;
   ProfScope ps(h, 0, iter);
   if (const int nb = xs_plan(h, c1 - c0, grid)) {
-    sa.xs = nb;
+    // workgroups per XCD: 3 per CU when the operand is row-major (2: 1.37, 4: 1.15 ms vs 1.11), 4 per CU when it is
+    // slab-major (3: 1.09, 4: 1.05 ms)
+    sa.xs = (h.xs_nb <= 0 && sa.xblk != 0) ? std::min(grid / 8, 128) : nb;
     sa.xs_groups = xs_groups(c1 - c0);
     launch_spmm(mode, sa, grid, h.stream);
     return;
@@ -850,9 +853,15 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   sa.U = b.rhsU;
   sa.Y = b.rhsY;
   sa.gate = nullptr;
+  // slab-major search direction: only where the XCD-affine slab apply runs (its gathers then read contiguous slabs)
+  // and P is private to this solve (N x ld floats either way; needs whole 32-column slabs inside the pitch)
+  const bool pblk = h.p_blocked && xs_plan(h, b.c1 - b.c0, grid) > 0 && (b.ld & 31) == 0 && (b.c0 & 31) == 0 &&
+                    b.ld == h.ld;
+  sa.pblk = pblk ? h.N : 0;
   spmm_slabbed(h, SPMM_INIT, sa, grid);
   launch_reduce_init(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.stream);
   UpdateArgs ua{};
+  ua.pblk = pblk ? h.N : 0;
   ua.X = b.X;
   ua.R = b.R;
   ua.P = b.P;
@@ -869,6 +878,8 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   ua.c1 = b.c1;
   sa.X = b.P;
   sa.OUT = b.AP;
+  sa.xblk = pblk ? h.N : 0;
+  sa.pblk = 0;
 
   auto enqueue_iter = [&](int it) {  // everything of iteration `it` up to its residual, gated on iteration it-1
     const Gate g{it > 1 ? res_dev + (it - 1) : nullptr, tol};
@@ -1218,6 +1229,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_GRID_CAP")) h->grid_cap = std::max(1, atoi(e));
     if (const char* e = getenv("OSC_SPMM_XS")) h->spmm_xs = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_XS_NB")) h->xs_nb = std::max(1, atoi(e));
+    if (const char* e = getenv("OSC_P_BLOCKED")) h->p_blocked = atoi(e) != 0;
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
     if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_SHARD")) h->shard_mode = !strcmp(e, "row") ? 1 : 0;
