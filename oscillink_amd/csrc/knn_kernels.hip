@@ -67,6 +67,60 @@ __global__ __launch_bounds__(256) void k_rows_dot(const float* Yn, int32_t ldn, 
   if (lane == 0) out[row] = s;
 }
 
+// Sorted insert of the candidates flagged in (m0, m1) -- one bit per lane of half 0 / half 1 -- of register `c` (a query
+// row per half-wave, 32 columns starting at `cbase`) into that row's register-resident list: one candidate per half
+// per trip, rank by ballot + popcount, shift by v_mov_dpp wave_shr:1, carries by v_readlane; no LDS traffic.
+template <int E>
+__device__ __forceinline__ void list_insert(float (&lvg)[E], int (&lig)[E], float c, int cbase, unsigned m0, unsigned m1,
+                                            int h, int l31) {
+  while (m0 | m1) {
+    const int s0 = m0 ? (__ffs(m0) - 1) : 0, s1 = m1 ? (__ffs(m1) - 1) : 0;
+    const float cv0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), s0));
+    const float cv1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 32 + s1));
+    const float cv = h ? cv1 : cv0;
+    const int cc = cbase + (h ? s1 : s0);
+    // insertion rank = number of list entries that beat the candidate
+    int p0 = 0, p1 = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const bool better = lvg[e] > cv || (lvg[e] == cv && lig[e] < cc);
+      const unsigned long long bm = __ballot(better);
+      p0 += __popc((unsigned)bm);
+      p1 += __popc((unsigned)(bm >> 32));
+    }
+    if (!m0) p0 = 1 << 20;
+    if (!m1) p1 = 1 << 20;
+    const int p = h ? p1 : p0;
+    // shift ranks > p down by one (v_mov_dpp wave_shr:1; the rank-32e slot takes the carry of register e-1)
+#pragma unroll
+    for (int e = E - 1; e >= 0; --e) {
+      const int rank = l31 + 32 * e;
+      float inv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lvg[e]), 0x138, 0xf, 0xf, false));
+      int ini = __builtin_amdgcn_update_dpp(0, lig[e], 0x138, 0xf, 0xf, false);
+      if (e > 0) {
+        const int pv = __float_as_int(lvg[e - 1]);
+        const float c0 = __int_as_float(__builtin_amdgcn_readlane(pv, 31));
+        const float c1 = __int_as_float(__builtin_amdgcn_readlane(pv, 63));
+        const int i0 = __builtin_amdgcn_readlane(lig[e - 1], 31);
+        const int i1 = __builtin_amdgcn_readlane(lig[e - 1], 63);
+        if (l31 == 0) {
+          inv = h ? c1 : c0;
+          ini = h ? i1 : i0;
+        }
+      }
+      if (rank > p) {
+        lvg[e] = inv;
+        lig[e] = ini;
+      } else if (rank == p) {
+        lvg[e] = cv;
+        lig[e] = cc;
+      }
+    }
+    m0 &= m0 - 1;  // drop the candidate just handled in each half
+    m1 &= m1 - 1;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // work item = (row block of 128, column split s of S).  cand_*: [N][S][32E]
 //
@@ -163,7 +217,12 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
         *reinterpret_cast<float4*>(Bs + srow[q] * LDT + sc4[q]) = rb[q];
       }
       __syncthreads();
-      if (kt + 1 < nkt) {  // issue next tile's global loads; they land under the MFMAs below
+#ifndef OSC_KNN_NOGLOAD  // experiment switch: reuse the first tile's registers (results are wrong)
+      if (kt + 1 < nkt)  // issue next tile's global loads; they land under the MFMAs below
+#else
+      if (false)
+#endif
+      {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           ra[q] = ld4(a_ptr[q] + (kt + 1) * BK);
@@ -174,10 +233,17 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
       const float* bp = Bs + l31 * LDT + 4 * h;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+#ifndef OSC_KNN_NOLDSREAD
         const float4 av = ld4(ap + 8 * s);
         float4 bv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) bv[t] = ld4(bp + 32 * t * LDT + 8 * s);
+#else  // experiment switch: MFMA on register operands only (results are wrong)
+        const float4 av = ra[s & 3];
+        float4 bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t] = rb[(s + t) & 3];
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           if constexpr (F16) {
@@ -213,52 +279,9 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
 #endif
         unsigned long long m = __ballot(pred);
         unsigned m0 = (unsigned)m, m1 = (unsigned)(m >> 32);  // wave-uniform (SGPR) candidate masks of the two halves
-        while (m0 | m1) {  // rare path: one candidate per half-wave per trip, exact sorted insert, no LDS traffic
+        if (m0 | m1) {
           touched = true;
-          const int s0 = m0 ? (__ffs(m0) - 1) : 0, s1 = m1 ? (__ffs(m1) - 1) : 0;
-          const float cv0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), s0));
-          const float cv1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 32 + s1));
-          const float cv = h ? cv1 : cv0;
-          const int cc = ct + 32 * t + (h ? s1 : s0);
-          // insertion rank = number of list entries that beat the candidate
-          int p0 = 0, p1 = 0;
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const bool better = lv[g][e] > cv || (lv[g][e] == cv && li[g][e] < cc);
-            const unsigned long long bm = __ballot(better);
-            p0 += __popc((unsigned)bm);
-            p1 += __popc((unsigned)(bm >> 32));
-          }
-          if (!m0) p0 = 1 << 20;
-          if (!m1) p1 = 1 << 20;
-          const int p = h ? p1 : p0;
-          // shift ranks > p down by one (v_mov_dpp wave_shr:1; the rank-32e slot takes the carry of register e-1)
-#pragma unroll
-          for (int e = E - 1; e >= 0; --e) {
-            const int rank = l31 + 32 * e;
-            float inv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lv[g][e]), 0x138, 0xf, 0xf, false));
-            int ini = __builtin_amdgcn_update_dpp(0, li[g][e], 0x138, 0xf, 0xf, false);
-            if (e > 0) {
-              const int pv = __float_as_int(lv[g][e - 1]);
-              const float c0 = __int_as_float(__builtin_amdgcn_readlane(pv, 31));
-              const float c1 = __int_as_float(__builtin_amdgcn_readlane(pv, 63));
-              const int i0 = __builtin_amdgcn_readlane(li[g][e - 1], 31);
-              const int i1 = __builtin_amdgcn_readlane(li[g][e - 1], 63);
-              if (l31 == 0) {
-                inv = h ? c1 : c0;
-                ini = h ? i1 : i0;
-              }
-            }
-            if (rank > p) {
-              lv[g][e] = inv;
-              li[g][e] = ini;
-            } else if (rank == p) {
-              lv[g][e] = cv;
-              li[g][e] = cc;
-            }
-          }
-          m0 &= m0 - 1;  // drop the candidate just handled in each half
-          m1 &= m1 - 1;
+          list_insert<E>(lv[g], li[g], c, ct + 32 * t, m0, m1, h, l31);
         }
       }
       if (touched) {  // refresh the filter threshold = similarity at rank keep-1
@@ -302,6 +325,192 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t k, int32_t S, int32_t cols_per_split, float* cand_val,
     int32_t* cand_idx, int32_t rb_begin, int32_t rb_count, const int32_t* __restrict__ qrows, int32_t nq) {
   knn_topk_body<4, false, QR>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count, qrows, nq);
+}
+
+// ---- prefilter kernel (fp16 MFMA), LDS-DMA staged -------------------------------------------------------------------
+// Same work decomposition, fragment mapping and register-resident lists as knn_topk_body<E, true, false>, different
+// staging pipeline:
+//   * operand tiles (128 rows x 128 B = one 64-half K step) go global -> LDS by global_load_lds_dwordx4 (no staging
+//     registers, no ds_write pass).  The LDS image is lane-linear per wave-instruction (8 rows x 128 B), so the bank
+//     swizzle sits on the SOURCE address: 16-byte chunk c of row r is stored at chunk position c ^ (r & 7), and the
+//     fragment reads apply the same xor (conflict-free ds_read_b128 without padding).
+//   * two LDS stages (64 KB per workgroup, two workgroups per CU), ONE barrier per K step; the (column tile, K step)
+//     loop is flat, so the first K step of the next column tile is in flight during the last MFMAs and the list update
+//     of the current one.
+//   * list update: one v_max3/v_max + compare per query-row register decides whether any of its 4 x 32 columns can
+//     enter the list before the four per-tile ballots are taken.
+constexpr int PF_STAGE = 2 * BM * BK;  // floats per stage: A tile + B tile, 128 x 32 slots each
+
+template <int E>
+__global__ __launch_bounds__(256, 2) void k_knn_pref(const float* __restrict__ Yh, int32_t ldn, int32_t N, int32_t k,
+                                                     int32_t S, int32_t cols_per_split, float* cand_val,
+                                                     int32_t* cand_idx, int32_t rb_begin, int32_t rb_count) {
+  __shared__ __attribute__((aligned(1024))) float lds[2 * PF_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;  // XCD-aware item order (see knn_topk_body)
+  const int rloc = (jx / S) * 8 + xcd, split = jx % S;
+  const int rblk = rb_begin + rloc;
+  if (rloc >= rb_count || rblk * BM >= N) return;
+  const int row0 = rblk * BM;
+  const int cbeg = split * cols_per_split;
+  const int cend = min(N, cbeg + cols_per_split);
+  const int nkt = ldn / BK;
+  const int ntile = (cend - cbeg + BN - 1) / BN;
+  if (ntile <= 0) return;
+
+  float lv[16][E];
+  int li[16][E];
+  float thr[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    thr[g] = NEG;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      lv[g][e] = NEG;
+      li[g][e] = 0x7fffffff;
+    }
+  }
+  const int thr_l = (k - 1) & 31, thr_e = (k - 1) >> 5;
+
+  // LDS-DMA roles: wave w fills rows [32 w, 32 w + 32) of both tiles, 8 rows (1 KiB) per instruction.  Lane L of an
+  // instruction lands at row L >> 3, chunk position L & 7, and therefore fetches source chunk (L & 7) ^ (row & 7).
+  const int frow = lane >> 3;                       // row inside the 8-row piece (= row & 7: pieces start at multiples of 8)
+  const int fchunk = ((lane & 7) ^ frow) * 4;       // source offset in floats
+  const float* a_src[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a_src[q] = Yh + (size_t)min(row0 + 32 * wave + 8 * q + frow, N - 1) * ldn + fchunk;
+
+  // The DMA is issued from inline asm: through the builtin the compiler orders every later ds_read behind it with
+  // s_waitcnt vmcnt(0) (it cannot see that the reads go to the other stage), which would expose the whole load latency
+  // in every K step.  The wait that retires the DMA is the explicit vmcnt(0) in front of the step's barrier.
+  const unsigned lds_base = (unsigned)(size_t)lds;  // LDS byte offset of the staging area (low half of the flat address)
+  auto glds16 = [&](const float* src, unsigned dst_bytes) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst_bytes)
+                 : "memory");
+  };
+  auto issue = [&](int stage, int ct, int kt) {  // one K step of tile `ct` into LDS stage `stage`
+    const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * PF_STAGE + 32 * wave * BK) * 4u);
+    const unsigned b_dst = a_dst + (unsigned)(BM * BK) * 4u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* bsrc = Yh + (size_t)min(ct + 32 * wave + 8 * q + frow, N - 1) * ldn + fchunk + kt * BK;
+      glds16(a_src[q] + kt * BK, a_dst + (unsigned)(8 * q * BK) * 4u);
+      glds16(bsrc, b_dst + (unsigned)(8 * q * BK) * 4u);
+    }
+  };
+  auto dma_wait_and_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  const int wrow_base = row0 + 32 * wave;
+  auto grow_at = [&](int g) -> int {
+    const int pos = wrow_base + (g & 3) + 8 * (g >> 2) + 4 * h;
+    return pos < N ? pos : -1;
+  };
+  const int swz = l31 & 7;  // (row & 7) of every fragment row this lane reads (tile bases are multiples of 8)
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+
+  int ct = cbeg, kt = 0;       // the step being computed
+  issue(0, ct, 0);
+  dma_wait_and_barrier();
+  const int total = ntile * nkt;
+  for (int step = 0; step < total; ++step) {
+    const int stage = step & 1;
+    {  // prefetch the next step into the other stage (its readers finished before the barrier that ended step-1)
+      int nct = ct, nkt2 = kt + 1;
+      if (nkt2 == nkt) {
+        nkt2 = 0;
+        nct = ct + BN;
+      }
+      if (step + 1 < total) issue(stage ^ 1, nct, nkt2);
+    }
+    const float* Asw = lds + stage * PF_STAGE + (32 * wave + l31) * BK;
+    const float* Bsw = lds + stage * PF_STAGE + BM * BK + l31 * BK;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int co = (((2 * s + h) ^ swz)) * 4;
+      const float4 av = ld4(Asw + co);
+      float4 bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bv[t] = ld4(Bsw + 32 * t * BK + co);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, av), __builtin_bit_cast(half8, bv[t]),
+                                                        acc[t], 0, 0, 0);
+    }
+    if (kt == nkt - 1) {  // ---- tile finished: running top-k update for this 32 x 128 slice ----
+      const bool need_mask = (ct + BN > cend) || (ct < wrow_base + 32 && ct + BN > wrow_base);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        float c4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c4[t] = acc[t][g];
+        if (need_mask) {
+          const int grow = grow_at(g);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int ccol = ct + 32 * t + l31;
+            if (ccol >= cend || ccol == grow) c4[t] = NEG;  // graph.py:37 (diag = -inf) and the ragged tail
+          }
+        }
+        const float cmax = fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3]));
+        if (__ballot(cmax > thr[g]) != 0ull) {  // some column of this row (either half) may enter its list
+          bool touched = false;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const unsigned long long m = __ballot(c4[t] > thr[g] && c4[t] > NEG);
+            const unsigned m0 = (unsigned)m, m1 = (unsigned)(m >> 32);
+            if (m0 | m1) {
+              touched = true;
+              list_insert<E>(lv[g], li[g], c4[t], ct + 32 * t, m0, m1, h, l31);
+              // later tiles of this register see the tightened threshold too
+              float src = lv[g][0];
+#pragma unroll
+              for (int e = 1; e < E; ++e)
+                if (thr_e == e) src = lv[g][e];
+              const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), thr_l));
+              const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), 32 + thr_l));
+              thr[g] = h ? t1 : t0;
+            }
+          }
+          (void)touched;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+      kt = 0;
+      ct += BN;
+    } else {
+      ++kt;
+    }
+    dma_wait_and_barrier();  // next stage landed and every wave is done reading this one
+  }
+
+  constexpr int KC = 32 * E;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int grow = grow_at(g);
+    if (grow >= 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const size_t o = ((size_t)grow * S + split) * KC + l31 + 32 * e;
+        cand_val[o] = lv[g][e];
+        cand_idx[o] = li[g][e];
+      }
+    }
+  }
 }
 
 // fp16 image of 16*Yn for the prefilter (|Yn| <= 1, so no overflow; the scale keeps small entries out of the
@@ -563,11 +772,18 @@ void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, 
   const dim3 grid((unsigned)(8 * ((p.rb_count + 7) / 8) * p.S)), block(256);
 #define OSC_KNN_ARGS \
   Yop, ld, N, p.keep, p.S, p.cols_per_split, cand_val, cand_idx, p.rb_begin, p.rb_count, p.qrows, p.nq
+#define OSC_KNN_PREF_ARGS Yop, ld, N, p.keep, p.S, p.cols_per_split, cand_val, cand_idx, p.rb_begin, p.rb_count
   if (p.f16) {
     if (p.qrows) throw std::runtime_error("the prefilter kernel has no row-list variant");
+#ifdef OSC_KNN_PREF_OLD  // register-staged prefilter (kept for A/B runs)
     if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
     else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
     else if (p.E == 3) hipLaunchKernelGGL((k_knn_topk<3, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
+#else
+    if (p.E == 1) hipLaunchKernelGGL((k_knn_pref<1>), grid, block, 0, s, OSC_KNN_PREF_ARGS);
+    else if (p.E == 2) hipLaunchKernelGGL((k_knn_pref<2>), grid, block, 0, s, OSC_KNN_PREF_ARGS);
+    else if (p.E == 3) hipLaunchKernelGGL((k_knn_pref<3>), grid, block, 0, s, OSC_KNN_PREF_ARGS);
+#endif
     else throw std::runtime_error("f16 prefilter supports at most 96 kept candidates");
   } else if (p.qrows) {
     if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, false, true>), grid, block, 0, s, OSC_KNN_ARGS);
