@@ -432,17 +432,26 @@ __global__ __launch_bounds__(256, 2) void k_knn_pref(const float* __restrict__ Y
         nkt2 = 0;
         nct = ct + BN;
       }
+#ifndef OSC_PF_NODMA  // experiment switches (wrong results): no DMA after the first step / no fragment reads / no list update
       if (step + 1 < total) issue(stage ^ 1, nct, nkt2);
+#endif
     }
     const float* Asw = lds + stage * PF_STAGE + (32 * wave + l31) * BK;
     const float* Bsw = lds + stage * PF_STAGE + BM * BK + l31 * BK;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int co = (((2 * s + h) ^ swz)) * 4;
+#ifndef OSC_PF_NOLDSREAD
       const float4 av = ld4(Asw + co);
       float4 bv[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) bv[t] = ld4(Bsw + 32 * t * BK + co);
+#else
+      const float4 av = make_float4(co + 1.f, s, h, 1.f);
+      float4 bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bv[t] = make_float4(t, co, 2.f, s);
+#endif
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, av), __builtin_bit_cast(half8, bv[t]),
@@ -464,7 +473,12 @@ __global__ __launch_bounds__(256, 2) void k_knn_pref(const float* __restrict__ Y
           }
         }
         const float cmax = fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3]));
-        if (__ballot(cmax > thr[g]) != 0ull) {  // some column of this row (either half) may enter its list
+#ifdef OSC_PF_NOEPI
+        asm volatile("" ::"v"(cmax));
+        if (false) {
+#else
+        if (__ballot(cmax > thr[g]) != 0ull) {
+#endif  // some column of this row (either half) may enter its list
           bool touched = false;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
