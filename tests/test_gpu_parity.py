@@ -840,3 +840,40 @@ def test_xcd_affine_slab_apply_is_the_default_only_in_its_window(amd, monkeypatc
     b = off.settle(max_iters=12, tol=1e-3)
     assert a["iters"] == b["iters"]
     assert relerr(big.U, off.U) < 1e-5
+
+
+@pytest.mark.parametrize("force_xs", ["0", "1"])
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_column_windows_of_a_sharded_solve_match_the_full_solve(amd, world, force_xs, monkeypatch):
+    """OSC_FAKE_COL_SHARD=r/w gives a handle rank r's column window of a w-rank column-sharded solve (no communicator).
+    With the stop test out of the way (tol = 0: every column runs max_iters iterations) each window must reproduce
+    the same columns of the unsharded solve; with OSC_SPMM_XS=1 the windows run the XCD-affine slab apply with the
+    slab-major search direction at a non-zero column offset."""
+    from oscillink_amd.sharding import column_shard
+
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    monkeypatch.setenv("OSC_SPMM_XS", force_xs)
+    rng = np.random.default_rng(21)
+    N, D, k = 3000, 256, 12
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    gates = rng.uniform(0.2, 1.0, N).astype(np.float32)
+    full = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+    full.set_query(psi, gates=gates)
+    full.add_chain([5, 9, 2, 77, 1500], lamP=0.3)
+    full.settle(max_iters=5, tol=0.0)
+    Uf = full.U.copy()
+    csr = full.graph_csr()
+    for r in range(world):
+        monkeypatch.setenv("OSC_FAKE_COL_SHARD", f"{r}/{world}")
+        part = amd.Oscillink(Y, kneighbors=k, deterministic_k=True, _build_graph=False)
+        part.set_graph_csr(csr[0], csr[1], csr[2])
+        part.set_query(psi, gates=gates)
+        part.add_chain([5, 9, 2, 77, 1500], lamP=0.3)
+        st = part.settle(max_iters=5, tol=0.0)
+        assert st["iters"] == 5
+        c0, c1 = column_shard(D, r, world)
+        assert relerr(part.U[:, c0:c1], Uf[:, c0:c1]) < 1e-5, (r, world)
+        if force_xs == "1":
+            assert part.build_info()["apply_xs_workgroups"] > 0
+    monkeypatch.delenv("OSC_FAKE_COL_SHARD")
