@@ -37,6 +37,7 @@ for name in (sys.argv[1:] or list(CONFIGS)):
         t0 = time.perf_counter()
         st = lat.settle(max_iters=12, tol=tol)
         ts.append(time.perf_counter() - t0)
+    lat.refresh_Ustar()  # first call: state signature (CSR download + hashing) and a GPU that idled meanwhile
     t0 = time.perf_counter()
     lat.refresh_Ustar()
     t_us = time.perf_counter() - t0
