@@ -126,10 +126,11 @@ def main():
     lat._call("osc_comm_shard", C.byref(c0), C.byref(c1))
     d_local = int(c1.value - c0.value)
     n_local = N // world if (args.shard == "row" and launched) else N  # rows this rank applies the operator to
-    # The dominant kernel is the operator apply (CG matvec).  It is launched as column slabs (k_spmm<32,1,0> at
-    # config 3: 6 slabs of 128 columns); the library times each apply (all its slab launches) with one HIP-event pair
-    # on its own stream.  Algorithmic bytes of ONE apply on this rank: read X once, write the
-    # result once, ELL col + val, rowptr/B/diag per row; per launch = per apply / slabs.
+    # The dominant kernel is the operator apply inside the CG loop (the CG matvec).  The library times each apply (all
+    # its launches: one at config 3, column slabs elsewhere) with one HIP-event pair on its own stream; the
+    # initial-residual apply of a settle (extra rhs / r / p streams) is kept in a separate slot.  Algorithmic bytes of
+    # ONE apply on this rank: read X once, write the result once, ELL col + val, rowptr/B/diag per
+    # row; per launch = per apply / launches.
     plan = lat.build_info()
     slabs = max(1, plan["apply_launches"])
     spmm_kernel = "k_spmm<8, 1, 0>" if plan["apply_xs_workgroups"] else None

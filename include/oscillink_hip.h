@@ -151,9 +151,10 @@ int osc_receipt_rows(osc_handle h, float z_th, float* coh_drop, float* anchor_pe
                      int32_t* j_out, float* z_out, float* r_out, int32_t* count);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* Per-kernel HIP-event timing on the handle's own stream.  which: 0 = operator apply (SpMM, the
- * CG matvec), 1 = fused x/r update, 2 = p update, 3 = kNN GEMM+top-k.  Returns launches and the
- * summed device time since the last reset.  Enabling adds two event records per launch. */
+/* Per-kernel HIP-event timing on the handle's own stream.  which: 0 = operator apply inside the CG loop (SpMM, the
+ * CG matvec; one sample per apply = all its launches), 1 = fused x/r update, 2 = p update, 3 = kNN GEMM+top-k,
+ * 4 = the initial-residual apply of a solve (same gather plus the rhs / r / p streams).  Returns samples and the
+ * summed device time since the last reset.  Enabling adds two event records per sample. */
 int osc_profile_enable(osc_handle h, int32_t on);
 int osc_profile_reset(osc_handle h);
 int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* total_ms);

@@ -149,8 +149,8 @@ struct osc_lattice {
   bool prof_on = false;
   std::vector<ProfSlot> prof_pending;
   std::vector<hipEvent_t> prof_pool;
-  int64_t prof_count[4] = {0, 0, 0, 0};
-  double prof_ms[4] = {0, 0, 0, 0};
+  int64_t prof_count[5] = {0, 0, 0, 0, 0};
+  double prof_ms[5] = {0, 0, 0, 0, 0};
   std::string err;
 
   ~osc_lattice() {
@@ -699,7 +699,7 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
 
 void spmm_slabbed(L& h, int mode, SpmmArgs sa, int grid, int iter = 0) {
   const int32_t c0 = sa.c0, c1 = sa.c1;
-  ProfScope ps(h, 0, iter);
+  ProfScope ps(h, mode == SPMM_INIT ? 4 : 0, iter);  // slot 0: AP applies (the CG matvec); slot 4: the INIT apply
   if (const int nb = xs_plan(h, c1 - c0, grid)) {
     // workgroups per XCD: 3 per CU when the operand is row-major (2: 1.37, 4: 1.15 ms vs 1.11), 4 per CU when it is
     // slab-major (3: 1.09, 4: 1.05 ms)
@@ -1846,7 +1846,7 @@ int osc_profile_enable(osc_handle h, int32_t on) {
 int osc_profile_reset(osc_handle h) {
   return guarded(h, [&](L& l) {
     prof_drain(l);
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
       l.prof_count[i] = 0;
       l.prof_ms[i] = 0.0;
     }
@@ -1854,7 +1854,7 @@ int osc_profile_reset(osc_handle h) {
 }
 int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* total_ms) {
   return guarded(h, [&](L& l) {
-    if (which < 0 || which > 3) throw Invalid("osc_profile_get: which must be 0..3");
+    if (which < 0 || which > 4) throw Invalid("osc_profile_get: which must be 0..4");
     prof_drain(l);
     if (launches) *launches = l.prof_count[which];
     if (total_ms) *total_ms = l.prof_ms[which];
