@@ -224,12 +224,28 @@ void upload_rows(L& h, float* dst, const float* src) {  // N x D host -> N x ld 
     HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)h.N * h.D * 4, hipMemcpyHostToDevice, h.stream));
     return;
   }
+  // padded pitch: a strided copy from pageable host memory is several times slower than a contiguous one, so large
+  // arrays go contiguous into a scratch array (R / P are free between solves) and are re-pitched on the device
+  float* stage = (dst == h.R.p) ? h.P.p : h.R.p;
+  if ((int64_t)h.N * h.D >= ((int64_t)1 << 20) && stage != nullptr && stage != dst) {
+    HIP_CHECK(hipMemcpyAsync(stage, src, (size_t)h.N * h.D * 4, hipMemcpyHostToDevice, h.stream));
+    HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)h.ld * 4, stage, (size_t)h.D * 4, (size_t)h.D * 4, (size_t)h.N,
+                               hipMemcpyDeviceToDevice, h.stream));
+    return;
+  }
   HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)h.ld * 4, src, (size_t)h.D * 4, (size_t)h.D * 4, (size_t)h.N,
                              hipMemcpyHostToDevice, h.stream));
 }
 void download_rows(L& h, float* dst, const float* src) {
   if (h.ld == h.D) {
     HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)h.N * h.D * 4, hipMemcpyDeviceToHost, h.stream));
+    return;
+  }
+  float* stage = (src == h.R.p) ? h.P.p : h.R.p;
+  if ((int64_t)h.N * h.D >= ((int64_t)1 << 20) && stage != nullptr && stage != src) {
+    HIP_CHECK(hipMemcpy2DAsync(stage, (size_t)h.D * 4, src, (size_t)h.ld * 4, (size_t)h.D * 4, (size_t)h.N,
+                               hipMemcpyDeviceToDevice, h.stream));
+    HIP_CHECK(hipMemcpyAsync(dst, stage, (size_t)h.N * h.D * 4, hipMemcpyDeviceToHost, h.stream));
     return;
   }
   HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)h.D * 4, src, (size_t)h.ld * 4, (size_t)h.D * 4, (size_t)h.N,
