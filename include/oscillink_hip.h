@@ -135,6 +135,13 @@ int osc_cg_single_rhs(osc_handle h, float gamma, const float* s, float tol, int3
                       int32_t* iters, float* res);
 /* cosine of every anchor row with psi (diffusion.py:104-107): out[i] = <Y_i/(|Y_i|+1e-12), psi/(|psi|+1e-12)> */
 int osc_cosine_to(osc_handle h, const float* psi, float* out);
+/* the same over the rows of the resident U*: bundle()'s alignment term (lattice.py:530-568:
+ * align_i = <U*_i / (|U*_i| + 1e-12), psi / (|psi| + 1e-12)>); OSC_E_STATE without a resident U*.  With psi = an
+ * anchor row, osc_cosine_to gives the similarity row mmr_diversify needs for one chosen item (graph.py:114-133). */
+int osc_ustar_cosine_to(osc_handle h, const float* psi, float* out);
+/* out[i] = <Yn_i, Yn_row>: the similarity row of one chosen item for mmr_diversify (graph.py:114-133), from the
+ * device's own copy of the anchors */
+int osc_cosine_to_row(osc_handle h, int64_t row, float* out);
 
 /* ---- receipts ------------------------------------------------------------------------------- */
 /* deltaH_trace (receipts.py:10-25) on the resident U and U* */

@@ -22,6 +22,7 @@ struct KnnPlan {
 KnnPlan knn_plan(int32_t N, int32_t keep, int32_t slots, int rb_begin, int rb_count, bool f16);
 void launch_normalize_rows(const float* Y, int32_t ldy, float* Yn, int32_t ldn, int64_t N, int32_t D, hipStream_t s);
 void launch_rows_dot(const float* Yn, int32_t ldn, const float* q, float* out, int64_t N, int32_t D, hipStream_t s);
+void launch_rows_cosine(const float* A, int32_t ld, const float* q, float* out, int64_t N, int32_t D, hipStream_t s);
 void launch_to_f16(const float* Yn, int32_t ldn, void* Yh, int32_t ldh, int64_t N, int32_t D, hipStream_t s);
 // Yop: fp32 Yn (ld floats) or the fp16 image (ld = ldh/2 float slots)
 void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, float* cand_val, int32_t* cand_idx,

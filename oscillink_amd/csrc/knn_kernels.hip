@@ -67,6 +67,28 @@ __global__ __launch_bounds__(256) void k_rows_dot(const float* Yn, int32_t ldn, 
   if (lane == 0) out[row] = s;
 }
 
+// out[i] = <A_i / (|A_i| + 1e-12), q> in one pass over the rows (q pre-normalised): the cosine of every row of an N x D
+// array to one query without a normalised copy (diffusion.py:104-107, lattice.py:530-568, graph.py:114-133)
+__global__ __launch_bounds__(256) void k_rows_cosine(const float* A, int32_t ld, const float* q, float* out, int64_t N,
+                                                     int32_t D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* y = A + row * ld;
+  float s = 0.f, n2 = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float v = y[c];
+    s = fmaf(v, q[c], s);
+    n2 = fmaf(v, v, n2);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    n2 += __shfl_xor(n2, o, 64);
+  }
+  if (lane == 0) out[row] = s / (sqrtf(n2) + 1e-12f);
+}
+
 // Sorted insert of the candidates flagged in (m0, m1) -- one bit per lane of half 0 / half 1 -- of register `c` (a query
 // row per half-wave, 32 columns starting at `cbase`) into that row's register-resident list: one candidate per half
 // per trip, rank by ballot + popcount, shift by v_mov_dpp wave_shr:1, carries by v_readlane; no LDS traffic.
@@ -732,6 +754,10 @@ __global__ void k_normalize_w(const float* ell_a, const int32_t* ell_col, const 
 // ---- launchers --------------------------------------------------------------------------------
 void launch_normalize_rows(const float* Y, int32_t ldy, float* Yn, int32_t ldn, int64_t N, int32_t D, hipStream_t s) {
   hipLaunchKernelGGL(k_normalize_rows, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Y, ldy, Yn, ldn, N, D);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_rows_cosine(const float* A, int32_t ld, const float* q, float* out, int64_t N, int32_t D, hipStream_t s) {
+  hipLaunchKernelGGL(k_rows_cosine, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, A, ld, q, out, N, D);
   HIP_CHECK(hipGetLastError());
 }
 void launch_rows_dot(const float* Yn, int32_t ldn, const float* q, float* out, int64_t N, int32_t D, hipStream_t s) {

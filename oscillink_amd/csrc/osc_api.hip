@@ -119,6 +119,7 @@ struct osc_lattice {
   DevBuf<float> pw;
   // CG scratch
   int grid_cap = 1024;
+  DevBuf<float> vec_q, vec_n;  // query / per-row result scratch of the cosine calls
   int32_t dcols = 0;      // D rounded up to 4: the columns the kernels work on (ld >= dcols is the row pitch)
   int32_t spmm_slab = 0;  // 0 = whole window per launch
   int spmm_xs = -1;        // XCD-affine narrow slabs: -1 auto, 0 off, 1 on (OSC_SPMM_XS)
@@ -1658,27 +1659,47 @@ int osc_cg_single_rhs(osc_handle h, float gamma, const float* s, float tol, int3
   });
 }
 
+// cosine of every row of a resident N x ld array to one host query (rows and query normalised with the +1e-12 of the
+// reference); result in API row order
+static void rows_cosine_to(L& l, const float* rows, const float* psi, float* out) {
+  l.vec_q.alloc((size_t)l.D);
+  l.vec_n.alloc((size_t)l.N);
+  std::vector<float> qn((size_t)l.D);
+  float ss = 0.f;
+  for (int c = 0; c < l.D; ++c) ss += psi[c] * psi[c];
+  const float inv = 1.0f / (std::sqrt(ss) + 1e-12f);
+  for (int c = 0; c < l.D; ++c) qn[(size_t)c] = psi[c] * inv;
+  HIP_CHECK(hipMemcpyAsync(l.vec_q.p, qn.data(), (size_t)l.D * 4, hipMemcpyHostToDevice, l.stream));
+  launch_rows_cosine(rows, l.ld, l.vec_q.p, l.vec_n.p, l.N, l.D, l.stream);
+  HIP_CHECK(hipMemcpyAsync(out, l.vec_n.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+  sync(l);
+  to_api_order(l, out);
+}
+
 int osc_cosine_to(osc_handle h, const float* psi, float* out) {
   return guarded(h, [&](L& l) {
     if (!psi || !out) throw Invalid("osc_cosine_to: NULL buffer");
-    const int32_t ldn = l.ld;
-    DevBuf<float> Yn, q, o;
-    Yn.alloc((size_t)l.N * ldn);
-    q.alloc((size_t)l.D);
-    o.alloc((size_t)l.N);
-    double nn = 0.0;
-    std::vector<float> qn((size_t)l.D);
-    float ss = 0.f;
-    for (int c = 0; c < l.D; ++c) ss += psi[c] * psi[c];
-    (void)nn;
-    const float inv = 1.0f / (std::sqrt(ss) + 1e-12f);
-    for (int c = 0; c < l.D; ++c) qn[(size_t)c] = psi[c] * inv;
-    HIP_CHECK(hipMemcpyAsync(q.p, qn.data(), (size_t)l.D * 4, hipMemcpyHostToDevice, l.stream));
-    launch_normalize_rows(l.Y.p, l.ld, Yn.p, ldn, l.N, l.D, l.stream);
-    launch_rows_dot(Yn.p, ldn, q.p, o.p, l.N, l.D, l.stream);
-    HIP_CHECK(hipMemcpyAsync(out, o.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+    rows_cosine_to(l, l.Y.p, psi, out);
+  });
+}
+
+int osc_cosine_to_row(osc_handle h, int64_t row, float* out) {
+  return guarded(h, [&](L& l) {
+    if (!out) throw Invalid("osc_cosine_to_row: out is NULL");
+    if (row < 0 || row >= l.N) throw Invalid("osc_cosine_to_row: row out of range");
+    const int64_t dev_row = permuted(l) ? l.inv_h[(size_t)row] : row;
+    std::vector<float> q((size_t)l.D);
+    HIP_CHECK(hipMemcpyAsync(q.data(), l.Y.p + (size_t)dev_row * l.ld, (size_t)l.D * 4, hipMemcpyDeviceToHost, l.stream));
     sync(l);
-    to_api_order(l, out);
+    rows_cosine_to(l, l.Y.p, q.data(), out);
+  });
+}
+
+int osc_ustar_cosine_to(osc_handle h, const float* psi, float* out) {
+  return guarded(h, [&](L& l) {
+    if (!psi || !out) throw Invalid("osc_ustar_cosine_to: NULL buffer");
+    if (!l.have_ustar) throw StateError("osc_ustar_cosine_to: no resident U* (call osc_solve_ustar first)");
+    rows_cosine_to(l, l.Ustar.p, psi, out);
   });
 }
 

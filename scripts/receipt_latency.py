@@ -40,3 +40,7 @@ print("deltaH_ms", t(lambda: lat._call("osc_deltaH", C.byref(dH))))
 print("components_ms", t(lat._components))
 print("nulls_ms", t(lambda: lat._null_points(3.0)))
 print("signature_ms", t(lambda: (lat._touch(), lat._signature())))
+lat.add_chain(list(range(8)), lamP=0.2)
+lat.settle()
+print("chain_receipt_ms", t(lambda: lat.chain_receipt(list(range(8)))))
+print("bundle_ms (k=10)", t(lambda: lat.bundle(k=10)))
