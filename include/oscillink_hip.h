@@ -126,6 +126,9 @@ int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out
 int osc_has_ustar(osc_handle h, int32_t* yes);
 /* copy the resident U* (N x D) to the host; OSC_E_STATE if no solve happened since the last state change */
 int osc_get_ustar(osc_handle h, float* out);
+/* n selected rows (caller's row ids) of Y (which = 0), U (1) or the resident U* (2) into out (n x D): what
+ * chain_receipt (lattice.py:466-528) reads -- the chain nodes and their neighbours -- without moving N x D floats */
+int osc_get_rows(osc_handle h, int32_t which, const int32_t* rows, int32_t n, float* out);
 /* residual after every iteration of the last solve (solver.py:29), n <= cap entries written */
 int osc_residual_history(osc_handle h, float* out, int32_t cap, int32_t* n);
 

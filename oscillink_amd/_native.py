@@ -52,6 +52,7 @@ SIGNATURES = {
     "osc_solve_ustar": (C.c_int, [Handle, C.c_float, C.c_int32, c_f32p, c_i32p, c_f32p, c_f64p]),
     "osc_has_ustar": (C.c_int, [Handle, c_i32p]),
     "osc_get_ustar": (C.c_int, [Handle, c_f32p]),
+    "osc_get_rows": (C.c_int, [Handle, C.c_int32, c_i32p, C.c_int32, c_f32p]),
     "osc_residual_history": (C.c_int, [Handle, c_f32p, C.c_int32, c_i32p]),
     "osc_cg_single_rhs": (C.c_int, [Handle, C.c_float, c_f32p, C.c_float, C.c_int32, c_f32p, c_i32p, c_f32p]),
     "osc_cosine_to": (C.c_int, [Handle, c_f32p, c_f32p]),

@@ -1594,6 +1594,34 @@ int osc_get_ustar(osc_handle h, float* out) {
   });
 }
 
+int osc_get_rows(osc_handle h, int32_t which, const int32_t* rows, int32_t n, float* out) {
+  return guarded(h, [&](L& l) {
+    if (n < 0 || (n > 0 && (!rows || !out))) throw Invalid("osc_get_rows: bad arguments");
+    const float* src = which == 0 ? l.Y.p : which == 1 ? l.U.p : which == 2 ? l.Ustar.p : nullptr;
+    if (!src) throw Invalid("osc_get_rows: which must be 0 (Y), 1 (U) or 2 (U*)");
+    if (which == 2 && !l.have_ustar) throw StateError("osc_get_rows: no resident U* (call osc_solve_ustar first)");
+    if (which == 1 && l.u_sharded) {  // collective in column-sharded runs, like osc_get_U
+      gather_columns(l, l.U.p);
+      l.u_sharded = false;
+    }
+    if (n == 0) return;
+    std::vector<int32_t> dev_rows((size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+      if (rows[i] < 0 || rows[i] >= l.N) throw Invalid("osc_get_rows: row out of range");
+      dev_rows[(size_t)i] = permuted(l) ? l.inv_h[(size_t)rows[i]] : rows[i];
+    }
+    DevBuf<int32_t> idx;
+    DevBuf<float> tmp;
+    idx.alloc((size_t)n);
+    tmp.alloc((size_t)n * l.ld);
+    HIP_CHECK(hipMemcpyAsync(idx.p, dev_rows.data(), (size_t)n * 4, hipMemcpyHostToDevice, l.stream));
+    launch_move_rows(tmp.p, src, idx.p, n, l.ld, false, l.stream);  // tmp[i] = src[rows[i]]
+    HIP_CHECK(hipMemcpy2DAsync(out, (size_t)l.D * 4, tmp.p, (size_t)l.ld * 4, (size_t)l.D * 4, (size_t)n,
+                               hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+  });
+}
+
 int osc_residual_history(osc_handle h, float* out, int32_t cap, int32_t* n) {
   return guarded(h, [&](L& l) {
     const int32_t m = std::min<int32_t>(cap, (int32_t)l.history.size());

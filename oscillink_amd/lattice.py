@@ -586,12 +586,42 @@ class OscillinkLattice:
         return verify_receipt(self.receipt(), secret)
 
     # ------------------------------------------------------------------ chain receipt (lattice.py:466-528), sparse
+    def _fetch_rows(self, which: int, rows: np.ndarray) -> np.ndarray:
+        """Selected rows (caller's ids) of Y (0), U (1) or the resident U* (2) as an (n, D) array."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        out = np.empty((rows.size, self.D), dtype=np.float32)
+        self._call("osc_get_rows", int(which), nat.i32(rows), int(rows.size), nat.f32(out))
+        return out
+
     def chain_receipt(self, chain: list[int], z_th: float = 2.5) -> dict[str, Any]:
-        Ustar = self._host_ustar()
         rowptr, col, a, _, sd = self._host_csr()
         di = sd + 1e-12
         N = self.N
         lamC = float(self.lamC)
+        # only the chain nodes and their structural / path neighbours are read: fetch those rows of U* (and the chain's
+        # rows of Y) instead of mirroring the N x D arrays on the host
+        own_nodes = self._chain_nodes if self._chain_nodes is not None else [int(c) for c in chain]
+        need = {int(c) for c in chain if 0 <= int(c) < N} | {int(c) for c in own_nodes if 0 <= int(c) < N}
+        for c in [int(c) for c in chain if 0 <= int(c) < N]:
+            need.update(int(j) for j in col[rowptr[c]: rowptr[c + 1]])
+        need_ids = np.array(sorted(need), dtype=np.int64)
+        if self._Ustar_cache is not None and self._Ustar_sig == self._signature():
+            Ustar_rows = self._Ustar_cache[need_ids]
+        else:
+            self._ensure_device_ustar()
+            Ustar_rows = self._fetch_rows(2, need_ids)
+        slot = {int(r): t for t, r in enumerate(need_ids)}
+
+        class _Rows:  # Ustar[i] / Ustar[js] on the fetched subset
+            def __getitem__(_self, key):
+                if isinstance(key, (int, np.integer)):
+                    return Ustar_rows[slot[int(key)]]
+                return Ustar_rows[[slot[int(t)] for t in np.asarray(key).ravel()]]
+
+        Ustar = _Rows()
+        chain_ids = np.array(sorted({int(c) for c in chain if 0 <= int(c) < N}), dtype=np.int64)
+        Y_rows = self._Y_host[chain_ids] if self._Y_host is not None else self._fetch_rows(0, chain_ids)
+        yslot = {int(r): t for t, r in enumerate(chain_ids)}
 
         def un(i):
             return Ustar[i] / di[i]
@@ -648,7 +678,7 @@ class OscillinkLattice:
             if max(z_struct, z_path) > worst[1]:
                 worst = (k, max(z_struct, z_path), (i, j))
             w_ij = float(a[rowptr[i]: rowptr[i + 1]][sj == j][0]) if np.any(sj == j) else 0.0
-            ydiff = self.Y[i] / di[i] - self.Y[j] / di[j]
+            ydiff = Y_rows[yslot[i]] / di[i] - Y_rows[yslot[j]] / di[j]
             udiff = un(i) - un(j)
             gain += 0.5 * lamC * max(w_ij, 0.0) * (float(ydiff @ ydiff) - float(udiff @ udiff))
         verdict = all(max(float(e["z_struct"]), float(e["z_path"])) <= float(z_th) for e in edges)

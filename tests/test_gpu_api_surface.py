@@ -246,3 +246,43 @@ def test_small_lattice_latency_budget(amd):
         lat.settle(max_iters=6, tol=1e-3)
         lat.receipt()
     assert (time.perf_counter() - t0) / 10 < 0.05
+
+
+def test_chain_receipt_and_bundle_do_not_mirror_the_state_on_the_host(amd):
+    """Both calls read a handful of rows (chain nodes, their neighbours, the chosen bundle items): they must work from
+    the device-resident arrays (osc_get_rows / osc_ustar_cosine_to / osc_cosine_to_row) without creating the N x D host
+    mirrors of Y or U*, and give what the mirrored path gives."""
+    rng = np.random.default_rng(8)
+    N, D = 5000, 96
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    chain = [3, 17, 4021, 256, 9]
+
+    def run(mirror):
+        lat = amd.Oscillink(Y, kneighbors=10, deterministic_k=True)
+        lat.set_query(psi)
+        lat.add_chain(chain, lamP=0.25)
+        lat.settle(max_iters=12, tol=1e-4)
+        if mirror:
+            _ = lat.Y
+            _ = lat.solve_Ustar()
+        cr = lat.chain_receipt(chain)
+        bd = lat.bundle(k=6)
+        return lat, cr, bd
+
+    lean, cr0, bd0 = run(False)
+    assert lean._Y_host is None and lean._Ustar_cache is None
+    full, cr1, bd1 = run(True)
+    assert full._Y_host is not None and full._Ustar_cache is not None
+    assert cr0["verdict"] == cr1["verdict"] and cr0["weakest_link"]["edge"] == cr1["weakest_link"]["edge"]
+    assert cr0["coherence_gain"] == pytest.approx(cr1["coherence_gain"], rel=1e-5, abs=1e-6)
+    for e0, e1 in zip(cr0["edges"], cr1["edges"]):
+        assert e0["edge"] == e1["edge"]
+        for key in ("z_struct", "z_path", "r_struct", "r_path"):
+            assert e0[key] == pytest.approx(e1[key], rel=1e-5, abs=1e-6)
+    assert [b["id"] for b in bd0] == [b["id"] for b in bd1]
+    assert np.allclose([b["score"] for b in bd0], [b["score"] for b in bd1], rtol=1e-5, atol=1e-6)
+    rows = np.array([0, 4999, 17, 17, 2500], dtype=np.int32)
+    assert np.array_equal(lean._fetch_rows(0, rows), Y[rows])
+    with pytest.raises(ValueError):
+        lean._fetch_rows(0, np.array([N], dtype=np.int32))
