@@ -89,6 +89,10 @@ int osc_spmm_plan(osc_handle h, int32_t* launches, int32_t* slab_cols, int32_t* 
  * Any output pointer may be NULL. */
 int osc_get_csr(osc_handle h, int64_t* rowptr, int32_t* col, float* a, float* w, float* sqrt_deg);
 
+/* the first min(cap, nnz) stored edges as int64 (i, j) pairs in row-major order, columns ascending within a row:
+ * `argwhere(A > 0)[:cap]` of _signature() (lattice.py:729-744) without moving the whole graph to the host */
+int osc_edge_prefix(osc_handle h, int32_t cap, int64_t* pairs, int32_t* n);
+
 /* Inject a (symmetric, zero-diagonal, already capped) adjacency as CSR; recomputes sqrt_deg and W
  * exactly as normalized_laplacian (graph.py:86-93).  Mirrors from_state's `lat.A = A;
  * lat.L_sym, lat.sqrt_deg = normalized_laplacian(lat.A)` (lattice.py:709-713). */

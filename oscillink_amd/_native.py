@@ -39,6 +39,7 @@ SIGNATURES = {
     "osc_spmm_plan": (C.c_int, [Handle, c_i32p, c_i32p, c_i32p]),
     "osc_get_csr": (C.c_int, [Handle, c_i64p, c_i32p, c_f32p, c_f32p, c_f32p]),
     "osc_set_csr": (C.c_int, [Handle, c_i64p, c_i32p, c_f32p]),
+    "osc_edge_prefix": (C.c_int, [Handle, C.c_int32, c_i64p, c_i32p]),
     "osc_get_knn_lists": (C.c_int, [Handle, c_i32p, c_f32p, c_i32p]),
     "osc_set_query": (C.c_int, [Handle, c_f32p, c_f32p]),
     "osc_set_chain": (C.c_int, [Handle, c_i32p, c_f32p, C.c_int32, C.c_float]),

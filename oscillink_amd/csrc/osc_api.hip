@@ -1377,6 +1377,42 @@ int osc_get_csr(osc_handle h, int64_t* rowptr, int32_t* col, float* a, float* w,
   });
 }
 
+int osc_edge_prefix(osc_handle h, int32_t cap, int64_t* pairs, int32_t* n_out) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (cap < 0 || (cap > 0 && !pairs) || !n_out) throw Invalid("osc_edge_prefix: bad arguments");
+    int32_t n = 0;
+    std::vector<int32_t> hc, hd;
+    std::vector<int32_t> ent;
+    // rows are fetched in chunks until `cap` edges are collected (a few dozen rows at k = 32), not the whole graph
+    for (int64_t r0 = 0; r0 < l.N && n < cap;) {
+      const int64_t chunk = std::min<int64_t>(l.N - r0, permuted(l) ? 1 : 256);
+      const int64_t d0 = permuted(l) ? l.inv_h[(size_t)r0] : r0;  // device row (chunk == 1 when rows are permuted)
+      hc.resize((size_t)chunk * l.width);
+      hd.resize((size_t)chunk);
+      HIP_CHECK(hipMemcpyAsync(hc.data(), l.ell_col.p + (size_t)d0 * l.width, hc.size() * 4, hipMemcpyDeviceToHost, l.stream));
+      HIP_CHECK(hipMemcpyAsync(hd.data(), l.deg.p + d0, (size_t)chunk * 4, hipMemcpyDeviceToHost, l.stream));
+      sync(l);
+      for (int64_t t = 0; t < chunk && n < cap; ++t) {
+        ent.clear();
+        for (int e = 0; e < hd[(size_t)t]; ++e) {
+          const int32_t c = hc[(size_t)t * l.width + e];
+          ent.push_back(permuted(l) ? l.perm_h[(size_t)c] : c);
+        }
+        if (permuted(l)) std::sort(ent.begin(), ent.end());
+        for (int32_t c : ent) {
+          if (n >= cap) break;
+          pairs[2 * (size_t)n] = r0 + t;
+          pairs[2 * (size_t)n + 1] = c;
+          ++n;
+        }
+      }
+      r0 += chunk;
+    }
+    *n_out = n;
+  });
+}
+
 int osc_set_csr(osc_handle h, const int64_t* rowptr, const int32_t* col, const float* a) {
   return guarded(h, [&](L& l) {
     if (!rowptr || rowptr[0] != 0) throw Invalid("osc_set_csr: rowptr[0] must be 0");

@@ -762,6 +762,11 @@ class OscillinkLattice:
 
     # ------------------------------------------------------------------ signature / cache (lattice.py:729-758)
     def _edge_prefix(self, limit: int = 2048) -> np.ndarray:
+        if self._csr is None:  # a few rows of the device graph instead of the whole CSR
+            pairs = np.zeros((limit, 2), dtype=np.int64)
+            n = C.c_int32(0)
+            self._call("osc_edge_prefix", int(limit), nat.i64(pairs), C.byref(n))
+            return pairs[: n.value]
         rowptr, col, _, _, _ = self._host_csr()
         m = min(limit, col.shape[0])
         rows = np.searchsorted(rowptr, np.arange(m), side="right") - 1

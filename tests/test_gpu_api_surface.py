@@ -286,3 +286,24 @@ def test_chain_receipt_and_bundle_do_not_mirror_the_state_on_the_host(amd):
     assert np.array_equal(lean._fetch_rows(0, rows), Y[rows])
     with pytest.raises(ValueError):
         lean._fetch_rows(0, np.array([N], dtype=np.int32))
+
+
+@pytest.mark.parametrize("reorder", ["0", "1"])
+def test_signature_edge_prefix_matches_the_full_csr(amd, reorder, monkeypatch):
+    """_signature() hashes the first 2048 (i, j) pairs of argwhere(A > 0); osc_edge_prefix serves them from a few rows of
+    the device graph.  Same pairs as the full CSR export, also when the rows are stored in BFS order internally."""
+    monkeypatch.setenv("OSC_REORDER", reorder)
+    rng = np.random.default_rng(3)
+    centers = rng.standard_normal((40, 48)).astype(np.float32)
+    Y = (centers[rng.integers(0, 40, 9000)] + 0.05 * rng.standard_normal((9000, 48))).astype(np.float32)
+    lat = amd.Oscillink(Y, kneighbors=3, deterministic_k=True)
+    assert lat.build_info()["reordered"] == int(reorder)
+    assert lat._csr is None
+    lean = lat._edge_prefix()
+    sig_lean = lat._signature()
+    assert lat._csr is None  # still no host CSR
+    lat._host_csr()
+    full = lat._edge_prefix()
+    assert lean.dtype == np.int64 and np.array_equal(lean, full) and lean.shape == (2048, 2)
+    lat._sig_cache = None
+    assert lat._signature() == sig_lean
