@@ -22,28 +22,45 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 }
 #define HIP_CHECK(x) ::osc::hip_check((x), #x, __FILE__, __LINE__)
 
+// Device memory comes from a per-process caching allocator (osc_api.hip): hipMalloc / hipFree cost 0.1-1 ms each and
+// hipFree synchronises the device, which dominated the create + destroy time of small lattices (one lattice per request
+// in the reference's service).  Freed blocks are parked per device in size classes and handed out again; a block is
+// parked only after the freeing handle's stream has drained (alloc_ctx.stream), so no other handle can receive memory
+// that still has work in flight.  Contents are NOT zeroed -- exactly like hipMalloc.  OSC_POOL_MB caps the parked bytes
+// per device (default 16384, 0 = no caching).
+struct AllocCtx {
+  int device = 0;
+  hipStream_t stream = nullptr;  // the stream the calling handle enqueues on (nullptr: nothing can be in flight)
+};
+AllocCtx& alloc_ctx();  // thread-local, set by every API entry point
+void* pool_alloc(size_t bytes, size_t* cap_bytes);
+void pool_free(void* p, size_t cap_bytes);
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  size_t cap = 0;  // bytes of the underlying block (size class)
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) pool_free(p, cap);
     p = nullptr;
     n = 0;
+    cap = 0;
   }
   void alloc(size_t count) {
     if (count == n && p) return;
     release();
-    if (count) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    if (count) p = reinterpret_cast<T*>(pool_alloc(count * sizeof(T), &cap));
     n = count;
   }
   void swap(DevBuf& o) {
     std::swap(p, o.p);
     std::swap(n, o.n);
+    std::swap(cap, o.cap);
   }
 };
 

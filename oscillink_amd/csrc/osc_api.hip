@@ -74,7 +74,94 @@ double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// ---- caching device allocator (see common.hpp) ------------------------------------------------------------------
+struct DevPool {
+  std::multimap<size_t, void*> parked;  // size class -> block
+  size_t parked_bytes = 0;
+};
+std::mutex g_mem_mu;
+std::map<int, DevPool> g_mem_pool;
+size_t pool_limit_bytes() {
+  static const size_t lim = [] {
+    const char* e = getenv("OSC_POOL_MB");
+    const long long mb = e ? atoll(e) : 16384;
+    return (size_t)std::max<long long>(0, mb) << 20;
+  }();
+  return lim;
+}
+size_t size_class(size_t bytes) {  // <= 12.5 % over-allocation, so equal shapes and near-equal ones share blocks
+  if (bytes <= 4096) return 4096;
+  size_t p2 = (size_t)1 << (63 - __builtin_clzll((unsigned long long)bytes));
+  const size_t step = std::max<size_t>(p2 / 8, 4096);
+  return (bytes + step - 1) / step * step;
+}
+
+// CG control block: pinned residual mirror + per-iteration events (hipHostMalloc ~0.3 ms, 66 x hipEventCreate); parked
+// per device like the streams
+struct CtrlBlock {
+  float* res_host = nullptr;
+  size_t res_host_n = 0;
+  std::vector<hipEvent_t> events;
+};
+std::map<int, std::vector<CtrlBlock>> g_ctrl_pool;
+
 }  // namespace
+
+namespace osc {
+AllocCtx& alloc_ctx() {
+  static thread_local AllocCtx c;
+  return c;
+}
+void* pool_alloc(size_t bytes, size_t* cap_bytes) {
+  const size_t cls = size_class(bytes);
+  const int dev = alloc_ctx().device;
+  if (pool_limit_bytes() > 0) {
+    std::lock_guard<std::mutex> lk(g_mem_mu);
+    DevPool& dp = g_mem_pool[dev];
+    auto it = dp.parked.find(cls);
+    if (it != dp.parked.end()) {
+      void* p = it->second;
+      dp.parked.erase(it);
+      dp.parked_bytes -= cls;
+      *cap_bytes = cls;
+      return p;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, cls);
+  if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {  // give the parked blocks back and retry once
+    (void)hipGetLastError();
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> lk(g_mem_mu);
+      DevPool& dp = g_mem_pool[dev];
+      for (auto& kv : dp.parked) drop.push_back(kv.second);
+      dp.parked.clear();
+      dp.parked_bytes = 0;
+    }
+    for (void* q : drop) (void)hipFree(q);
+    e = hipMalloc(&p, cls);
+  }
+  hip_check(e, "hipMalloc", __FILE__, __LINE__);
+  *cap_bytes = cls;
+  return p;
+}
+void pool_free(void* p, size_t cap_bytes) {
+  if (!p) return;
+  const AllocCtx& c = alloc_ctx();
+  if (pool_limit_bytes() > 0 && cap_bytes > 0) {
+    if (c.stream) (void)hipStreamSynchronize(c.stream);  // nothing of this handle may still touch the block
+    std::lock_guard<std::mutex> lk(g_mem_mu);
+    DevPool& dp = g_mem_pool[c.device];
+    if (dp.parked_bytes + cap_bytes <= pool_limit_bytes()) {
+      dp.parked.emplace(cap_bytes, p);
+      dp.parked_bytes += cap_bytes;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+}  // namespace osc
 
 struct osc_lattice {
   int device = 0;
@@ -160,12 +247,30 @@ struct osc_lattice {
       (void)hipEventDestroy(s.b);
     }
     for (auto e : prof_pool) (void)hipEventDestroy(e);
-    for (auto e : iter_events) (void)hipEventDestroy(e);
-    if (res_host) (void)hipHostFree(res_host);
     if (comm) (void)ncclCommDestroy(comm);
+    park_ctrl();
     release_stream(device, stream);
   }
+  void park_ctrl();
 };
+
+void osc_lattice::park_ctrl() {
+  if (!res_host && iter_events.empty()) return;
+  CtrlBlock cb;
+  cb.res_host = res_host;
+  cb.res_host_n = res_host_n;
+  cb.events.swap(iter_events);
+  res_host = nullptr;
+  res_host_n = 0;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto& v = g_ctrl_pool[device];
+  if (v.size() < 64) {
+    v.push_back(std::move(cb));
+    return;
+  }
+  for (auto e : cb.events) (void)hipEventDestroy(e);
+  if (cb.res_host) (void)hipHostFree(cb.res_host);
+}
 
 namespace {
 
@@ -282,6 +387,16 @@ void ensure_cg_scratch(L& h, int max_iters) {
   // for re-allocating the residual slots, their pinned mirror and the per-iteration events
   const size_t slots = (size_t)std::max(max_iters, 64) + 2;
   if (h.res_bits.n < slots) h.res_bits.alloc(slots);
+  if (!h.res_host && h.iter_events.empty()) {  // a parked control block of a destroyed handle, if any
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto& v = g_ctrl_pool[h.device];
+    if (!v.empty()) {
+      h.res_host = v.back().res_host;
+      h.res_host_n = v.back().res_host_n;
+      h.iter_events.swap(v.back().events);
+      v.pop_back();
+    }
+  }
   if (h.res_host_n < slots) {
     if (h.res_host) (void)hipHostFree(h.res_host);
     h.res_host = nullptr;
@@ -1143,6 +1258,7 @@ int guarded(osc_handle h, F&& f) {
   if (!h) return OSC_E_INVALID;
   try {
     use_device(*h);
+    alloc_ctx() = AllocCtx{h->device, h->stream};
     f(*h);
     return OSC_OK;
   } catch (const Invalid& e) {
@@ -1211,13 +1327,23 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
   try {
     h->device = device;
     HIP_CHECK(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_CHECK(hipGetDeviceProperties(&prop, device));
-    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
-      g_create_error = std::string("osc_create: device is ") + prop.gcnArchName + ", this build targets gfx950 only";
-      return OSC_E_NODEVICE;
+    {
+      static std::mutex arch_mu;
+      static std::map<int, std::string> arch;  // hipGetDeviceProperties is slow: ask once per device
+      std::lock_guard<std::mutex> lk(arch_mu);
+      auto it = arch.find(device);
+      if (it == arch.end()) {
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        it = arch.emplace(device, std::string(prop.gcnArchName)).first;
+      }
+      if (it->second.find("gfx950") == std::string::npos) {
+        g_create_error = std::string("osc_create: device is ") + it->second + ", this build targets gfx950 only";
+        return OSC_E_NODEVICE;
+      }
     }
     h->stream = acquire_stream(device);
+    alloc_ctx() = AllocCtx{device, h->stream};
     h->N = N;
     h->D = D;
     h->dcols = ((D + 3) / 4) * 4;
@@ -1288,6 +1414,7 @@ int osc_destroy(osc_handle h) {
   if (!h) return OSC_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  alloc_ctx() = AllocCtx{h->device, nullptr};  // drained: the blocks go back to the pool without further waits
   delete h;
   return OSC_OK;
 }
