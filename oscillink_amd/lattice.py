@@ -781,7 +781,6 @@ class OscillinkLattice:
         adj_sig = hashlib.sha256(np.ascontiguousarray(self._edge_prefix()).tobytes()).hexdigest()
         data = {
             "psi": np.round(self._psi, 6).tolist(),
-            "B": np.round(self._B, 6).tolist(),
             "lam": [self.lamG, self.lamC, self.lamQ, self.lamP],
             "chain_present": self._chain_nodes is not None,
             "chain_len": len(self._chain_nodes) if self._chain_nodes else 0,
@@ -789,9 +788,22 @@ class OscillinkLattice:
             "detk": self._deterministic_k,
             "adj": adj_sig,
         }
-        sig = hashlib.sha256(json.dumps(data, sort_keys=True).encode("utf-8")).hexdigest()
+        sig = hashlib.sha256(self._signature_json(data, self._B).encode("utf-8")).hexdigest()
         self._sig_cache = (key, sig)
         return sig
+
+    @staticmethod
+    def _signature_json(rest: dict, B: np.ndarray) -> str:
+        """`json.dumps({**rest, "B": np.round(B, 6).tolist()}, sort_keys=True)` (lattice.py:729-744).  "B" sorts before
+        every other key (upper case), so its N numbers are spliced in front; ungated lattices (all gates 1.0, the common
+        case) skip the per-element float formatting, which is most of the cost at N = 100k."""
+        if B.size and bool(np.all(B == 1.0)):
+            b_json = "[" + ", ".join(["1.0"] * int(B.size)) + "]"
+        else:
+            b_json = json.dumps(np.round(B, 6).tolist())
+        tail = json.dumps(rest, sort_keys=True)
+        assert tail.startswith("{") and not any(k < "B" for k in rest)
+        return '{"B": ' + b_json + (", " + tail[1:] if len(rest) else "}")
 
     def _invalidate_cache(self) -> None:
         self._Ustar_cache = None

@@ -107,3 +107,19 @@ def test_column_shard_plan():
             assert a1 == b0 and a0 % 4 == 0 and a1 > a0
     with pytest.raises(ValueError):
         column_shard(8, 0, 3)
+
+
+def test_signature_json_fast_path_equals_json_dumps():
+    """The state signature hashes json.dumps(..., sort_keys=True) of a dict holding the N gates; the mirror splices the
+    gate list in (and skips float formatting for ungated lattices).  Byte-identical to the plain form."""
+    import json
+
+    from oscillink_amd.lattice import OscillinkLattice as L
+
+    rest = {"psi": [0.1, -0.25, 3e-06], "lam": [1.0, 0.5, 4.0, 0.2], "chain_present": True, "chain_len": 4, "k": 6,
+            "detk": False, "adj": "0f" * 32}
+    rng = np.random.default_rng(0)
+    for B in (np.ones(1000, dtype=np.float32), np.ones(1, dtype=np.float32), rng.uniform(0, 1, 257).astype(np.float32),
+              np.array([1.0, 0.0, 1.0], dtype=np.float32)):
+        plain = json.dumps({**rest, "B": np.round(B, 6).tolist()}, sort_keys=True)
+        assert L._signature_json(rest, B) == plain
