@@ -23,6 +23,7 @@
 // replace-worst step.  Expected hits per row are O(k log(N/k)), so the MFMA pipe stays the bound.
 #include "common.hpp"
 #include "knn.hpp"
+#include <mutex>
 
 namespace osc {
 namespace {
@@ -361,20 +362,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //     of the current one.
 //   * list update: one v_max3/v_max + compare per query-row register decides whether any of its 4 x 32 columns can
 //     enter the list before the four per-tile ballots are taken.
-constexpr int PF_STAGE = 2 * BM * BK;  // floats per stage: A tile + B tile, 128 x 32 slots each
+// Two shapes of the same body: <E, 4, 2> = 128 query rows, two stages, 64 KB, two workgroups per CU (default);
+// <E, 8, 3> = 256 query rows (half the B-tile traffic per MFMA), three stages (two K steps of DMA in flight across
+// each barrier, retired by a counted vmcnt), 144 KB, one workgroup per CU.
 
-template <int E>
-__global__ __launch_bounds__(256, 2) void k_knn_pref(const float* __restrict__ Yh, int32_t ldn, int32_t N, int32_t k,
-                                                     int32_t S, int32_t cols_per_split, float* cand_val,
-                                                     int32_t* cand_idx, int32_t rb_begin, int32_t rb_count) {
-  __shared__ __attribute__((aligned(1024))) float lds[2 * PF_STAGE];
+template <int E, int NW, int NST>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_knn_pref(const float* __restrict__ Yh, int32_t ldn,
+                                                                       int32_t N, int32_t k, int32_t S,
+                                                                       int32_t cols_per_split, float* cand_val,
+                                                                       int32_t* cand_idx, int32_t rb_begin,
+                                                                       int32_t rb_count) {
+  constexpr int BMX = 32 * NW;                 // query rows per workgroup
+  constexpr int PF_STAGE = (BMX + BN) * BK;    // floats per stage: A tile (BMX rows) + B tile (128 rows), 32 slots each
+  constexpr int RB = NW / 4;                   // 128-row blocks of the plan per workgroup
+  extern __shared__ __attribute__((aligned(1024))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;  // XCD-aware item order (see knn_topk_body)
-  const int rloc = (jx / S) * 8 + xcd, split = jx % S;
+  const int rloc = ((jx / S) * 8 + xcd) * RB, split = jx % S;
   const int rblk = rb_begin + rloc;
   if (rloc >= rb_count || rblk * BM >= N) return;
   const int row0 = rblk * BM;
+  const int row_limit = min(N, (rb_begin + rb_count) * BM);  // rows past the plan's range belong to another pass
   const int cbeg = split * cols_per_split;
   const int cend = min(N, cbeg + cols_per_split);
   const int nkt = ldn / BK;
@@ -402,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_pref(const float* __restrict__ Y
   const float* a_src[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) a_src[q] = Yh + (size_t)min(row0 + 32 * wave + 8 * q + frow, N - 1) * ldn + fchunk;
+  constexpr int BQ = 16 / NW;  // 8-row pieces of the B tile per wave (4 waves: 4, 8 waves: 2)
 
   // The DMA is issued from inline asm: through the builtin the compiler orders every later ds_read behind it with
   // s_waitcnt vmcnt(0) (it cannot see that the reads go to the other stage), which would expose the whole load latency
@@ -416,23 +426,33 @@ __global__ __launch_bounds__(256, 2) void k_knn_pref(const float* __restrict__ Y
   };
   auto issue = [&](int stage, int ct, int kt) {  // one K step of tile `ct` into LDS stage `stage`
     const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * PF_STAGE + 32 * wave * BK) * 4u);
-    const unsigned b_dst = a_dst + (unsigned)(BM * BK) * 4u;
+    const unsigned b_dst =
+        __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * PF_STAGE + BMX * BK + 8 * BQ * wave * BK) * 4u);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float* bsrc = Yh + (size_t)min(ct + 32 * wave + 8 * q + frow, N - 1) * ldn + fchunk + kt * BK;
-      glds16(a_src[q] + kt * BK, a_dst + (unsigned)(8 * q * BK) * 4u);
+    for (int q = 0; q < 4; ++q) glds16(a_src[q] + kt * BK, a_dst + (unsigned)(8 * q * BK) * 4u);
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+      const float* bsrc = Yh + (size_t)min(ct + 8 * BQ * wave + 8 * q + frow, N - 1) * ldn + fchunk + kt * BK;
       glds16(bsrc, b_dst + (unsigned)(8 * q * BK) * 4u);
     }
   };
-  auto dma_wait_and_barrier = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  constexpr int DMA_PER_STEP = 4 + BQ;  // LDS-DMA instructions one wave issues per K step
+  // retire the DMA of the step that is read next; with three stages the step after that stays in flight across the
+  // barrier (counted vmcnt: the wave's youngest DMA_PER_STEP operations) unless nothing was issued behind it
+  auto dma_wait_and_barrier = [&](bool keep_one_step) {
+    if (NST == 3 && keep_one_step) {
+      if constexpr (DMA_PER_STEP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
   };
 
   const int wrow_base = row0 + 32 * wave;
   auto grow_at = [&](int g) -> int {
     const int pos = wrow_base + (g & 3) + 8 * (g >> 2) + 4 * h;
-    return pos < N ? pos : -1;
+    return pos < row_limit ? pos : -1;
   };
   const int swz = l31 & 7;  // (row & 7) of every fragment row this lane reads (tile bases are multiples of 8)
 
@@ -443,23 +463,31 @@ __global__ __launch_bounds__(256, 2) void k_knn_pref(const float* __restrict__ Y
     for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
 
   int ct = cbeg, kt = 0;       // the step being computed
-  issue(0, ct, 0);
-  dma_wait_and_barrier();
   const int total = ntile * nkt;
-  for (int step = 0; step < total; ++step) {
-    const int stage = step & 1;
-    {  // prefetch the next step into the other stage (its readers finished before the barrier that ended step-1)
-      int nct = ct, nkt2 = kt + 1;
-      if (nkt2 == nkt) {
-        nkt2 = 0;
-        nct = ct + BN;
-      }
-#ifndef OSC_PF_NODMA  // experiment switches (wrong results): no DMA after the first step / no fragment reads / no list update
-      if (step + 1 < total) issue(stage ^ 1, nct, nkt2);
-#endif
+  // (ict, ikt) = the next step to issue; the pipeline runs NST - 1 steps ahead of the compute
+  int ict = cbeg, ikt = 0, issued = 0;
+  auto issue_next = [&]() {
+    issue(issued % NST, ict, ikt);
+    ++issued;
+    if (++ikt == nkt) {
+      ikt = 0;
+      ict += BN;
     }
+  };
+  for (int pre = 0; pre < NST - 1 && issued < total; ++pre) issue_next();
+  dma_wait_and_barrier(issued > 1);
+  for (int step = 0; step < total; ++step) {
+    const int stage = step % NST;
+    // prefetch into the stage whose readers finished before the barrier that ended step-1
+    bool issued_now = false;
+#ifndef OSC_PF_NODMA  // experiment switches (wrong results): no DMA after the prologue / no fragment reads / no list update
+    if (issued < total) {
+      issue_next();
+      issued_now = true;
+    }
+#endif
     const float* Asw = lds + stage * PF_STAGE + (32 * wave + l31) * BK;
-    const float* Bsw = lds + stage * PF_STAGE + BM * BK + l31 * BK;
+    const float* Bsw = lds + stage * PF_STAGE + BMX * BK + l31 * BK;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int co = (((2 * s + h) ^ swz)) * 4;
@@ -531,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_pref(const float* __restrict__ Y
     } else {
       ++kt;
     }
-    dma_wait_and_barrier();  // next stage landed and every wave is done reading this one
+    dma_wait_and_barrier(issued_now);  // next stage landed and every wave is done reading this one
   }
 
   constexpr int KC = 32 * E;
@@ -815,16 +843,32 @@ void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, 
 #define OSC_KNN_PREF_ARGS Yop, ld, N, p.keep, p.S, p.cols_per_split, cand_val, cand_idx, p.rb_begin, p.rb_count
   if (p.f16) {
     if (p.qrows) throw std::runtime_error("the prefilter kernel has no row-list variant");
+    if (p.E > 3) throw std::runtime_error("f16 prefilter supports at most 96 kept candidates");
 #ifdef OSC_KNN_PREF_OLD  // register-staged prefilter (kept for A/B runs)
     if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
     else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
     else if (p.E == 3) hipLaunchKernelGGL((k_knn_topk<3, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
 #else
-    if (p.E == 1) hipLaunchKernelGGL((k_knn_pref<1>), grid, block, 0, s, OSC_KNN_PREF_ARGS);
-    else if (p.E == 2) hipLaunchKernelGGL((k_knn_pref<2>), grid, block, 0, s, OSC_KNN_PREF_ARGS);
-    else if (p.E == 3) hipLaunchKernelGGL((k_knn_pref<3>), grid, block, 0, s, OSC_KNN_PREF_ARGS);
+    static const bool wide = [] { const char* e = getenv("OSC_KNN_PREF_WG"); return e && atoi(e) == 8; }();
+    if (!wide) {
+      constexpr size_t lds = (size_t)2 * (128 + 128) * BK * 4;
+      if (p.E == 1) hipLaunchKernelGGL((k_knn_pref<1, 4, 2>), grid, block, lds, s, OSC_KNN_PREF_ARGS);
+      else if (p.E == 2) hipLaunchKernelGGL((k_knn_pref<2, 4, 2>), grid, block, lds, s, OSC_KNN_PREF_ARGS);
+      else if (p.E == 3) hipLaunchKernelGGL((k_knn_pref<3, 4, 2>), grid, block, lds, s, OSC_KNN_PREF_ARGS);
+    } else {  // 256-row workgroups, three stages
+      constexpr size_t lds = (size_t)3 * (256 + 128) * BK * 4;
+      const dim3 grid8((unsigned)(8 * ((((p.rb_count + 1) / 2) + 7) / 8) * p.S)), block8(512);
+      static std::once_flag once;
+      std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_pref<1, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_pref<2, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_pref<3, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      });
+      if (p.E == 1) hipLaunchKernelGGL((k_knn_pref<1, 8, 3>), grid8, block8, lds, s, OSC_KNN_PREF_ARGS);
+      else if (p.E == 2) hipLaunchKernelGGL((k_knn_pref<2, 8, 3>), grid8, block8, lds, s, OSC_KNN_PREF_ARGS);
+      else if (p.E == 3) hipLaunchKernelGGL((k_knn_pref<3, 8, 3>), grid8, block8, lds, s, OSC_KNN_PREF_ARGS);
+    }
 #endif
-    else throw std::runtime_error("f16 prefilter supports at most 96 kept candidates");
   } else if (p.qrows) {
     if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, false, true>), grid, block, 0, s, OSC_KNN_ARGS);
     else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, false, true>), grid, block, 0, s, OSC_KNN_ARGS);
