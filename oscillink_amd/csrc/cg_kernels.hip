@@ -433,9 +433,13 @@ __global__ __launch_bounds__(1024) void k_reduce_alpha(const float* part, int nb
     alpha[col] = (float)(rz[col] / (t[0] + 1e-18));  // solver.py:25-26
 }
 
+// host_slot != nullptr: the last workgroup to finish publishes the iteration's residual straight into host-mapped
+// memory (the host polls that word instead of paying a 4-byte copy + event + event wait per iteration); done_ctr is
+// this iteration's arrival counter (zeroed with the residual slots).
 __global__ __launch_bounds__(1024) void k_reduce_beta(const float* part_rr, const float* part_rz, int nb, int32_t ld,
                                                       int32_t c0, int32_t c1, double* rz, float* beta,
-                                                      uint32_t* res_bits, Gate gt) {
+                                                      uint32_t* res_bits, Gate gt, uint32_t* done_ctr,
+                                                      float* host_slot) {
   if (gt.p != nullptr && *gt.p <= gt.tol) return;
   double t[2];
   int col;
@@ -449,7 +453,17 @@ __global__ __launch_bounds__(1024) void k_reduce_beta(const float* part_rr, cons
   if ((threadIdx.x >> 6) == 0) {  // wave 0 holds the 64 column residuals of this block
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) resc = fmaxf(resc, __shfl_xor(resc, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(res_bits, __float_as_uint(resc));  // non-negative floats order as uints
+    if ((threadIdx.x & 63) == 0) {
+      atomicMax(res_bits, __float_as_uint(resc));  // non-negative floats order as uints
+      if (host_slot != nullptr) {
+        __threadfence();
+        if (atomicAdd(done_ctr, 1u) == gridDim.x - 1) {      // every workgroup's maximum is in
+          const uint32_t bits = atomicMax(res_bits, 0u);     // read it back through the same (coherent) path
+          *reinterpret_cast<volatile uint32_t*>(host_slot) = bits;
+          __threadfence_system();
+        }
+      }
+    }
   }
 }
 
@@ -584,9 +598,10 @@ void launch_reduce_alpha(const float* part, int nb, int32_t ld, int32_t c0, int3
   HIP_CHECK(hipGetLastError());
 }
 void launch_reduce_beta(const float* part_rr, const float* part_rz, int nb, int32_t ld, int32_t c0, int32_t c1,
-                        double* rz, float* beta, uint32_t* res_bits_slot, Gate g, hipStream_t s) {
+                        double* rz, float* beta, uint32_t* res_bits_slot, Gate g, hipStream_t s, uint32_t* done_ctr,
+                        float* host_slot) {
   hipLaunchKernelGGL(k_reduce_beta, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part_rr, part_rz, nb, ld, c0, c1, rz,
-                     beta, res_bits_slot, g);
+                     beta, res_bits_slot, g, done_ctr, host_slot);
   HIP_CHECK(hipGetLastError());
 }
 void launch_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols, hipStream_t s) {

@@ -159,7 +159,8 @@ void launch_reduce_init(const float* part, int nb, int32_t ld, int32_t c0, int32
 void launch_reduce_alpha(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, const double* rz,
                          float* alpha, Gate g, hipStream_t s);
 void launch_reduce_beta(const float* part_rr, const float* part_rz, int nb, int32_t ld, int32_t c0, int32_t c1,
-                        double* rz, float* beta, uint32_t* res_bits_slot, Gate g, hipStream_t s);
+                        double* rz, float* beta, uint32_t* res_bits_slot, Gate g, hipStream_t s,
+                        uint32_t* done_ctr = nullptr, float* host_slot = nullptr);
 void launch_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols,
                        hipStream_t s);
 void launch_axpby(float* out, const float* a, float ca, const float* b, float cb, int64_t n, hipStream_t s);

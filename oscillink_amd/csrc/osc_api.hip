@@ -220,8 +220,10 @@ struct osc_lattice {
   DevBuf<float> ell_w_t;
   bool ell_t_ready = false;
   int64_t small_solves = 0;
-  float* res_host = nullptr;  // pinned mirror of res_bits for the per-iteration read-back
+  float* res_host = nullptr;  // pinned, host-mapped mirror of res_bits for the per-iteration read-back
+  float* res_host_dev = nullptr;  // the device's address of it
   size_t res_host_n = 0;
+  bool mapped_residual = true;  // OSC_MAPPED_RES=0: copy + event per iteration instead
   std::vector<hipEvent_t> iter_events;
   std::vector<float> history;
   // column shard (multi-GPU, column-sharded CG); single GPU: [0, ld)
@@ -375,18 +377,10 @@ void download_api_order(L& h, float* dst, const float* src) {
   sync(h);
 }
 
-void ensure_cg_scratch(L& h, int max_iters) {
-  const size_t pn = (size_t)h.grid_cap * h.ld;
-  h.part0.alloc(pn);
-  h.part1.alloc(pn);
-  h.alpha.alloc(h.ld);
-  h.beta.alloc(h.ld);
-  h.rz.alloc(h.ld);
-  h.colsum.alloc(h.ld);
-  // sized for solve_Ustar's default 64 iterations from the start: a settle(12) followed by a U* solve must not pay
-  // for re-allocating the residual slots, their pinned mirror and the per-iteration events
-  const size_t slots = (size_t)std::max(max_iters, 64) + 2;
-  if (h.res_bits.n < slots) h.res_bits.alloc(slots);
+// residual slots + arrival counters on the device, their host-mapped mirror (the device publishes each iteration's
+// residual into it; also the read-back buffer of the one-launch path) and the per-iteration events
+void ensure_ctrl(L& h, size_t slots) {
+  if (h.res_bits.n < 2 * slots) h.res_bits.alloc(2 * slots);  // [residual bits | arrival counters]
   if (!h.res_host && h.iter_events.empty()) {  // a parked control block of a destroyed handle, if any
     std::lock_guard<std::mutex> lk(g_pool_mu);
     auto& v = g_ctrl_pool[h.device];
@@ -400,14 +394,28 @@ void ensure_cg_scratch(L& h, int max_iters) {
   if (h.res_host_n < slots) {
     if (h.res_host) (void)hipHostFree(h.res_host);
     h.res_host = nullptr;
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h.res_host), slots * 4, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h.res_host), slots * 4, hipHostMallocMapped));
     h.res_host_n = slots;
   }
+  HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h.res_host_dev), h.res_host, 0));
   while (h.iter_events.size() < slots) {
     hipEvent_t e;
     HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     h.iter_events.push_back(e);
   }
+}
+
+void ensure_cg_scratch(L& h, int max_iters) {
+  const size_t pn = (size_t)h.grid_cap * h.ld;
+  h.part0.alloc(pn);
+  h.part1.alloc(pn);
+  h.alpha.alloc(h.ld);
+  h.beta.alloc(h.ld);
+  h.rz.alloc(h.ld);
+  h.colsum.alloc(h.ld);
+  // sized for solve_Ustar's default 64 iterations from the start: a settle(12) followed by a U* solve must not pay
+  // for re-allocating the residual slots, their pinned mirror and the per-iteration events
+  ensure_ctrl(h, (size_t)std::max(max_iters, 64) + 2);
 }
 
 // one grid for every CG kernel of a handle, so all column partial buffers have the same number of rows
@@ -892,12 +900,7 @@ bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, 
   const size_t nslots = (size_t)max_iters + 2;
   const size_t nctl = 2 * nslots + 2;  // [residual slots | arrival counters | status]: one memset, one read-back
   if (h.arrive.n < nctl) h.arrive.alloc(nctl);
-  if (h.res_host_n < nctl) {
-    if (h.res_host) (void)hipHostFree(h.res_host);
-    h.res_host = nullptr;
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h.res_host), nctl * 4, hipHostMallocDefault));
-    h.res_host_n = nctl;
-  }
+  ensure_ctrl(h, nctl);
   HIP_CHECK(hipMemsetAsync(h.arrive.p, 0, nctl * 4, h.stream));
   SmallArgs a{};
   if (!h.ell_t_ready) {
@@ -954,18 +957,18 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     if (run_cg_small(h, op, b, with_path, max_iters, tol, small)) return small;
   }
   const int grid = cg_grid(h);
-  HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, ((size_t)max_iters + 2) * 4, h.stream));
-  if (h.res_host_n < (size_t)max_iters + 2) {
-    if (h.res_host) (void)hipHostFree(h.res_host);
-    h.res_host = nullptr;
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h.res_host), ((size_t)max_iters + 2) * 4, hipHostMallocDefault));
-    h.res_host_n = (size_t)max_iters + 2;
-  }
-  while (h.iter_events.size() < (size_t)max_iters + 2) {
-    hipEvent_t e;
-    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    h.iter_events.push_back(e);
-  }
+  const size_t nslots = (size_t)max_iters + 2;
+  ensure_ctrl(h, nslots);
+  uint32_t* done_ctr = h.res_bits.p + h.res_bits.n / 2;  // second half of the control array
+  HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, nslots * 4, h.stream));
+  HIP_CHECK(hipMemsetAsync(done_ctr, 0, nslots * 4, h.stream));
+  // Single GPU: the last workgroup of each iteration's beta reduction writes the residual into host-mapped memory and
+  // the host polls that word (no 4-byte copy, event record and event wait per iteration).  Under a communicator the
+  // residual first goes through the all-reduce, so the copy + event path stays.
+  const bool mapped = h.comm == nullptr && h.mapped_residual;
+  constexpr uint32_t kPending = 0xFFFFFFFFu;  // never a residual (those are sqrt(...) >= 0 or a canonical NaN)
+  if (mapped)
+    for (size_t i = 0; i < nslots; ++i) reinterpret_cast<volatile uint32_t*>(h.res_host)[i] = kPending;
   const float* res_dev = reinterpret_cast<const float*>(h.res_bits.p);
   SpmmArgs sa{};
   sa.g = graph_view(h, with_path);
@@ -1029,6 +1032,11 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       ProfScope ps(h, 1, it);
       for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });
     }
+    if (mapped) {
+      launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream,
+                         done_ctr + it, h.res_host_dev + it);
+      return;
+    }
     launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream);
     if (h.comm) {  // column-sharded: the stop test is the max over all shards (solver.py:29)
       if (ncclAllReduce(h.res_bits.p + it, h.res_bits.p + it, 1, ncclFloat, ncclMax, h.comm, h.stream) != ncclSuccess)
@@ -1037,6 +1045,29 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     HIP_CHECK(hipMemcpyAsync(h.res_host + it, h.res_bits.p + it, 4, hipMemcpyDeviceToHost, h.stream));
     HIP_CHECK(hipEventRecord(h.iter_events[(size_t)it], h.stream));
   };
+  auto wait_residual = [&](int it) -> float {
+    if (!mapped) {
+      HIP_CHECK(hipEventSynchronize(h.iter_events[(size_t)it]));
+      return h.res_host[it];
+    }
+    volatile uint32_t* slot = reinterpret_cast<volatile uint32_t*>(h.res_host) + it;
+    const double t_start = now_ms();
+    for (uint64_t spin = 1;; ++spin) {
+      const uint32_t bits = *slot;
+      if (bits != kPending) {
+        float v;
+        std::memcpy(&v, &bits, 4);
+        return v;
+      }
+      if ((spin & 0x3FFF) == 0) {  // every ~16k polls: has the stream died or drained without publishing?
+        const hipError_t q = hipStreamQuery(h.stream);
+        if (q != hipSuccess && q != hipErrorNotReady) hip_check(q, "hipStreamQuery (CG residual wait)", __FILE__, __LINE__);
+        if (q == hipSuccess && *slot == kPending) throw HipError("CG iteration finished without publishing its residual");
+        if (now_ms() - t_start > 120000.0) throw HipError("timeout waiting for a CG residual");
+      }
+      __builtin_ia32_pause();
+    }
+  };
 
   h.history.clear();
   CgResult out{max_iters, 0.f};
@@ -1044,8 +1075,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   enqueue_iter(1);
   for (int it = 1; it <= max_iters; ++it) {
     if (it < max_iters) enqueue_iter(it + 1);  // speculative: no-ops if iteration `it` converged
-    HIP_CHECK(hipEventSynchronize(h.iter_events[(size_t)it]));
-    const float res = h.res_host[it];
+    const float res = wait_residual(it);
     h.history.push_back(res);
     out.res = res;
     if ((double)res <= (double)tol) {
@@ -1053,7 +1083,10 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       break;
     }
   }
-  sync(h);
+  // The solution is complete once the last residual is out; what may still be queued are the gated-off launches of
+  // the speculative iteration (they return at once and write nothing).  With the mapped read-back the stream is left
+  // to drain on its own -- later calls are ordered behind it anyway; the copy + event path keeps its full wait.
+  if (!mapped || h.prof_on) sync(h);
   for (size_t i = prof_mark; i < h.prof_pending.size(); ++i)  // speculative (gated-off) launches are not samples
     if (h.prof_pending[i].iter > out.iters) h.prof_pending[i].which = -1;
   return out;
@@ -1373,6 +1406,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_SPMM_XS")) h->spmm_xs = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_XS_NB")) h->xs_nb = std::max(1, atoi(e));
     if (const char* e = getenv("OSC_P_BLOCKED")) h->p_blocked = atoi(e) != 0;
+    if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
     if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_SHARD")) h->shard_mode = !strcmp(e, "row") ? 1 : 0;
