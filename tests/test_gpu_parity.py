@@ -878,3 +878,25 @@ def test_column_windows_of_a_sharded_solve_match_the_full_solve(amd, world, forc
         if force_xs == "1":
             assert part.build_info()["apply_xs_workgroups"] > 0
     monkeypatch.delenv("OSC_FAKE_COL_SHARD")
+
+
+@pytest.mark.parametrize("name,ld", [("c2_n1200_d128_k16", "160"), ("gates_chain_n333_d50_k7", "64"),
+                                     ("gates_chain_n333_d50_k7", "96"), ("g1_n400_d64_k6_chain8", "100")])
+@pytest.mark.parametrize("small", ["0", "1"])
+def test_padded_row_pitch_is_invisible(amd, name, ld, small, monkeypatch):
+    """Large lattices get a 128-byte-aligned row pitch (ld > D); OSC_LD forces such a pitch onto the fixtures so every
+    kernel, the strided host transfers and the row fetches run with ld != D.  Same answers, same iteration counts."""
+    monkeypatch.setenv("OSC_LD", ld)
+    monkeypatch.setenv("OSC_SMALL_PATH", small)
+    case = load_case(name)
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"])
+    assert np.array_equal(lat.Y, Y) and np.array_equal(lat.U, Y)
+    rows = np.array([0, Y.shape[0] - 1, 7], dtype=np.int32)
+    assert np.array_equal(lat._fetch_rows(1, rows), Y[rows])
+    _configure(lat, case, rc, psi)
+    _check_solves(lat, case, rc, tol_u=TOL)
+    if rc["chain"]:
+        lat.chain_receipt(list(rc["chain"]))
+    assert len(lat.bundle(k=5)) == 5
