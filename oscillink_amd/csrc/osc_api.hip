@@ -212,6 +212,7 @@ struct osc_lattice {
   int spmm_xs = -1;        // XCD-affine narrow slabs: -1 auto, 0 off, 1 on (OSC_SPMM_XS)
   bool p_blocked = true;   // slab-major search direction in xs mode (OSC_P_BLOCKED=0 keeps it row-major)
   int xs_nb = 0;           // workgroups per XCD in that mode; 0 = automatic (OSC_XS_NB)
+  int xs_groups_cap = 8;   // upper bound on the slab groups (= slabs in flight) of that mode (OSC_XS_GROUPS)
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
   DevBuf<uint32_t> res_bits, arrive;  // arrive: per-iteration barrier counters (+1 status word) of the one-launch path
@@ -820,11 +821,25 @@ int32_t auto_slab(const L& h, int32_t ncols) {
 // XCD then keeps 4 MB / (N x 128 B) of ITS slab in L2 (31 % at N = 100k) instead of 4 MB / (N x 512 B) of a slab all
 // eight share.  With fewer than 8 slabs (or a count that is not a multiple of 8) the XCDs pair up: gcd(8, slabs) slab
 // groups, the XCDs of a group split the rows.  Needs 128-byte-aligned rows and the slabs in flight (groups x N x 128 B)
-// inside the Infinity Cache: measured 1.11 vs 1.26 ms per apply at N = 100k, D = 768; no gain at N = 200k, D = 1536
-// (205 MB in flight); 36 % slower at N = 1M, D = 384.
-int xs_groups(int32_t ncols) {
+// inside the Infinity Cache: measured 1.11 vs 1.26 ms per apply at N = 100k, D = 768; no gain at N = 200k, D = 1536 with
+// 8 slabs (205 MB) in flight, 4 % with 4 (xs_groups_for); 36 % slower at N = 1M, D = 384.
+int xs_groups(int32_t ncols, int cap = 8) {
   const int nsl = (ncols + 31) / 32;
-  return (nsl % 8 == 0) ? 8 : (nsl % 4 == 0) ? 4 : (nsl % 2 == 0) ? 2 : 1;
+  const int g = (nsl % 8 == 0) ? 8 : (nsl % 4 == 0) ? 4 : (nsl % 2 == 0) ? 2 : 1;
+  return std::min(g, cap);
+}
+// slab groups (= slabs in flight) of the XCD-affine apply: the natural count gcd(8, slabs), halved until the slabs in
+// flight fit 128 MiB of the Infinity Cache; 0 = the mode does not pay (measured: shrinking below 4 groups loses to the
+// general path -- config 5's shape 56.4 ms general, 54.2 at 4 groups, 57.1 at 2, 60.7 at 1; config 4's shape loses at
+// every count).
+int xs_groups_for(const L& h, int32_t ncols) {
+  const int natural = xs_groups(ncols, h.xs_groups_cap);
+  int g = natural;
+  const double cap_bytes = 128.0 * 1024 * 1024;
+  while (g > 1 && (double)g * (double)h.N * 128.0 > cap_bytes) g >>= 1;
+  if ((double)g * (double)h.N * 128.0 > cap_bytes) return 0;
+  if (g != natural && g < 4) return 0;
+  return g;
 }
 int xs_plan(const L& h, int32_t ncols, int grid) {
   if (grid < 8 || (grid & 7) != 0) return 0;
@@ -833,7 +848,7 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   if (h.spmm_xs == 1) return nb;
   if (h.spmm_slab != 0 || h.reordered || (h.ld & 31) != 0 || (h.c0 & 31) != 0) return 0;
   if (h.N < 32768 || ncols < 96) return 0;
-  if ((double)xs_groups(ncols) * (double)h.N * 128.0 > 128.0 * 1024 * 1024) return 0;
+  if (xs_groups_for(h, ncols) == 0) return 0;
   return nb;
 }
 
@@ -844,7 +859,8 @@ void spmm_slabbed(L& h, int mode, SpmmArgs sa, int grid, int iter = 0) {
     // workgroups per XCD: 3 per CU when the operand is row-major (2: 1.37, 4: 1.15 ms vs 1.11), 4 per CU when it is
     // slab-major (3: 1.09, 4: 1.05 ms)
     sa.xs = (h.xs_nb <= 0 && sa.xblk != 0) ? std::min(grid / 8, 128) : nb;
-    sa.xs_groups = xs_groups(c1 - c0);
+    const int xg = xs_groups_for(h, c1 - c0);
+    sa.xs_groups = xg > 0 ? xg : xs_groups(c1 - c0, h.xs_groups_cap);  // forced mode: natural count
     launch_spmm(mode, sa, grid, h.stream);
     return;
   }
@@ -1405,6 +1421,10 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_GRID_CAP")) h->grid_cap = std::max(1, atoi(e));
     if (const char* e = getenv("OSC_SPMM_XS")) h->spmm_xs = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_XS_NB")) h->xs_nb = std::max(1, atoi(e));
+    if (const char* e = getenv("OSC_XS_GROUPS")) {
+      const int g = atoi(e);
+      h->xs_groups_cap = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;
+    }
     if (const char* e = getenv("OSC_P_BLOCKED")) h->p_blocked = atoi(e) != 0;
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
