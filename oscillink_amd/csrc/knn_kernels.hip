@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // staging pipeline:
 //   * operand tiles (128 rows x 128 B = one 64-half K step) go global -> LDS by global_load_lds_dwordx4 (no staging
 //     registers, no ds_write pass).  The LDS image is lane-linear per wave-instruction (8 rows x 128 B), so the bank
-//     swizzle sits on the SOURCE address: 16-byte chunk c of row r is stored at chunk position c ^ (r & 7), and the
-//     fragment reads apply the same xor (conflict-free ds_read_b128 without padding).
+//     swizzle sits on the SOURCE address: 16-byte chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7), and
+//     the fragment reads apply the same xor (conflict-free for ds_read_b128's 16-lane groups, no padding).
 //   * two LDS stages (64 KB per workgroup, two workgroups per CU), ONE barrier per K step; the (column tile, K step)
 //     loop is flat, so the first K step of the next column tile is in flight during the last MFMAs and the list update
 //     of the current one.
@@ -406,11 +406,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_knn_pref(const flo
 
   // LDS-DMA roles: wave w fills rows [32 w, 32 w + 32) of both tiles, 8 rows (1 KiB) per instruction.  Lane L of an
   // instruction lands at row L >> 3, chunk position L & 7, and therefore fetches source chunk (L & 7) ^ (row & 7).
-  const int frow = lane >> 3;                       // row inside the 8-row piece (= row & 7: pieces start at multiples of 8)
-  const int fchunk = ((lane & 7) ^ frow) * 4;       // source offset in floats
+  // Bank swizzle.  ds_read_b128 is served in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) over a
+  // 256-byte bank row (MI355X_MICROARCH.md, LDS): with 128-byte tile rows the 16-byte slot of (row, chunk position p) is
+  // (row & 1) * 8 + p, so the eight even and the eight odd rows of a group must get eight different positions for one
+  // source chunk.  p = chunk ^ ((row >> 1) & 7) does that for both groups (row >> 1 mod 8 runs over 0..7 on the even
+  // rows and on the odd rows of each); the former chunk ^ (row & 7) was 2-way conflicted (SQ_LDS_BANK_CONFLICT = half
+  // of SQ_LDS_IDX_ACTIVE).
+  const int frow = lane >> 3;                       // row inside the 8-row piece (pieces start at multiples of 8)
+  // piece q of a wave starts at tile row 8 q (mod 16): (row >> 1) & 7 = ((q & 1) << 2) | (frow >> 1)
+  auto fchunk_of = [&](int q) -> int { return ((lane & 7) ^ (((q & 1) << 2) | (frow >> 1))) * 4; };  // source offset in floats
   const float* a_src[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) a_src[q] = Yh + (size_t)min(row0 + 32 * wave + 8 * q + frow, N - 1) * ldn + fchunk;
+  for (int q = 0; q < 4; ++q) a_src[q] = Yh + (size_t)min(row0 + 32 * wave + 8 * q + frow, N - 1) * ldn + fchunk_of(q);
   constexpr int BQ = 16 / NW;  // 8-row pieces of the B tile per wave (4 waves: 4, 8 waves: 2)
 
   // The DMA is issued from inline asm: through the builtin the compiler orders every later ds_read behind it with
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_knn_pref(const flo
     for (int q = 0; q < 4; ++q) glds16(a_src[q] + kt * BK, a_dst + (unsigned)(8 * q * BK) * 4u);
 #pragma unroll
     for (int q = 0; q < BQ; ++q) {
-      const float* bsrc = Yh + (size_t)min(ct + 8 * BQ * wave + 8 * q + frow, N - 1) * ldn + fchunk + kt * BK;
+      const float* bsrc = Yh + (size_t)min(ct + 8 * BQ * wave + 8 * q + frow, N - 1) * ldn + fchunk_of(q) + kt * BK;
       glds16(bsrc, b_dst + (unsigned)(8 * q * BK) * 4u);
     }
   };
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_knn_pref(const flo
     const int pos = wrow_base + (g & 3) + 8 * (g >> 2) + 4 * h;
     return pos < row_limit ? pos : -1;
   };
-  const int swz = l31 & 7;  // (row & 7) of every fragment row this lane reads (tile bases are multiples of 8)
+  const int swz = (l31 >> 1) & 7;  // ((row >> 1) & 7) of every fragment row this lane reads (tile bases are multiples of 32)
 
   f32x16 acc[4];
 #pragma unroll
