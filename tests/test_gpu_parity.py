@@ -446,8 +446,9 @@ def test_mid_size_against_sparse_oracle(amd, orc):
     assert lat.receipt()["deltaH_total"] == pytest.approx(ref.deltaH(Us), rel=TOL)
 
 
-def test_full_config3_properties(amd, orc):
+def test_full_config3_properties(amd, orc, monkeypatch):
     """BASELINE config 3 at full size (N=100k, D=768, k=32): size-independent properties + sampled-row parity."""
+    monkeypatch.delenv("OSC_KNN_MODE", raising=False)  # the default build path is part of what is asserted
     rng = np.random.default_rng(0)
     N, D, k = 100_000, 768, 32
     Y = rng.standard_normal((N, D)).astype(np.float32)
