@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
         } else if (MODE == SPMM_DOT) {
           dot[ch] = mulacc4(xs[ch], o, dot[ch]);
         } else {  // INIT: r = b - A x0 ; z = r / (Md + eps) ; p = z ; rz = sum r.z   (solver.py:19-22)
-          const float4 u = ld4_stream(a.U + off), y = ld4_stream(a.Y + off);
+          // warm-started settle: the rhs term U is the gathered operand itself (x0 = U), already in xs
+          const float4 u = (a.U == a.X) ? xs[ch] : ld4_stream(a.U + off), y = ld4_stream(a.Y + off);
           const float qb = a.op.rbB * Bi;
           float4 r, z;
           r.x = (a.op.rbU * u.x + a.op.rbY * y.x + qb * psi4[ch].x) - o.x;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
           r.z = (a.op.rbU * u.z + a.op.rbY * y.z + qb * psi4[ch].z) - o.z;
           r.w = (a.op.rbU * u.w + a.op.rbY * y.w + qb * psi4[ch].w) - o.w;
           z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
-          st4_stream(a.OUT + off, xs[ch]);
+          if (a.OUT != a.X) st4_stream(a.OUT + off, xs[ch]);  // in-place solve (x0 is the work array): nothing to copy
           st4_stream(a.R + off, r);
           st4(a.P + (LPR == 8 && a.pblk != 0 ? blk_off(a.pblk, row, coff[ch]) : off), z);
           dot[ch] = mulacc4(r, z, dot[ch]);

@@ -1762,10 +1762,13 @@ int osc_settle(osc_handle h, float dt, int32_t max_iters, float tol, int32_t pre
         x0 = l.AP.p;  // AP is free until the first operator apply overwrites it (INIT gathers x0 before that)
       }
     }
-    CgBuffers b{x0, l.X.p, l.R.p, l.P.p, l.AP.p, l.U.p, l.Y.p, l.B.p, l.psi.p, l.ld, l.c0, l.c1};
+    // Warm start from U itself (the default): the CG runs in place on U -- the old state is only read by the INIT pass
+    // (as x0 and as the rhs term), which then has no x0 copy to write, and there is nothing to swap afterwards.
+    const bool in_place = x0 == l.U.p && !row_mode(l);
+    CgBuffers b{x0, in_place ? l.U.p : l.X.p, l.R.p, l.P.p, l.AP.p, l.U.p, l.Y.p, l.B.p, l.psi.p, l.ld, l.c0, l.c1};
     // when x0 aliases AP the INIT pass reads it completely before the first SPMM_AP launch writes AP: same stream
     const CgResult r = run_cg(l, op, b, path_active(l), max_iters, tol);
-    l.U.swap(l.X);  // U <- U+ (lattice.py:206)
+    if (!in_place) l.U.swap(l.X);  // U <- U+ (lattice.py:206)
     if (l.comm && l.world > 1 && l.shard_mode == 0) {
       // the swapped-in buffer only holds this rank's columns; the others are refreshed lazily by osc_get_U.
       l.u_sharded = true;
