@@ -19,89 +19,124 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifndef SCHED
+#define SCHED 1
+#endif
 constexpr int D = 768, NKT = D / 64, NK16 = D / 16;
 
+// Lean variant: every address of the K-step loop is (register set up once per tile) + (compile-time immediate).
+//   ring of 4 stages, 12 K steps per tile: the stage of step kt is kt % 4 and the stage filled during it (kt + 3) % 4,
+//   both compile-time in the unrolled loop; B piece sources = per-tile row bases + kt * 128 B immediate offsets;
+//   fragment reads = four per-lane bases (one per k16 slice, the swizzle is an xor) + immediate (stage, column subtile).
+//   Rows are padded to a multiple of 128 by the host: no clamps.
 template <int NSTG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_core(const _Float16* __restrict__ Yh, int N, float* __restrict__ rowmax, unsigned* queue) {
-  extern __shared__ __attribute__((aligned(1024))) float lds[];  // NSTG stages x [128 rows][32 float slots]
+  static_assert(NSTG == 4, "template value kept from the first version; the ring has 6 stages");
+  extern __shared__ __attribute__((aligned(1024))) float lds[];  // 4 stages x [128 rows][32 float slots]
   __shared__ int s_rb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int nblocks = (N + 127) / 128, ntile = (N + 127) / 128;
-  const unsigned lds_base = (unsigned)(size_t)lds;
+  const int nblocks = (N + 127) / 128, ntile = nblocks;
   const int frow = lane >> 3;
-  auto fchunk_of = [&](int q) -> int { return ((lane & 7) ^ (((q & 1) << 2) | (frow >> 1))) * 8; };  // halfs
-  auto glds16 = [&](const _Float16* src, unsigned dst_bytes) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst_bytes) : "memory");
-  };
   const int swz = (l31 >> 1) & 7;
+  // LDS byte offsets
+  // NB: the immediate offset of global_load_lds is added to the LDS destination as well as to the global address, so
+  // m0 carries (destination - offset); the ring starts 2 KB into the dynamic region to keep that positive.
+  const unsigned lds_base = (unsigned)(size_t)lds + 2048u;
+  const unsigned fill_base = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(32 * wave * 128));  // + stage * 16384 + q * 1024
+  unsigned rd[4];  // fragment read base of slice s: row l31, chunk (2 s + h) ^ swz   (+ stage * 16384 + t * 4096)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) rd[s] = (unsigned)(l31 * 128 + (((2 * s + h) ^ swz) * 16));
+  const char* ldsc = reinterpret_cast<const char*>(lds) + 2048;
   for (;;) {
     if (tid == 0) s_rb = (int)atomicAdd(queue, 1u);
     __syncthreads();
     const int rb = s_rb;
     __syncthreads();
     if (rb >= nblocks) break;
-    const int row = min(rb * 128 + 32 * wave + l31, N - 1);
+    const int row = rb * 128 + 32 * wave + l31;
     half8 areg[NK16];
 #pragma unroll
     for (int i = 0; i < NK16; ++i) areg[i] = *(const half8*)(Yh + (size_t)row * D + i * 16 + h * 8);
     float cmax[16];
 #pragma unroll
     for (int g = 0; g < 16; ++g) cmax[g] = -3.0e38f;
-
-    // B ring: step = (tile, kt); the wave fills rows [32 wave, 32 wave + 32) of a stage, 8 rows per piece
-    const int total = ntile * NKT;
-    int ict = 0, ikt = 0, issued = 0;
-    auto issue_next = [&]() {
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((issued % NSTG) * 128 * 32 + 32 * wave * 32) * 4u);
+    // source of piece q of this wave's share of a B tile: row 32 wave + 8 q + frow of the tile, swizzled chunk
+    const _Float16* bsrc[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const _Float16* src = Yh + (size_t)min(ict * 128 + 32 * wave + 8 * q + frow, N - 1) * D + fchunk_of(q) + ikt * 64;
-        glds16(src, dst + (unsigned)(8 * q * 32) * 4u);
-      }
-      ++issued;
-      if (++ikt == NKT) { ikt = 0; ++ict; }
+    for (int q = 0; q < 4; ++q)
+      bsrc[q] = Yh + (size_t)(32 * wave + 8 * q + frow) * D + ((lane & 7) ^ (((q & 1) << 2) | (frow >> 1))) * 8;
+    const size_t tile_stride = (size_t)128 * D;  // halfs between column tiles
+    auto piece = [&](const _Float16* src, int kt, int stage, int q) {
+      // m0 = LDS destination; the K offset rides in the instruction's immediate
+      asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%3"
+                   :: "v"(src), "s"(fill_base), "n"(0), "n"(0) : "memory");
+      (void)kt; (void)stage; (void)q;
     };
-    for (int pre = 0; pre < NSTG - 1 && issued < total; ++pre) issue_next();
+    (void)piece;
+#define PIECE(SRC, KT, STAGE, Q)                                                                                   \
+    do {                                                                                                           \
+      unsigned keep_;                                                                                              \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep_)                                                                                 \
+                   : "v"(SRC), "s"(fill_base + (unsigned)((STAGE) * 16384 + (Q) * 1024) - (unsigned)((KT) * 128)), "n"((KT) * 128) \
+                   : "memory");                                                                                    \
+    } while (0)
+    // ring of 6 stages, K steps handled in pairs (one barrier per 32 MFMAs): pair pr of a tile reads stages
+    // (2 pr) % 6 and (2 pr + 1) % 6 and fetches pair pr + 2 (of this tile or the next) two pairs ahead
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { PIECE(bsrc[q], st, st, q); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int step = 0;
     for (int ct = 0; ct < ntile; ++ct) {
+      const bool last_tile = ct + 1 == ntile;
       f32x16 acc[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+      const _Float16* nsrc[4];
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt, ++step) {
-        const bool more = issued < total;
-        if (more) issue_next();
-        const float* Bsw = lds + (step % NSTG) * 128 * 32 + l31 * 32;
+      for (int q = 0; q < 4; ++q) nsrc[q] = bsrc[q] + tile_stride;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int co = ((2 * s + h) ^ swz) * 4;
-          v4f bv[4];
+      for (int pr = 0; pr < NKT / 2; ++pr) {
+        const bool next_tile = 2 * pr + 4 >= NKT;
+        const bool fetch = !(next_tile && last_tile);
+        v4f fa[4], fb[4];
+        auto read_frags = [&](int st, int sl, v4f (&bv)[4]) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) bv[t] = *(const v4f*)(Bsw + 32 * t * 32 + co);
+          for (int t = 0; t < 4; ++t) bv[t] = *(const v4f*)(ldsc + rd[sl] + st * 16384 + t * 4096);
+        };
+        read_frags((2 * pr) % 6, 0, fa);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // eight k16 slices: two K steps
+          const int kt = 2 * pr + (u >> 2), sl = u & 3;
+          v4f(&cur)[4] = (u & 1) ? fb : fa;
+          v4f(&nxt)[4] = (u & 1) ? fa : fb;
+          if (u + 1 < 8) read_frags((2 * pr + ((u + 1) >> 2)) % 6, (u + 1) & 3, nxt);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[kt * 4 + s], __builtin_bit_cast(half8, bv[t]), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[kt * 4 + sl], __builtin_bit_cast(half8, cur[t]), acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (u < 4 && fetch) {  // two DMA pieces behind each of the first four MFMA groups
+            const int fk = (2 * pr + 4 + (u >> 1)) % NKT, fst = (2 * pr + 4 + (u >> 1)) % 6;
+#pragma unroll
+            for (int q = 2 * (u & 1); q < 2 * (u & 1) + 2; ++q) {
+              if (next_tile) { PIECE(nsrc[q], fk, fst, q); } else { PIECE(bsrc[q], fk, fst, q); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-        // the stage read next (step + 1) was issued NSTG - 2 steps before this step's own issue: all but the youngest
-        // (NSTG - 2) * 4 pieces must have landed
-        if (more) {
-          if constexpr (NSTG == 8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-          else if constexpr (NSTG == 6) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-          else if constexpr (NSTG == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (fetch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the pair fetched during this pair stays in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bsrc[q] = nsrc[q];
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         float m = fmaxf(fmaxf(acc[0][g], acc[1][g]), fmaxf(acc[2][g], acc[3][g]));
@@ -126,7 +161,8 @@ int main(int argc, char** argv) {
   const int grid = argc > 3 ? atoi(argv[3]) : 256;
   std::mt19937 rng(1);
   std::normal_distribution<float> nd(0.f, 1.f);
-  std::vector<_Float16> Y((size_t)N * D);
+  const int Npad = (N + 127) / 128 * 128;
+  std::vector<_Float16> Y((size_t)Npad * D, (_Float16)0.f);
   std::vector<float> rowf(D);
   for (int i = 0; i < N; ++i) {
     double n2 = 0;
@@ -140,10 +176,10 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&]() {
     CK(hipMemsetAsync(dq, 0, 4, 0));
-    const size_t sh = (size_t)nstg * 128 * 32 * 4;
+    const size_t sh = (size_t)6 * 128 * 32 * 4 + 2048;
 #define L(S) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_core<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
                hipLaunchKernelGGL((k_core<S>), dim3(grid), dim3(256), sh, 0, dY, N, dmax, dq); }
-    if (nstg == 8) L(8) else if (nstg == 6) L(6) else if (nstg == 4) L(4) else L(2)
+    L(4)
     CK(hipGetLastError());
   };
   launch();
