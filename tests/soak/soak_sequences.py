@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Extended run of the randomised operation-sequence parity test (tests/test_gpu_parity.py) over many seeds; prints
-the failing seeds.  Not part of the test suite (the suite runs seeds 0-3); used to look for rare divergences."""
+the failing seeds.  Not collected by pytest (the suite runs seeds 0-3); run by hand on a GPU box to look for rare divergences:
+    python tests/soak/soak_sequences.py 4 60"""
 import os
 import sys
 import traceback
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import oscillink_amd as amd  # noqa: E402
 from oracle import oscillink_oracle as orc  # noqa: E402
