@@ -19,20 +19,46 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// NCH = float4 chunks per lane that cover a row (ld <= 256 NCH): the row's own scaled Y / U* values stay in registers for
+// all its edges, and EU edges are gathered together (independent accumulators and reductions), so the loop is no
+// longer one exposed gather latency per edge.  Arithmetic per edge is unchanged (same products, same fma order per
+// lane, same butterfly), hence bit-identical results.  NCH = 0: generic loop for wider rows.
+template <int NCH>
 __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
+  constexpr int EU = 2;  // edges in flight
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.N) return;
   const size_t ro = (size_t)row * a.ld;
   const float inv_i = 1.0f / (a.sqrt_deg[row] + 1e-12f);
-  // anchor / query terms
+  // anchor / query terms; the row's own values are kept for the edge loop
   float an = 0.f, qu = 0.f;
-  for (int c = lane * 4; c < a.ld; c += 256) {  // pitch ld is a multiple of 4; pad columns are zero everywhere
-    const float4 us = ld4(a.Ustar + ro + c), y = ld4(a.Y + ro + c), ps = ld4(a.psi + c);
-    const float d0 = us.x - y.x, d1 = us.y - y.y, d2 = us.z - y.z, d3 = us.w - y.w;
-    const float q0 = us.x - ps.x, q1 = us.y - ps.y, q2 = us.z - ps.z, q3 = us.w - ps.w;
-    an = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, an))));
-    qu = fmaf(q0, q0, fmaf(q1, q1, fmaf(q2, q2, fmaf(q3, q3, qu))));
+  float4 yi_r[NCH > 0 ? NCH : 1], ui_r[NCH > 0 ? NCH : 1];
+  if constexpr (NCH > 0) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = lane * 4 + ch * 256;
+      float4 us = make_float4(0.f, 0.f, 0.f, 0.f), y = us, ps = us;
+      if (c < a.ld) {
+        us = ld4(a.Ustar + ro + c);
+        y = ld4(a.Y + ro + c);
+        ps = ld4(a.psi + c);
+        const float d0 = us.x - y.x, d1 = us.y - y.y, d2 = us.z - y.z, d3 = us.w - y.w;
+        const float q0 = us.x - ps.x, q1 = us.y - ps.y, q2 = us.z - ps.z, q3 = us.w - ps.w;
+        an = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, an))));
+        qu = fmaf(q0, q0, fmaf(q1, q1, fmaf(q2, q2, fmaf(q3, q3, qu))));
+      }
+      yi_r[ch] = y;
+      ui_r[ch] = us;
+    }
+  } else {
+    for (int c = lane * 4; c < a.ld; c += 256) {  // pitch ld is a multiple of 4; pad columns are zero everywhere
+      const float4 us = ld4(a.Ustar + ro + c), y = ld4(a.Y + ro + c), ps = ld4(a.psi + c);
+      const float d0 = us.x - y.x, d1 = us.y - y.y, d2 = us.z - y.z, d3 = us.w - y.w;
+      const float q0 = us.x - ps.x, q1 = us.y - ps.y, q2 = us.z - ps.z, q3 = us.w - ps.w;
+      an = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, an))));
+      qu = fmaf(q0, q0, fmaf(q1, q1, fmaf(q2, q2, fmaf(q3, q3, qu))));
+    }
   }
   an = wave_sum(an);
   qu = wave_sum(qu);
@@ -42,24 +68,39 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
   double s1 = 0.0, s2 = 0.0;
   float rmax = 0.f;
   int jmax = -1;
-  for (int e = 0; e < deg; ++e) {
-    const int j = a.col[(size_t)row * a.width + e];
-    const float w = a.adj[(size_t)row * a.width + e];
+  auto edge_terms = [&](int j, float inv_j, float& dy, float& du) {  // per-lane partial sums of one edge
     const size_t jo = (size_t)j * a.ld;
-    const float inv_j = 1.0f / (a.sqrt_deg[j] + 1e-12f);
-    float dy = 0.f, du = 0.f;
-    for (int c = lane * 4; c < a.ld; c += 256) {
-      const float4 yi = ld4(a.Y + ro + c), yj = ld4(a.Y + jo + c);
-      const float4 ui = ld4(a.Ustar + ro + c), uj = ld4(a.Ustar + jo + c);
-      const float y0 = yi.x * inv_i - yj.x * inv_j, y1 = yi.y * inv_i - yj.y * inv_j;
-      const float y2 = yi.z * inv_i - yj.z * inv_j, y3 = yi.w * inv_i - yj.w * inv_j;
-      const float u0 = ui.x * inv_i - uj.x * inv_j, u1 = ui.y * inv_i - uj.y * inv_j;
-      const float u2 = ui.z * inv_i - uj.z * inv_j, u3 = ui.w * inv_i - uj.w * inv_j;
-      dy = fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, fmaf(y3, y3, dy))));
-      du = fmaf(u0, u0, fmaf(u1, u1, fmaf(u2, u2, fmaf(u3, u3, du))));
+    dy = 0.f;
+    du = 0.f;
+    if constexpr (NCH > 0) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c = lane * 4 + ch * 256;
+        if (c < a.ld) {
+          const float4 yi = yi_r[ch], ui = ui_r[ch];
+          const float4 yj = ld4(a.Y + jo + c), uj = ld4(a.Ustar + jo + c);
+          const float y0 = yi.x * inv_i - yj.x * inv_j, y1 = yi.y * inv_i - yj.y * inv_j;
+          const float y2 = yi.z * inv_i - yj.z * inv_j, y3 = yi.w * inv_i - yj.w * inv_j;
+          const float u0 = ui.x * inv_i - uj.x * inv_j, u1 = ui.y * inv_i - uj.y * inv_j;
+          const float u2 = ui.z * inv_i - uj.z * inv_j, u3 = ui.w * inv_i - uj.w * inv_j;
+          dy = fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, fmaf(y3, y3, dy))));
+          du = fmaf(u0, u0, fmaf(u1, u1, fmaf(u2, u2, fmaf(u3, u3, du))));
+        }
+      }
+    } else {
+      for (int c = lane * 4; c < a.ld; c += 256) {
+        const float4 yi = ld4(a.Y + ro + c), yj = ld4(a.Y + jo + c);
+        const float4 ui = ld4(a.Ustar + ro + c), uj = ld4(a.Ustar + jo + c);
+        const float y0 = yi.x * inv_i - yj.x * inv_j, y1 = yi.y * inv_i - yj.y * inv_j;
+        const float y2 = yi.z * inv_i - yj.z * inv_j, y3 = yi.w * inv_i - yj.w * inv_j;
+        const float u0 = ui.x * inv_i - uj.x * inv_j, u1 = ui.y * inv_i - uj.y * inv_j;
+        const float u2 = ui.z * inv_i - uj.z * inv_j, u3 = ui.w * inv_i - uj.w * inv_j;
+        dy = fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, fmaf(y3, y3, dy))));
+        du = fmaf(u0, u0, fmaf(u1, u1, fmaf(u2, u2, fmaf(u3, u3, du))));
+      }
     }
-    dy = wave_sum(dy);
-    du = wave_sum(du);
+  };
+  auto edge_finish = [&](int j, float w, float dy, float du) {  // in edge order: the reference's column order
     if (w > 0.f) {
       coh += 0.5f * a.lamC * w * (dy - du);
       const float R = a.lamC * w * du;
@@ -73,6 +114,39 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
         jmax = j;
       }
     }
+  };
+  const int32_t* crow = a.col + (size_t)row * a.width;
+  const float* arow = a.adj + (size_t)row * a.width;
+  int e = 0;
+  for (; e + EU <= deg; e += EU) {
+    int jj[EU];
+    float ww[EU], ij[EU], dy[EU], du[EU];
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      jj[u] = crow[e + u];
+      ww[u] = arow[e + u];
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) ij[u] = 1.0f / (a.sqrt_deg[jj[u]] + 1e-12f);
+#pragma unroll
+    for (int u = 0; u < EU; ++u) edge_terms(jj[u], ij[u], dy[u], du[u]);
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      dy[u] = wave_sum(dy[u]);
+      du[u] = wave_sum(du[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) edge_finish(jj[u], ww[u], dy[u], du[u]);
+  }
+  for (; e < deg; ++e) {
+    const int j = crow[e];
+    const float w = arow[e];
+    const float inv_j = 1.0f / (a.sqrt_deg[j] + 1e-12f);
+    float dy, du;
+    edge_terms(j, inv_j, dy, du);
+    dy = wave_sum(dy);
+    du = wave_sum(du);
+    edge_finish(j, w, dy, du);
   }
   if (lane == 0) {
     if (a.coh) a.coh[row] = coh;
@@ -94,7 +168,14 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
 }  // namespace
 
 void launch_receipt_rows(const ReceiptArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_receipt_rows, dim3((unsigned)((a.N + 3) / 4)), dim3(256), 0, s, a);
+  const dim3 grid((unsigned)((a.N + 3) / 4)), block(256);
+  const int nch = (a.ld + 255) / 256;
+  if (nch <= 1) hipLaunchKernelGGL(k_receipt_rows<1>, grid, block, 0, s, a);
+  else if (nch == 2) hipLaunchKernelGGL(k_receipt_rows<2>, grid, block, 0, s, a);
+  else if (nch == 3) hipLaunchKernelGGL(k_receipt_rows<3>, grid, block, 0, s, a);
+  else if (nch == 4) hipLaunchKernelGGL(k_receipt_rows<4>, grid, block, 0, s, a);
+  else if (nch <= 6) hipLaunchKernelGGL(k_receipt_rows<6>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(k_receipt_rows<0>, grid, block, 0, s, a);
   HIP_CHECK(hipGetLastError());
 }
 
