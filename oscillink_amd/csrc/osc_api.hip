@@ -1875,7 +1875,12 @@ int osc_cg_single_rhs(osc_handle h, float gamma, const float* s, float tol, int3
       for (int64_t i = 0; i < l.N; ++i) sp[(size_t)i] = s[l.perm_h[(size_t)i]];
       s = sp.data();
     }
-    HIP_CHECK(hipMemcpy2DAsync(S.p, ld1 * 4, s, 4, 4, (size_t)l.N, hipMemcpyHostToDevice, l.stream));
+    // host <-> device contiguous through a scratch vector, re-pitched on the device: a strided copy of N 4-byte rows
+    // from/to pageable memory costs more than the whole solve
+    DevBuf<float> flat;
+    flat.alloc((size_t)l.N);
+    HIP_CHECK(hipMemcpyAsync(flat.p, s, (size_t)l.N * 4, hipMemcpyHostToDevice, l.stream));
+    HIP_CHECK(hipMemcpy2DAsync(S.p, ld1 * 4, flat.p, 4, 4, (size_t)l.N, hipMemcpyDeviceToDevice, l.stream));
     OpParams op{};
     op.cs_const = 1.0f + gamma;  // (L_sym + gamma I) x = (1 + gamma) x - W x
     op.cs_B = 0.f;
@@ -1899,7 +1904,8 @@ int osc_cg_single_rhs(osc_handle h, float gamma, const float* s, float tol, int3
       throw;
     }
     l.comm = saved;
-    HIP_CHECK(hipMemcpy2DAsync(h_out, 4, X.p, ld1 * 4, 4, (size_t)l.N, hipMemcpyDeviceToHost, l.stream));
+    HIP_CHECK(hipMemcpy2DAsync(flat.p, 4, X.p, ld1 * 4, 4, (size_t)l.N, hipMemcpyDeviceToDevice, l.stream));
+    HIP_CHECK(hipMemcpyAsync(h_out, flat.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     sync(l);
     to_api_order(l, h_out);
     if (iters) *iters = r.iters;
