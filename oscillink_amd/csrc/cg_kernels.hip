@@ -265,8 +265,10 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
         } else if (MODE == SPMM_DOT) {
           dot[ch] = mulacc4(xs[ch], o, dot[ch]);
         } else {  // INIT: r = b - A x0 ; z = r / (Md + eps) ; p = z ; rz = sum r.z   (solver.py:19-22)
-          // warm-started settle: the rhs term U is the gathered operand itself (x0 = U), already in xs
-          const float4 u = (a.U == a.X) ? xs[ch] : ld4_stream(a.U + off), y = ld4_stream(a.Y + off);
+          // warm-started settle: the rhs term U is the gathered operand itself (x0 = U), already in xs; the stationary
+          // solve has no U term at all (rbU = 0) and starts from Y, which is then the gathered operand
+          const float4 u = (a.U == a.X) ? xs[ch] : (a.op.rbU != 0.f ? ld4_stream(a.U + off) : f4(0.f));
+          const float4 y = (a.Y == a.X) ? xs[ch] : ld4_stream(a.Y + off);
           const float qb = a.op.rbB * Bi;
           float4 r, z;
           r.x = (a.op.rbU * u.x + a.op.rbY * y.x + qb * psi4[ch].x) - o.x;
