@@ -77,7 +77,13 @@ __global__ __launch_bounds__(256) void k_rows_cosine(const float* A, int32_t ld,
   if (row >= N) return;
   const float* y = A + row * ld;
   float s = 0.f, n2 = 0.f;
-  for (int c = lane; c < D; c += 64) {
+  const int d4 = D & ~3;  // 16 bytes per lane over the aligned part (ld is a multiple of 4), scalar tail
+  for (int c = lane * 4; c < d4; c += 256) {
+    const float4 v = ld4(y + c), w = ld4(q + c);
+    s = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, s))));
+    n2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, n2))));
+  }
+  for (int c = d4 + lane; c < D; c += 64) {
     const float v = y[c];
     s = fmaf(v, q[c], s);
     n2 = fmaf(v, v, n2);
