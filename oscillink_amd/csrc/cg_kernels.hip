@@ -519,6 +519,7 @@ struct Shape {
 // on 8 / 4 / 2 GPUs: <8,3>, <16,3>, <32,3>) were measured and are no faster than the padded ones below (the apply is
 // bound by the gathered bytes, not by idle lanes), so they are not instantiated.
 inline Shape pick_shape(int ncols) {
+  if (ncols <= 16) return {4, 1};  // single right-hand sides (diffusion gates: pitch 4) and very narrow lattices
   if (ncols <= 64) return {16, 1};
   if (ncols <= 128) return {32, 1};
   int nch = (ncols + 255) / 256;
@@ -530,7 +531,8 @@ inline Shape pick_shape(int ncols) {
 
 #define OSC_SHAPE_SWITCH(sh, CALL)                                   \
   do {                                                               \
-    if ((sh).lpr == 16) { CALL(16, 1); }                             \
+    if ((sh).lpr == 4) { CALL(4, 1); }                               \
+    else if ((sh).lpr == 16) { CALL(16, 1); }                        \
     else if ((sh).lpr == 32) { CALL(32, 1); }                        \
     else switch ((sh).nch) {                                         \
       case 1: CALL(64, 1); break;                                    \
