@@ -149,6 +149,10 @@ int osc_ustar_cosine_to(osc_handle h, const float* psi, float* out);
 /* out[i] = <Yn_i, Yn_row>: the similarity row of one chosen item for mmr_diversify (graph.py:114-133), from the
  * device's own copy of the anchors */
 int osc_cosine_to_row(osc_handle h, int64_t row, float* out);
+/* mmr_diversify (graph.py:114-133) over the device's own anchors: greedy selection of min(k, N) rows maximising
+ * (1 - lambda_div) * scores[i] - lambda_div * max_{j chosen} cos(Y_i, Y_j), first maximum in row order; scores and
+ * out_idx in API row order.  *out_count receives the number of rows written. */
+int osc_mmr(osc_handle h, const float* scores, int32_t k, float lambda_div, int32_t* out_idx, int32_t* out_count);
 
 /* ---- receipts ------------------------------------------------------------------------------- */
 /* deltaH_trace (receipts.py:10-25) on the resident U and U* */

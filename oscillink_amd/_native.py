@@ -59,6 +59,7 @@ SIGNATURES = {
     "osc_cosine_to": (C.c_int, [Handle, c_f32p, c_f32p]),
     "osc_ustar_cosine_to": (C.c_int, [Handle, c_f32p, c_f32p]),
     "osc_cosine_to_row": (C.c_int, [Handle, C.c_int64, c_f32p]),
+    "osc_mmr": (C.c_int, [Handle, c_f32p, C.c_int32, C.c_float, c_i32p, c_i32p]),
     "osc_deltaH": (C.c_int, [Handle, c_f64p]),
     "osc_receipt_components": (C.c_int, [Handle, c_f32p, c_f32p, c_f32p]),
     "osc_null_points": (C.c_int, [Handle, C.c_float, c_i32p, c_i32p, c_f32p, c_f32p, c_i32p]),

@@ -1949,6 +1949,57 @@ int osc_cosine_to_row(osc_handle h, int64_t row, float* out) {
   });
 }
 
+int osc_mmr(osc_handle h, const float* scores, int32_t k, float lambda_div, int32_t* out_idx, int32_t* out_count) {
+  return guarded(h, [&](L& l) {
+    if (!scores || !out_idx || !out_count) throw Invalid("osc_mmr: NULL buffer");
+    *out_count = 0;
+    const int32_t want = (int32_t)std::min<int64_t>(std::max(k, 0), l.N);
+    if (want <= 0) return;
+    const int32_t N = (int32_t)l.N;
+    // (1 - lambda) * score in fp64 and in device row order, like the NumPy float64 arithmetic this replaces
+    std::vector<double> base((size_t)N);
+    for (int32_t i = 0; i < N; ++i)
+      base[(size_t)i] = (1.0 - (double)lambda_div) * (double)scores[permuted(l) ? l.perm_h[(size_t)i] : i];
+    DevBuf<double> d_base, d_maxsim, d_pval;
+    DevBuf<unsigned char> d_alive;
+    DevBuf<int32_t> d_pid, d_prow, d_chosen;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>((N + 255) / 256, 256));
+    d_base.alloc((size_t)N);
+    d_maxsim.alloc((size_t)N);
+    d_alive.alloc((size_t)N);
+    d_pval.alloc((size_t)nblocks);
+    d_pid.alloc((size_t)nblocks);
+    d_prow.alloc((size_t)nblocks);
+    d_chosen.alloc((size_t)want);
+    l.vec_q.alloc((size_t)l.D);
+    HIP_CHECK(hipMemcpyAsync(d_base.p, base.data(), (size_t)N * 8, hipMemcpyHostToDevice, l.stream));
+    HIP_CHECK(hipMemsetAsync(d_alive.p, 1, (size_t)N, l.stream));
+    MmrArgs a{};
+    a.Y = l.Y.p;
+    a.base = d_base.p;
+    a.maxsim = d_maxsim.p;
+    a.alive = d_alive.p;
+    a.api_id = permuted(l) ? l.perm_d.p : nullptr;
+    a.q = l.vec_q.p;
+    a.pval = d_pval.p;
+    a.pid = d_pid.p;
+    a.prow = d_prow.p;
+    a.chosen_api = d_chosen.p;
+    a.N = N;
+    a.D = l.D;
+    a.ld = l.ld;
+    a.nblocks = nblocks;
+    a.lambda = (double)lambda_div;
+    for (int step = 0; step < want; ++step) launch_mmr_step(a, step, l.stream);
+    std::vector<int32_t> chosen((size_t)want);
+    HIP_CHECK(hipMemcpyAsync(chosen.data(), d_chosen.p, (size_t)want * 4, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+    int32_t n = 0;
+    for (; n < want && chosen[(size_t)n] >= 0; ++n) out_idx[n] = chosen[(size_t)n];
+    *out_count = n;
+  });
+}
+
 int osc_ustar_cosine_to(osc_handle h, const float* psi, float* out) {
   return guarded(h, [&](L& l) {
     if (!psi || !out) throw Invalid("osc_ustar_cosine_to: NULL buffer");

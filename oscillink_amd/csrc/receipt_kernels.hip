@@ -165,6 +165,136 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
   }
 }
 
+
+// ---- greedy MMR on the device (graph.py:114-133; bundle(), lattice.py:530-568) ---------------------------------------
+// val_i = (1 - lambda) score_i - lambda max_{j chosen} cos(Y_i, Y_j) over the rows still alive; the next item is the
+// first maximum in API row order.  One step = argmax (two stages), normalise the chosen row, one cosine pass over the
+// anchors fused with the running maximum.  All in fp64 where the host version used NumPy float64.
+constexpr double MMR_DEAD = -1.0e300;
+
+__device__ __forceinline__ bool mmr_better(double v, int id, double bv, int bid) { return v > bv || (v == bv && id < bid); }
+
+// stage 1: per-block best (value, API id, device row)
+__global__ __launch_bounds__(256) void k_mmr_argmax1(const double* base, const double* maxsim, const unsigned char* alive,
+                                                     const int32_t* api_id, int32_t N, double lambda, int first,
+                                                     double* pval, int32_t* pid, int32_t* prow) {
+  __shared__ double sv[256];
+  __shared__ int sid[256], srow[256];
+  double bv = MMR_DEAD;
+  int bid = 0x7fffffff, brow = -1;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    if (!alive[i]) continue;
+    const double v = base[i] - (first ? 0.0 : lambda * maxsim[i]);
+    const int id = api_id ? api_id[i] : i;
+    if (brow < 0 || mmr_better(v, id, bv, bid)) {
+      bv = v;
+      bid = id;
+      brow = i;
+    }
+  }
+  sv[threadIdx.x] = bv;
+  sid[threadIdx.x] = bid;
+  srow[threadIdx.x] = brow;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const int t = threadIdx.x + o;
+      if (srow[t] >= 0 && (srow[threadIdx.x] < 0 || mmr_better(sv[t], sid[t], sv[threadIdx.x], sid[threadIdx.x]))) {
+        sv[threadIdx.x] = sv[t];
+        sid[threadIdx.x] = sid[t];
+        srow[threadIdx.x] = srow[t];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    pval[blockIdx.x] = sv[0];
+    pid[blockIdx.x] = sid[0];
+    prow[blockIdx.x] = srow[0];
+  }
+}
+
+// stage 2 (one block): the winner; mark it dead, record it, and write its normalised anchor row into q
+__global__ __launch_bounds__(256) void k_mmr_argmax2(const double* pval, const int32_t* pid, const int32_t* prow, int nb,
+                                                     unsigned char* alive, int32_t* chosen_api, int step, const float* Y,
+                                                     int32_t ld, int32_t D, float* q) {
+  __shared__ double sv[256];
+  __shared__ int sid[256], srow[256];
+  __shared__ float sn[256];
+  double bv = MMR_DEAD;
+  int bid = 0x7fffffff, brow = -1;
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    if (prow[b] >= 0 && (brow < 0 || mmr_better(pval[b], pid[b], bv, bid))) {
+      bv = pval[b];
+      bid = pid[b];
+      brow = prow[b];
+    }
+  }
+  sv[threadIdx.x] = bv;
+  sid[threadIdx.x] = bid;
+  srow[threadIdx.x] = brow;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const int t = threadIdx.x + o;
+      if (srow[t] >= 0 && (srow[threadIdx.x] < 0 || mmr_better(sv[t], sid[t], sv[threadIdx.x], sid[threadIdx.x]))) {
+        sv[threadIdx.x] = sv[t];
+        sid[threadIdx.x] = sid[t];
+        srow[threadIdx.x] = srow[t];
+      }
+    }
+    __syncthreads();
+  }
+  const int row = srow[0];
+  if (row < 0) {
+    if (threadIdx.x == 0) chosen_api[step] = -1;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    alive[row] = 0;
+    chosen_api[step] = sid[0];
+  }
+  // q = Y_row / (|Y_row| + 1e-12)
+  const float* y = Y + (size_t)row * ld;
+  float n2 = 0.f;
+  for (int c = threadIdx.x; c < D; c += 256) n2 = fmaf(y[c], y[c], n2);
+  sn[threadIdx.x] = n2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sn[threadIdx.x] += sn[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float inv = 1.0f / (sqrtf(sn[0]) + 1e-12f);
+  for (int c = threadIdx.x; c < D; c += 256) q[c] = y[c] * inv;
+}
+
+// maxsim_i = max(maxsim_i, cos(Y_i, q)) for every row (first step: = cos); one wave per row
+__global__ __launch_bounds__(256) void k_mmr_update(const float* Y, int32_t ld, int32_t D, const float* q, int32_t N, int first,
+                                                    double* maxsim) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* y = Y + (size_t)row * ld;
+  float s = 0.f, n2 = 0.f;
+  const int d4 = D & ~3;
+  for (int c = lane * 4; c < d4; c += 256) {
+    const float4 v = ld4(y + c), w = ld4(q + c);
+    s = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, s))));
+    n2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, n2))));
+  }
+  for (int c = d4 + lane; c < D; c += 64) {
+    const float v = y[c];
+    s = fmaf(v, q[c], s);
+    n2 = fmaf(v, v, n2);
+  }
+  s = wave_sum(s);
+  n2 = wave_sum(n2);
+  if (lane == 0) {
+    const double cs = (double)(s / (sqrtf(n2) + 1e-12f));
+    maxsim[row] = first ? cs : fmax(maxsim[row], cs);
+  }
+}
+
 }  // namespace
 
 void launch_receipt_rows(const ReceiptArgs& a, hipStream_t s) {
@@ -176,6 +306,17 @@ void launch_receipt_rows(const ReceiptArgs& a, hipStream_t s) {
   else if (nch == 4) hipLaunchKernelGGL(k_receipt_rows<4>, grid, block, 0, s, a);
   else if (nch <= 6) hipLaunchKernelGGL(k_receipt_rows<6>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(k_receipt_rows<0>, grid, block, 0, s, a);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_mmr_step(const MmrArgs& a, int step, hipStream_t s) {
+  const int nb = a.nblocks;
+  hipLaunchKernelGGL(k_mmr_argmax1, dim3(nb), dim3(256), 0, s, a.base, a.maxsim, a.alive, a.api_id, a.N, a.lambda,
+                     step == 0 ? 1 : 0, a.pval, a.pid, a.prow);
+  hipLaunchKernelGGL(k_mmr_argmax2, dim3(1), dim3(256), 0, s, a.pval, a.pid, a.prow, nb, a.alive, a.chosen_api, step, a.Y,
+                     a.ld, a.D, a.q);
+  hipLaunchKernelGGL(k_mmr_update, dim3((unsigned)((a.N + 3) / 4)), dim3(256), 0, s, a.Y, a.ld, a.D, a.q, a.N,
+                     step == 0 ? 1 : 0, a.maxsim);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -26,4 +26,21 @@ struct ReceiptArgs {
 
 void launch_receipt_rows(const ReceiptArgs& a, hipStream_t s);
 
+// greedy MMR (graph.py:114-133) on the device: one call per selection step
+struct MmrArgs {
+  const float* Y;           // anchors, N x ld
+  const double* base;       // (1 - lambda) * score, device row order
+  double* maxsim;           // running max cosine to the chosen items
+  unsigned char* alive;     // 1 = still a candidate
+  const int32_t* api_id;    // device row -> API row id (nullptr = identity): ties go to the smaller API id
+  float* q;                 // [D] normalised anchor row of the item chosen in this step
+  double* pval;             // [nblocks] stage-1 partials
+  int32_t* pid;
+  int32_t* prow;
+  int32_t* chosen_api;      // [k] chosen items (API ids), -1 = none left
+  int32_t N, D, ld, nblocks;
+  double lambda;
+};
+void launch_mmr_step(const MmrArgs& a, int step, hipStream_t s);
+
 }  // namespace osc

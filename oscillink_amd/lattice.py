@@ -702,25 +702,16 @@ class OscillinkLattice:
         return [{"id": int(i), "score": float(score[i]), "align": float(align[i])} for i in order]
 
     def _mmr(self, scores: np.ndarray, k: int, lambda_div: float) -> list[int]:
-        """Greedy MMR over cosine similarity of Y; similarity rows are formed only for chosen items (O(kND))."""
+        """Greedy MMR over cosine similarity of Y (graph.py:114-133) as ONE device call: per step an argmax over the
+        candidates and one pass over the anchors for the chosen item's similarity row (O(kND), nothing N x N)."""
         if k <= 0:
             return []
-        chosen: list[int] = []
-        maxsim = np.zeros(self.N, dtype=np.float64)
-        alive = np.ones(self.N, dtype=bool)
-        s32 = np.empty(self.N, dtype=np.float32)
-        base = (1 - lambda_div) * scores.astype(np.float64)
-        while len(chosen) < min(k, self.N):
-            val = base - lambda_div * (maxsim if chosen else 0.0)
-            val = np.where(alive, val, -np.inf)
-            b = int(np.argmax(val))
-            chosen.append(b)
-            alive[b] = False
-            # similarity row of the chosen item: <Yn_i, Yn_b> for every i, one pass over the anchors on the device
-            self._call("osc_cosine_to_row", b, nat.f32(s32))
-            s = s32.astype(np.float64)
-            maxsim = s if len(chosen) == 1 else np.maximum(maxsim, s)
-        return chosen
+        want = min(int(k), self.N)
+        out = np.zeros(want, dtype=np.int32)
+        n = C.c_int32(0)
+        self._call("osc_mmr", nat.f32(np.ascontiguousarray(scores, dtype=np.float32)), want, float(lambda_div),
+                   nat.i32(out), C.byref(n))
+        return [int(i) for i in out[: int(n.value)]]
 
     # ------------------------------------------------------------------ callbacks / logging (lattice.py:571-579, 930-949)
     def add_settle_callback(self, fn) -> None:
