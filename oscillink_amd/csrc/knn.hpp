@@ -27,6 +27,9 @@ void launch_to_f16(const float* Yn, int32_t ldn, void* Yh, int32_t ldh, int64_t 
 // Yop: fp32 Yn (ld floats) or the fp16 image (ld = ldh/2 float slots)
 void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, float* cand_val, int32_t* cand_idx,
                      hipStream_t s);
+// small lattices (N <= 4096): dense similarity matrix Sm (N x lds_ floats of scratch) + per-row selection of the k best
+void launch_knn_dense(const float* Yn, int32_t ldn, int32_t N, int32_t k, float* Sm, int32_t lds_, float* out_val,
+                      int32_t* out_idx, hipStream_t s);
 // rank-select the best k_out of the S*KC candidates of each row of the plan's range (or of plan.qrows)
 void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* cand_idx, int32_t N, int32_t k_out,
                       float* out_val, int32_t* out_idx, int clip, hipStream_t s);

@@ -348,6 +348,137 @@ __global__ __launch_bounds__(256, 2) void k_knn_topk(const float* __restrict__ Y
                                                      const int32_t* __restrict__ qrows, int32_t nq) {
   knn_topk_body<E, F16, QR>(Yn, ldn, N, k, S, cols_per_split, cand_val, cand_idx, rb_begin, rb_count, qrows, nq);
 }
+// ---- small lattices: dense similarity matrix + per-row selection ---------------------------------------------------
+// For N <= 4096 the streaming top-k above spends its time inserting the first tile's 128 columns one by one into empty
+// lists (N = 1200: 374 us of a 0.5 ms build).  Here one workgroup per (row block, column tile) writes its 128 x 128
+// tile of S = Yn Yn^T (same staging, fragment order and MFMA sequence as knn_topk_body, so S is bitwise symmetric and
+// bit-identical to what the streaming kernel scores), and one wave per row then picks the k best by repeated argmax.
+__global__ __launch_bounds__(256, 2) void k_knn_dense(const float* __restrict__ Yn, int32_t ldn, int32_t N,
+                                                      float* __restrict__ Sm, int32_t lds_) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * BM * LDT];
+  float* As = lds;
+  float* Bs = lds + BM * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int row0 = blockIdx.y * BM, ct = blockIdx.x * BN;
+  const int nkt = ldn / BK;
+  int srow[4], sc4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = tid + 256 * q;
+    srow[q] = f >> 3;
+    sc4[q] = (f & 7) * 4;
+  }
+  const float* a_ptr[4];
+  const float* b_ptr[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    a_ptr[q] = Yn + (size_t)min(row0 + srow[q], N - 1) * ldn + sc4[q];
+    b_ptr[q] = Yn + (size_t)min(ct + srow[q], N - 1) * ldn + sc4[q];
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+  float4 ra[4], rb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    ra[q] = ld4(a_ptr[q]);
+    rb[q] = ld4(b_ptr[q]);
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<float4*>(As + srow[q] * LDT + sc4[q]) = ra[q];
+      *reinterpret_cast<float4*>(Bs + srow[q] * LDT + sc4[q]) = rb[q];
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ra[q] = ld4(a_ptr[q] + (kt + 1) * BK);
+        rb[q] = ld4(b_ptr[q] + (kt + 1) * BK);
+      }
+    }
+    const float* ap = As + (32 * wave + l31) * LDT + 4 * h;
+    const float* bp = Bs + l31 * LDT + 4 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 av = ld4(ap + 8 * s);
+      float4 bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bv[t] = ld4(bp + 32 * t * LDT + 8 * s);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int row = row0 + 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * h;
+    if (row >= N) continue;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = ct + 32 * t + l31;
+      if (col < N) Sm[(size_t)row * lds_ + col] = acc[t][g];
+    }
+  }
+}
+
+// one wave per row: the k best columns by (similarity desc, index asc), diagonal excluded (graph.py:37, 46-49), values
+// clipped at 0 (graph.py:62).  M = registers per lane (64 M >= N).
+template <int M>
+__global__ __launch_bounds__(256) void k_knn_select(const float* __restrict__ Sm, int32_t lds_, int32_t N, int32_t k,
+                                                    float* out_val, int32_t* out_idx) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float v[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int c = lane + 64 * m;
+    v[m] = (c < N && c != row) ? Sm[(size_t)row * lds_ + c] : NEG;
+  }
+  for (int r = 0; r < k; ++r) {
+    float bv = v[0];
+    int bm = 0;
+#pragma unroll
+    for (int m = 1; m < M; ++m)
+      if (v[m] > bv) {  // strict: equal values keep the smaller index (smaller m)
+        bv = v[m];
+        bm = m;
+      }
+    int bi = lane + 64 * bm;
+    float wv = bv;
+    int wi = bi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(wv, o, 64);
+      const int oi = __shfl_xor(wi, o, 64);
+      if (ov > wv || (ov == wv && oi < wi)) {
+        wv = ov;
+        wi = oi;
+      }
+    }
+    if (!(wv > NEG)) break;  // nothing left (cannot happen for k <= N - 1)
+    if (wi == bi) {  // this lane held the winner: retire it
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+        if (m == bm) v[m] = NEG;
+    }
+    if (lane == 0) {
+      out_val[(size_t)row * k + r] = fmaxf(wv, 0.f);
+      out_idx[(size_t)row * k + r] = wi;
+    }
+  }
+}
+
 // k in (64, 128]: 128 list registers per lane -> one wave per SIMD with the whole 512-entry register file
 template <bool QR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_knn_topk_wide(
@@ -940,6 +1071,21 @@ void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, 
     else hipLaunchKernelGGL(k_knn_topk_wide<false>, grid, block, 0, s, OSC_KNN_ARGS);
   }
 #undef OSC_KNN_ARGS
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_knn_dense(const float* Yn, int32_t ldn, int32_t N, int32_t k, float* Sm, int32_t lds_, float* out_val,
+                      int32_t* out_idx, hipStream_t s) {
+  if (N > 4096) throw std::runtime_error("launch_knn_dense: N > 4096");
+  const int nb = (N + BM - 1) / BM;
+  hipLaunchKernelGGL(k_knn_dense, dim3(nb, nb), dim3(256), 0, s, Yn, ldn, N, Sm, lds_);
+  const dim3 grid((unsigned)((N + 3) / 4)), block(256);
+  const int m = (N + 63) / 64;
+  if (m <= 4) hipLaunchKernelGGL(k_knn_select<4>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx);
+  else if (m <= 8) hipLaunchKernelGGL(k_knn_select<8>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx);
+  else if (m <= 16) hipLaunchKernelGGL(k_knn_select<16>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx);
+  else if (m <= 32) hipLaunchKernelGGL(k_knn_select<32>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx);
+  else hipLaunchKernelGGL(k_knn_select<64>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -687,6 +687,7 @@ void build_graph(L& h) {
     if (!strcmp(e, "exact")) prefilter = false;
     if (!strcmp(e, "prefilter")) prefilter = (keep_f >= k + 8);
   }
+  static const bool dense_small = [] { const char* e = getenv("OSC_KNN_DENSE"); return !(e && atoi(e) == 0); }();
   DevBuf<float> cand_val, cval;
   DevBuf<int32_t> cand_idx, cidx, fail_rows, fail_count;
   DevBuf<float> Yh;  // fp16 image, viewed as float slots
@@ -721,6 +722,14 @@ void build_graph(L& h) {
       launch_knn_merge(plan, cand_val.p, cand_idx.p, N, keep_f, cval.p, cidx.p, 0, h.stream);
       launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
                          fail_count.p, h.stream);
+    } else if (parts == 1 && N <= 4096 && dense_small) {
+      // small lattices: dense S + per-row argmax selection (the streaming kernel's first-tile inserts dominate here)
+      const int32_t ldS = ((N + 31) / 32) * 32;
+      DevBuf<float> Sm;
+      Sm.alloc((size_t)N * ldS);
+      ProfScope ps(h, 3);
+      launch_knn_dense(Yn.p, ldn, N, k, Sm.p, ldS, h.knn_val.p, h.knn_idx.p, h.stream);
+      sync(h);  // Sm goes back to the pool at scope exit
     } else {
       const KnnPlan plan = knn_plan(N, k, slots, rb_begin, rb_count, false);
       const size_t ncand = (size_t)h.N * plan.S * plan.KC;
