@@ -1076,16 +1076,24 @@ void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, 
 
 void launch_knn_dense(const float* Yn, int32_t ldn, int32_t N, int32_t k, float* Sm, int32_t lds_, float* out_val,
                       int32_t* out_idx, hipStream_t s) {
-  if (N > 4096) throw std::runtime_error("launch_knn_dense: N > 4096");
+  if (N > 8192) throw std::runtime_error("launch_knn_dense: N > 8192");
   const int nb = (N + BM - 1) / BM;
   hipLaunchKernelGGL(k_knn_dense, dim3(nb, nb), dim3(256), 0, s, Yn, ldn, N, Sm, lds_);
   const dim3 grid((unsigned)((N + 3) / 4)), block(256);
   const int m = (N + 63) / 64;
-  if (m <= 4) hipLaunchKernelGGL(k_knn_select<4>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx);
-  else if (m <= 8) hipLaunchKernelGGL(k_knn_select<8>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx);
-  else if (m <= 16) hipLaunchKernelGGL(k_knn_select<16>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx);
-  else if (m <= 32) hipLaunchKernelGGL(k_knn_select<32>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx);
-  else hipLaunchKernelGGL(k_knn_select<64>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx);
+#define OSC_SEL(MM) hipLaunchKernelGGL(k_knn_select<MM>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx)
+  if (m <= 4) OSC_SEL(4);
+  else if (m <= 8) OSC_SEL(8);
+  else if (m <= 16) OSC_SEL(16);
+  else if (m <= 24) OSC_SEL(24);
+  else if (m <= 32) OSC_SEL(32);
+  else if (m <= 48) OSC_SEL(48);
+  else if (m <= 64) OSC_SEL(64);
+  else if (m <= 80) OSC_SEL(80);
+  else if (m <= 96) OSC_SEL(96);
+  else if (m <= 112) OSC_SEL(112);
+  else OSC_SEL(128);
+#undef OSC_SEL
   HIP_CHECK(hipGetLastError());
 }
 

@@ -682,12 +682,14 @@ void build_graph(L& h) {
   //              to its top-k, otherwise the row is redone by the exact kernel.
   // kept candidates per row: k plus a margin; rows whose margin turns out too thin are redone exactly
   const int keep_f = std::min(96, k + std::max(12, k / 2));
-  bool prefilter = (keep_f >= k + 8) && N >= 4096;  // tiny lattices: the extra passes cost more than they save
+  static const bool dense_small = [] { const char* e = getenv("OSC_KNN_DENSE"); return !(e && atoi(e) == 0); }();
+  static const int dense_max = [] { const char* e = getenv("OSC_KNN_DENSE_MAX"); return e ? std::max(0, std::min(8192, atoi(e))) : 8192; }();
+  // small lattices go through the dense similarity matrix (below); beyond that the fp16 prefilter pays
+  bool prefilter = (keep_f >= k + 8) && N >= 4096 && !(dense_small && parts == 1 && N <= dense_max);
   if (const char* e = getenv("OSC_KNN_MODE")) {  // "exact" | "prefilter": force one path (tests, A/B)
     if (!strcmp(e, "exact")) prefilter = false;
     if (!strcmp(e, "prefilter")) prefilter = (keep_f >= k + 8);
   }
-  static const bool dense_small = [] { const char* e = getenv("OSC_KNN_DENSE"); return !(e && atoi(e) == 0); }();
   DevBuf<float> cand_val, cval;
   DevBuf<int32_t> cand_idx, cidx, fail_rows, fail_count;
   DevBuf<float> Yh;  // fp16 image, viewed as float slots
@@ -722,7 +724,7 @@ void build_graph(L& h) {
       launch_knn_merge(plan, cand_val.p, cand_idx.p, N, keep_f, cval.p, cidx.p, 0, h.stream);
       launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
                          fail_count.p, h.stream);
-    } else if (parts == 1 && N <= 4096 && dense_small) {
+    } else if (parts == 1 && N <= dense_max && dense_small) {
       // small lattices: dense S + per-row argmax selection (the streaming kernel's first-tile inserts dominate here)
       const int32_t ldS = ((N + 31) / 32) * 32;
       DevBuf<float> Sm;
