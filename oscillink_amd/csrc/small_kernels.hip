@@ -216,14 +216,19 @@ __global__ __launch_bounds__(T) void k_settle_small(const SmallArgs a) {
 
 size_t small_lds_bytes(int32_t N, int C) { return (size_t)N * C * 4 * sizeof(float) + NW * C * sizeof(double) + 64; }
 
-// every workgroup must be resident at once (counter barrier): one 1024-thread workgroup per CU, well under 256 CUs
+// every workgroup must be resident at once (counter barrier with a timeout that falls back to the general path)
 int small_pick_cols(int32_t N, int32_t ld) {
   for (int C : {4, 2, 1}) {
     const int blocks = (ld + C - 1) / C;
     // one column per workgroup leaves most of the chip idle behind long serial row loops: past N = 6000 the general
     // multi-launch path is faster (measured: N = 5000 0.18 vs 0.23 ms, 7000 0.24 vs 0.23, 9000 0.30 vs 0.23)
     if (C == 1 && N > 6000) continue;
-    if (blocks <= 128 && small_lds_bytes(N, C) <= 150 * 1024) return C;
+    // co-residency: one workgroup per CU always fits (256 CUs); two per CU when each stays under half the LDS
+    const size_t lds = small_lds_bytes(N, C);
+    // a second workgroup per CU only pays while the per-workgroup row loops are short (measured, 384 workgroups:
+    // N = 2000 x 768 0.162 vs 0.236 ms general; N = 2500 x 768 a tie; N = 5000 x 384 0.319 vs 0.240)
+    const int resident = (lds <= 79 * 1024 && N <= 2200) ? 512 : 256;
+    if (blocks <= resident && lds <= 150 * 1024) return C;
   }
   return 0;
 }
