@@ -33,7 +33,21 @@ for t in range(count):
     ea = set(zip(np.repeat(np.arange(N), np.diff(a[0])).tolist(), a[1].tolist()))
     eb = set(zip(np.repeat(np.arange(N), np.diff(b[0])).tolist(), b[1].tolist()))
     diff = len(ea ^ eb)
-    ok = diff <= 4
+    # edges present on one side only must be rank-k near-ties of one of their end rows: both paths score in fp32 with
+    # different summation orders, so scores closer than that noise may rank either way (so may the reference's BLAS)
+    ok = True
+    Yn = None
+    for (i, j) in list(ea ^ eb)[:64]:
+        if Yn is None:
+            Y64 = Y.astype(np.float64)
+            Yn = Y64 / (np.linalg.norm(Y64, axis=1, keepdims=True) + 1e-12)
+        near = False
+        for r, c in ((i, j), (j, i)):
+            srow = Yn @ Yn[r]
+            srow[r] = -np.inf
+            kth = np.partition(srow, -k)[-k]
+            near = near or abs(srow[c] - kth) < 2e-6
+        ok = ok and near
     bad += not ok
-    print(f"N={N} D={D} k={k} clustered={clustered} edges={len(eb)} symmetric-difference={diff} fallback_rows={info['prefilter']['fallback_rows']} {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"N={N} D={D} k={k} clustered={clustered} edges={len(eb)} symmetric-difference={diff}(near-ties only: {ok}) fallback_rows={info['prefilter']['fallback_rows']} {'ok' if ok else 'MISMATCH'}", flush=True)
 print("mismatches:", bad)
