@@ -183,8 +183,24 @@ int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* tota
  * all-reduce(max) of the stop-test residual.  id is an ncclUniqueId (128 bytes) made by rank 0
  * with osc_comm_unique_id and distributed by the caller. */
 int osc_comm_unique_id(char id_out[128]);
+/* An id for the in-process LOOPBACK backend instead: the ranks are threads of ONE process, each with its own handle on
+ * the same GPU, and every collective is device-to-device copies between host barriers.  It runs the multi-rank code
+ * paths (unequal column slabs, row-block / halo exchanges, the sharded kNN list all-gather, speculative iterations
+ * around collectives) at world > 1 on a single MI355X, where RCCL refuses two ranks on one device.  Test backend:
+ * every collective blocks the calling thread until all ranks of the group have entered it (60 s limit, then
+ * OSC_E_COMM on every rank; OSC_LOOPBACK_TIMEOUT_S overrides). */
+int osc_comm_loopback_id(char id_out[128]);
+/* Joins the communicator the id names (RCCL or loopback).  Sets this rank's column window (column-sharded CG, the
+ * default) or keeps all columns (OSC_SHARD=row: row-sharded CG).  Collective for RCCL ids. */
 int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world);
 int osc_comm_shard(osc_handle h, int32_t* c0, int32_t* c1);
+/* rank / world (0 / 1 without a communicator), shard_mode 0 = column-sharded CG, 1 = row-sharded; kind_out receives
+ * "none", "rccl" or "loopback" */
+int osc_comm_info(osc_handle h, int32_t* rank, int32_t* world, int32_t* shard_mode, char* kind_out, int32_t cap);
+/* Drains the handle's stream, then all-reduces n host doubles in place over the handle's communicator (op 0 = sum,
+ * 1 = max); n = 0 is a pure barrier.  Without a communicator: stream drain only.  What a benchmark harness needs for
+ * "barrier + max over ranks" without any other distributed runtime. */
+int osc_comm_allreduce_f64(osc_handle h, double* vals, int32_t n, int32_t op);
 
 #ifdef __cplusplus
 }

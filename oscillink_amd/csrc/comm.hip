@@ -1,0 +1,272 @@
+// Communicator backends (comm.hpp): RCCL, and the in-process loopback used to run the multi-rank paths on one GPU.
+#include "comm.hpp"
+
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+namespace osc {
+namespace {
+
+// ---- RCCL ---------------------------------------------------------------------------------------------------------
+void nccl_ok(ncclResult_t r, const char* what) {
+  if (r != ncclSuccess) throw CommError(std::string(what) + " failed: " + ncclGetErrorString(r));
+}
+
+class RcclComm final : public Comm {
+ public:
+  RcclComm(const char id[128], int rank, int world) {
+    rank_ = rank;
+    world_ = world;
+    ncclUniqueId uid;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(&uid, id, 128);
+    nccl_ok(ncclCommInitRank(&comm_, world, uid, rank), "ncclCommInitRank");
+  }
+  ~RcclComm() override {
+    if (comm_) (void)ncclCommDestroy(comm_);
+  }
+  const char* kind() const override { return "rccl"; }
+  void allreduce(void* buf, size_t n, CommDType t, CommOp op, hipStream_t s) override {
+    const ncclDataType_t dt = t == COMM_F32 ? ncclFloat : t == COMM_F64 ? ncclDouble : ncclInt32;
+    nccl_ok(ncclAllReduce(buf, buf, n, dt, op == COMM_SUM ? ncclSum : ncclMax, comm_, s), "ncclAllReduce");
+  }
+  void allgather(void* buf, size_t chunk_bytes, hipStream_t s) override {
+    nccl_ok(ncclAllGather(static_cast<char*>(buf) + (size_t)rank_ * chunk_bytes, buf, chunk_bytes, ncclChar, comm_, s),
+            "ncclAllGather");
+  }
+  void broadcast_group(const std::vector<CommXfer>& pieces, hipStream_t s) override {
+    nccl_ok(ncclGroupStart(), "ncclGroupStart");
+    for (const CommXfer& p : pieces)
+      if (p.bytes) nccl_ok(ncclBroadcast(p.ptr, p.ptr, p.bytes, ncclChar, p.peer, comm_, s), "ncclBroadcast");
+    nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+  }
+  void exchange(const std::vector<CommXfer>& sends, const std::vector<CommXfer>& recvs, hipStream_t s) override {
+    nccl_ok(ncclGroupStart(), "ncclGroupStart");
+    for (const CommXfer& p : sends)
+      if (p.bytes) nccl_ok(ncclSend(p.ptr, p.bytes, ncclChar, p.peer, comm_, s), "ncclSend");
+    for (const CommXfer& p : recvs)
+      if (p.bytes) nccl_ok(ncclRecv(p.ptr, p.bytes, ncclChar, p.peer, comm_, s), "ncclRecv");
+    nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+  }
+
+ private:
+  ncclComm_t comm_ = nullptr;
+};
+
+// ---- loopback -----------------------------------------------------------------------------------------------------
+constexpr char kLoopMagic[8] = {'O', 'S', 'C', 'L', 'O', 'O', 'P', '1'};
+
+template <typename T, int OP>
+__global__ void k_loop_reduce(T* __restrict__ acc, const T* __restrict__ src, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const T a = acc[i], b = src[i];
+    if (OP == COMM_SUM) acc[i] = a + b;
+    else acc[i] = (a != a || b != b) ? (a != a ? a : b) : (a > b ? a : b);  // NaN wins, like ncclMax on floats here
+  }
+}
+
+struct LoopGroup {
+  int world = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  bool broken = false;
+  int joined = 0;
+  double timeout_s = 60.0;
+  struct Slot {
+    void* ptr = nullptr;
+    const std::vector<CommXfer>* list = nullptr;
+  };
+  std::vector<Slot> slots;
+
+  // every rank of the group passes, or every rank throws
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (broken) throw CommError("loopback communicator is broken (a rank failed or timed out earlier)");
+    const uint64_t gen = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+      return;
+    }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
+    while (generation == gen && !broken) {
+      if (cv.wait_until(lk, deadline) == std::cv_status::timeout && generation == gen) {
+        broken = true;  // a rank never reached this collective: mismatched call sequences
+        cv.notify_all();
+      }
+    }
+    if (generation == gen) throw CommError("loopback barrier timed out: the ranks' collective sequences differ");
+  }
+  void fail() {
+    std::lock_guard<std::mutex> lk(mu);
+    broken = true;
+    cv.notify_all();
+  }
+};
+
+std::mutex g_loop_mu;
+std::map<uint64_t, std::weak_ptr<LoopGroup>> g_loop_groups;
+std::atomic<uint64_t> g_loop_next{1};
+
+class LoopbackComm final : public Comm {
+ public:
+  LoopbackComm(const char id[128], int rank, int world) {
+    rank_ = rank;
+    world_ = world;
+    uint64_t key = 0;
+    std::memcpy(&key, id + 8, 8);
+    std::lock_guard<std::mutex> lk(g_loop_mu);
+    auto it = g_loop_groups.find(key);
+    if (it != g_loop_groups.end()) g_ = it->second.lock();
+    if (!g_) {
+      g_ = std::make_shared<LoopGroup>();
+      g_->world = world;
+      g_->slots.resize((size_t)world);
+      if (const char* e = getenv("OSC_LOOPBACK_TIMEOUT_S")) g_->timeout_s = std::max(1.0, atof(e));
+      g_loop_groups[key] = g_;
+    }
+    if (g_->world != world) throw CommError("loopback: ranks of one group disagree on the world size");
+    if (++g_->joined > world) throw CommError("loopback: more ranks joined than the world size");
+  }
+  ~LoopbackComm() override {
+    std::lock_guard<std::mutex> lk(g_loop_mu);
+    --g_->joined;
+  }
+  const char* kind() const override { return "loopback"; }
+
+  // Protocol of every collective: publish my pointers, drain my stream (my data is final), barrier, read the peers'
+  // memory on my stream, drain, barrier (now every peer may overwrite what I read).
+  void allreduce(void* buf, size_t n, CommDType t, CommOp op, hipStream_t s) override {
+    const size_t esz = t == COMM_F64 ? 8 : 4;
+    enter(buf, nullptr, s);
+    tmp_.alloc((n * esz + 3) / 4);
+    try {
+      HIP_CHECK(hipMemcpyAsync(tmp_.p, g_->slots[0].ptr, n * esz, hipMemcpyDeviceToDevice, s));
+      for (int r = 1; r < world_; ++r) reduce_into(tmp_.p, g_->slots[(size_t)r].ptr, n, t, op, s);  // fixed order: same bits everywhere
+      HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+      g_->fail();
+      throw;
+    }
+    g_->barrier();
+    HIP_CHECK(hipMemcpyAsync(buf, tmp_.p, n * esz, hipMemcpyDeviceToDevice, s));
+  }
+  void allgather(void* buf, size_t chunk_bytes, hipStream_t s) override {
+    enter(buf, nullptr, s);
+    try {
+      for (int r = 0; r < world_; ++r) {
+        if (r == rank_ || !chunk_bytes) continue;
+        const size_t off = (size_t)r * chunk_bytes;
+        HIP_CHECK(hipMemcpyAsync(static_cast<char*>(buf) + off, static_cast<const char*>(g_->slots[(size_t)r].ptr) + off,
+                                 chunk_bytes, hipMemcpyDeviceToDevice, s));
+      }
+      HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+      g_->fail();
+      throw;
+    }
+    g_->barrier();
+  }
+  void broadcast_group(const std::vector<CommXfer>& pieces, hipStream_t s) override {
+    enter(nullptr, &pieces, s);
+    try {
+      for (size_t i = 0; i < pieces.size(); ++i) {
+        const CommXfer& p = pieces[i];
+        if (p.peer == rank_ || !p.bytes) continue;
+        if (p.peer < 0 || p.peer >= world_) throw CommError("loopback broadcast: bad root");
+        const std::vector<CommXfer>& theirs = *g_->slots[(size_t)p.peer].list;
+        if (theirs.size() != pieces.size() || theirs[i].bytes != p.bytes || theirs[i].peer != p.peer)
+          throw CommError("loopback broadcast: the ranks' piece lists differ");
+        HIP_CHECK(hipMemcpyAsync(p.ptr, theirs[i].ptr, p.bytes, hipMemcpyDeviceToDevice, s));
+      }
+      HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+      g_->fail();
+      throw;
+    }
+    g_->barrier();
+  }
+  void exchange(const std::vector<CommXfer>& sends, const std::vector<CommXfer>& recvs, hipStream_t s) override {
+    enter(nullptr, &sends, s);
+    try {
+      std::vector<size_t> cursor((size_t)world_, 0);  // next unmatched send of each peer
+      for (const CommXfer& rv : recvs) {
+        if (rv.peer < 0 || rv.peer >= world_) throw CommError("loopback recv: bad peer");
+        const std::vector<CommXfer>& theirs = *g_->slots[(size_t)rv.peer].list;
+        size_t& c = cursor[(size_t)rv.peer];
+        while (c < theirs.size() && theirs[c].peer != rank_) ++c;
+        if (c >= theirs.size() || theirs[c].bytes != rv.bytes) throw CommError("loopback exchange: unmatched recv");
+        if (rv.bytes) HIP_CHECK(hipMemcpyAsync(rv.ptr, theirs[c].ptr, rv.bytes, hipMemcpyDeviceToDevice, s));
+        ++c;
+      }
+      HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+      g_->fail();
+      throw;
+    }
+    g_->barrier();
+  }
+
+ private:
+  void enter(void* ptr, const std::vector<CommXfer>* list, hipStream_t s) {
+    g_->slots[(size_t)rank_].ptr = ptr;
+    g_->slots[(size_t)rank_].list = list;
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      g_->fail();
+      hip_check(e, "hipStreamSynchronize (loopback collective)", __FILE__, __LINE__);
+    }
+    g_->barrier();
+  }
+  static void reduce_into(void* acc, const void* src, size_t n, CommDType t, CommOp op, hipStream_t s) {
+    if (!n) return;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 1024);
+#define OSC_LOOP_CASE(T, TT)                                                                                   \
+  if (t == T) {                                                                                                \
+    if (op == COMM_SUM) hipLaunchKernelGGL((k_loop_reduce<TT, COMM_SUM>), dim3(grid), dim3(256), 0, s,         \
+                                           static_cast<TT*>(acc), static_cast<const TT*>(src), n);            \
+    else hipLaunchKernelGGL((k_loop_reduce<TT, COMM_MAX>), dim3(grid), dim3(256), 0, s, static_cast<TT*>(acc), \
+                            static_cast<const TT*>(src), n);                                                   \
+  }
+    OSC_LOOP_CASE(COMM_F32, float)
+    OSC_LOOP_CASE(COMM_F64, double)
+    OSC_LOOP_CASE(COMM_I32, int32_t)
+#undef OSC_LOOP_CASE
+    HIP_CHECK(hipGetLastError());
+  }
+
+  std::shared_ptr<LoopGroup> g_;
+  DevBuf<uint32_t> tmp_;
+};
+
+}  // namespace
+
+void comm_rccl_id(char id_out[128]) {
+  ncclUniqueId id;
+  nccl_ok(ncclGetUniqueId(&id), "ncclGetUniqueId");
+  std::memcpy(id_out, &id, 128);
+}
+
+void comm_loopback_id(char id_out[128]) {
+  std::memset(id_out, 0, 128);
+  std::memcpy(id_out, kLoopMagic, 8);
+  const uint64_t key = g_loop_next.fetch_add(1);
+  std::memcpy(id_out + 8, &key, 8);
+}
+
+std::unique_ptr<Comm> comm_create(const char id[128], int rank, int world, int device) {
+  (void)device;
+  if (std::memcmp(id, kLoopMagic, 8) == 0) return std::unique_ptr<Comm>(new LoopbackComm(id, rank, world));
+  return std::unique_ptr<Comm>(new RcclComm(id, rank, world));
+}
+
+}  // namespace osc

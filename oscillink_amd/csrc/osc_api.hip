@@ -1,7 +1,5 @@
 // C ABI of liboscillink_hip.so (include/oscillink_hip.h): handle management, lattice build orchestration,
 // the CG driver and receipts.  All device work of a handle goes to the handle's own HIP stream.
-#include <rccl/rccl.h>
-
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -13,6 +11,7 @@
 
 #include "../../include/oscillink_hip.h"
 #include "common.hpp"
+#include "comm.hpp"
 #include "knn.hpp"
 #include "receipts.hpp"
 #include "perm.hpp"
@@ -37,9 +36,6 @@ struct StateError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 struct Unsupported : std::runtime_error {
-  using std::runtime_error::runtime_error;
-};
-struct CommError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
@@ -229,7 +225,7 @@ struct osc_lattice {
   std::vector<float> history;
   // column shard (multi-GPU, column-sharded CG); single GPU: [0, ld)
   int32_t c0 = 0, c1 = 0;
-  ncclComm_t comm = nullptr;
+  std::unique_ptr<Comm> comm;  // RCCL (one process per GPU) or the in-process loopback (comm.hpp)
   int rank = 0, world = 1;
   bool u_sharded = false;  // U holds only this rank's columns (after a sharded settle)
   int shard_mode = 0;      // 0 = column-sharded CG (default), 1 = row-sharded CG (north-star wording; OSC_SHARD=row)
@@ -250,7 +246,6 @@ struct osc_lattice {
       (void)hipEventDestroy(s.b);
     }
     for (auto e : prof_pool) (void)hipEventDestroy(e);
-    if (comm) (void)ncclCommDestroy(comm);
     park_ctrl();
     release_stream(device, stream);
   }
@@ -762,9 +757,8 @@ void build_graph(L& h) {
   }
   if (sharded) {
     const size_t cnt = (size_t)rb_per * 128 * k;  // equal chunk per rank, in place
-    if (ncclAllGather(h.knn_val.p + (size_t)h.rank * cnt, h.knn_val.p, cnt, ncclFloat, h.comm, h.stream) != ncclSuccess ||
-        ncclAllGather(h.knn_idx.p + (size_t)h.rank * cnt, h.knn_idx.p, cnt, ncclInt32, h.comm, h.stream) != ncclSuccess)
-      throw CommError("ncclAllGather(kNN lists) failed");
+    h.comm->allgather(h.knn_val.p, cnt * 4, h.stream);
+    h.comm->allgather(h.knn_idx.p, cnt * 4, h.stream);
   }
   alloc_ell(h, k);
   launch_mutual_ell(h.knn_val.p, h.knn_idx.p, N, k, h.width, h.ell_col.p, h.ell_a.p, h.deg.p, h.stream);
@@ -1065,10 +1059,8 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       return;
     }
     launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream);
-    if (h.comm) {  // column-sharded: the stop test is the max over all shards (solver.py:29)
-      if (ncclAllReduce(h.res_bits.p + it, h.res_bits.p + it, 1, ncclFloat, ncclMax, h.comm, h.stream) != ncclSuccess)
-        throw CommError("ncclAllReduce(max residual) failed");
-    }
+    // column-sharded: the stop test is the max over all shards (solver.py:29)
+    if (h.comm) h.comm->allreduce(h.res_bits.p + it, 1, COMM_F32, COMM_MAX, h.stream);
     HIP_CHECK(hipMemcpyAsync(h.res_host + it, h.res_bits.p + it, 4, hipMemcpyDeviceToHost, h.stream));
     HIP_CHECK(hipEventRecord(h.iter_events[(size_t)it], h.stream));
   };
@@ -1135,8 +1127,7 @@ void gather_columns(L& h, float* arr) {
     if (r == h.rank)
       HIP_CHECK(hipMemcpy2DAsync(h.comm_buf.p, (size_t)w * 4, arr + lo, (size_t)h.ld * 4, (size_t)w * 4, (size_t)h.N,
                                  hipMemcpyDeviceToDevice, h.stream));
-    if (ncclBroadcast(h.comm_buf.p, h.comm_buf.p, (size_t)h.N * w, ncclFloat, r, h.comm, h.stream) != ncclSuccess)
-      throw CommError("ncclBroadcast(column slab) failed");
+    h.comm->broadcast_group({CommXfer{h.comm_buf.p, (size_t)h.N * w * 4, r}}, h.stream);
     if (r != h.rank)
       HIP_CHECK(hipMemcpy2DAsync(arr + lo, (size_t)h.ld * 4, h.comm_buf.p, (size_t)w * 4, (size_t)w * 4, (size_t)h.N,
                                  hipMemcpyDeviceToDevice, h.stream));
@@ -1166,21 +1157,17 @@ std::vector<RowShard> row_shards(const L& h) {
 // make every rank's copy of `arr` complete: each rank broadcasts its own row block (grouped, in place)
 void exchange_rows(L& h, float* arr, int32_t ld) {
   if (!h.comm) return;  // (a 1-rank communicator still runs the calls: that is how one GPU exercises this path)
-  if (ncclGroupStart() != ncclSuccess) throw CommError("ncclGroupStart failed");
+  std::vector<CommXfer> pieces;
   for (int r = 0; r < h.world; ++r) {
     const int64_t a = h.N * r / h.world, b = h.N * (r + 1) / h.world;
-    if (b <= a) continue;
-    float* blk = arr + (size_t)a * ld;
-    if (ncclBroadcast(blk, blk, (size_t)(b - a) * ld, ncclFloat, r, h.comm, h.stream) != ncclSuccess)
-      throw CommError("ncclBroadcast(row block) failed");
+    pieces.push_back(CommXfer{arr + (size_t)a * ld, (size_t)(b - a) * ld * 4, r});
   }
-  if (ncclGroupEnd() != ncclSuccess) throw CommError("ncclGroupEnd failed");
+  h.comm->broadcast_group(pieces, h.stream);
 }
 
 void allreduce_sums(L& h, double* buf, size_t n) {
   if (!h.comm) return;
-  if (ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, h.comm, h.stream) != ncclSuccess)
-    throw CommError("ncclAllReduce(column sums) failed");
+  h.comm->allreduce(buf, n, COMM_F64, COMM_SUM, h.stream);
 }
 
 CgResult run_cg_rows(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol) {
@@ -1905,16 +1892,15 @@ int osc_cg_single_rhs(osc_handle h, float gamma, const float* s, float tol, int3
     op.rbB = 0.f;
     CgBuffers b{X0.p, X.p, R.p, P.p, AP.p, S.p, S.p, l.B.p, psi0.p, ld1, 0, ld1};
     // scratch sized for ld >= 4 already
-    ncclComm_t saved = l.comm;
-    l.comm = nullptr;  // the diffusion solve is replicated, not sharded
+    std::unique_ptr<Comm> saved = std::move(l.comm);  // the diffusion solve is replicated, not sharded
     CgResult r;
     try {
       r = run_cg(l, op, b, false, max_iters, tol);
     } catch (...) {
-      l.comm = saved;
+      l.comm = std::move(saved);
       throw;
     }
-    l.comm = saved;
+    l.comm = std::move(saved);
     HIP_CHECK(hipMemcpy2DAsync(flat.p, 4, X.p, ld1 * 4, 4, (size_t)l.N, hipMemcpyDeviceToDevice, l.stream));
     HIP_CHECK(hipMemcpyAsync(h_out, flat.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
     sync(l);
@@ -2065,8 +2051,7 @@ int osc_deltaH(osc_handle h, double* dH) {
       DevBuf<double> t;
       t.alloc(1);
       HIP_CHECK(hipMemcpyAsync(t.p, &tot, 8, hipMemcpyHostToDevice, l.stream));
-      if (ncclAllReduce(t.p, t.p, 1, ncclDouble, ncclSum, l.comm, l.stream) != ncclSuccess)
-        throw CommError("ncclAllReduce(deltaH) failed");
+      l.comm->allreduce(t.p, 1, COMM_F64, COMM_SUM, l.stream);
       HIP_CHECK(hipMemcpyAsync(&tot, t.p, 8, hipMemcpyDeviceToHost, l.stream));
       sync(l);
     }
@@ -2215,20 +2200,23 @@ int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* tota
 }
 
 int osc_comm_unique_id(char id_out[128]) {
-  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
-  ncclUniqueId id;
-  if (ncclGetUniqueId(&id) != ncclSuccess) return OSC_E_COMM;
-  std::memcpy(id_out, &id, 128);
+  try {
+    comm_rccl_id(id_out);
+  } catch (const std::exception&) {
+    return OSC_E_COMM;
+  }
+  return OSC_OK;
+}
+
+int osc_comm_loopback_id(char id_out[128]) {
+  comm_loopback_id(id_out);
   return OSC_OK;
 }
 
 int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world) {
   return guarded(h, [&](L& l) {
     if (world < 1 || rank < 0 || rank >= world) throw Invalid("osc_comm_init: bad rank/world");
-    if (l.comm) {
-      (void)ncclCommDestroy(l.comm);
-      l.comm = nullptr;
-    }
+    l.comm.reset();
     l.rank = rank;
     l.world = world;
     // column slabs in units of 4 floats, as even as possible
@@ -2241,12 +2229,40 @@ int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world)
       l.c1 = l.dcols;
     }
     if (l.c1 <= l.c0) throw Invalid("osc_comm_init: more ranks than 4-column groups");
-    {
-      ncclUniqueId uid;
-      std::memcpy(&uid, id, 128);
-      if (ncclCommInitRank(&l.comm, world, uid, rank) != ncclSuccess) throw CommError("ncclCommInitRank failed");
-    }
+    l.comm = comm_create(id, rank, world, l.device);
     l.have_ustar = false;
+  });
+}
+
+int osc_comm_allreduce_f64(osc_handle h, double* vals, int32_t n, int32_t op) {
+  return guarded(h, [&](L& l) {
+    if (n < 0 || (n > 0 && !vals) || (op != 0 && op != 1)) throw Invalid("osc_comm_allreduce_f64: bad arguments");
+    sync(l);  // also the barrier use: everything this rank enqueued so far has finished
+    if (!l.comm || n == 0) {
+      if (l.comm) {  // n == 0: pure barrier
+        DevBuf<double> t;
+        t.alloc(1);
+        HIP_CHECK(hipMemsetAsync(t.p, 0, 8, l.stream));
+        l.comm->allreduce(t.p, 1, COMM_F64, COMM_SUM, l.stream);
+        sync(l);
+      }
+      return;
+    }
+    DevBuf<double> t;
+    t.alloc((size_t)n);
+    HIP_CHECK(hipMemcpyAsync(t.p, vals, (size_t)n * 8, hipMemcpyHostToDevice, l.stream));
+    l.comm->allreduce(t.p, (size_t)n, COMM_F64, op == 0 ? COMM_SUM : COMM_MAX, l.stream);
+    HIP_CHECK(hipMemcpyAsync(vals, t.p, (size_t)n * 8, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+  });
+}
+
+int osc_comm_info(osc_handle h, int32_t* rank, int32_t* world, int32_t* shard_mode, char* kind_out, int32_t cap) {
+  return guarded(h, [&](L& l) {
+    if (rank) *rank = l.comm ? l.rank : 0;
+    if (world) *world = l.comm ? l.world : 1;
+    if (shard_mode) *shard_mode = l.shard_mode;
+    if (kind_out && cap > 0) snprintf(kind_out, (size_t)cap, "%s", l.comm ? l.comm->kind() : "none");
   });
 }
 

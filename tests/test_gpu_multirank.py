@@ -1,0 +1,253 @@
+"""The NATIVE multi-rank paths of liboscillink_hip.so executed at world 2, 3 and 8 on one MI355X through the loopback
+communicator (include/oscillink_hip.h: osc_comm_loopback_id): the ranks are threads of this process, each with its own
+lattice handle and stream on the same GPU, and the library runs exactly the code it runs under RCCL -- unequal column
+slabs and their gather, grouped row-block / halo exchanges, fp64 column-sum all-reduces, the sharded kNN list
+all-gather, the speculative iteration enqueued ahead of each residual read-back -- with the collectives served by
+device-to-device copies between host barriers.  Results are held to the same fixtures and tolerances as the
+single-GPU tests (tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+from tests._cases import load_case, make_inputs, random_gates, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+WORLDS = [2, 3, 8]
+FIXTURES = ["c2_n1200_d128_k16", "g1_n400_d64_k6_chain8", "gates_chain_n333_d50_k7"]  # D = 128, 64, 50 (52 padded)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import oscillink_amd
+    from oscillink_amd import _native
+
+    assert _native.device_count() >= 1, "no HIP device: the GPU tests must run on the MI355X box"
+    return oscillink_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oscillink_oracle
+
+    return oscillink_oracle
+
+
+def _ranks(world, fn):
+    from oscillink_amd.sharding import run_loopback_ranks
+
+    return run_loopback_ranks(world, fn)
+
+
+def _configure(lat, case, rc, psi):
+    gates = None
+    if rc["gates"] == "random":
+        gates = random_gates(rc)
+    elif rc["gates"] == "diffusion":
+        gates = case["gates"]
+    lat.set_query(psi, gates=gates)
+    if rc["chain"]:
+        lat.add_chain(rc["chain"], lamP=rc["lamP"])
+
+
+def _solve_and_collect(lat, rc):
+    """The collective call sequence every rank runs; returns everything the asserts need."""
+    st = dict(lat.settle(max_iters=rc["settle_max_iters"], tol=rc["settle_tol"]))
+    hist = lat.residual_history()
+    U = lat.U.copy()  # collective in column-sharded runs (gather of the slabs)
+    Us = lat.solve_Ustar().copy()
+    us = dict(lat.last_ustar)
+    hist_u = lat.residual_history()
+    lat.set_receipt_detail(rc["detail"])
+    rec = lat.receipt()
+    import ctypes as C
+
+    kind = C.create_string_buffer(16)
+    rank, world, mode = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    lat._call("osc_comm_info", C.byref(rank), C.byref(world), C.byref(mode), kind, 16)
+    return {"st": st, "hist": hist, "U": U, "Us": Us, "us": us, "hist_u": hist_u, "rec": rec,
+            "comm": (int(rank.value), int(world.value), int(mode.value), kind.value.decode())}
+
+
+def _assert_matches_fixture(out, case, rc, world, mode):
+    for r, o in enumerate(out):
+        assert o["comm"] == (r, world, mode, "loopback")
+        assert o["st"]["iters"] == int(case["settle_iters"])
+        assert len(o["hist"]) == len(case["hist_settle"])
+        assert np.allclose(o["hist"], case["hist_settle"], rtol=2e-2, atol=1e-7)
+        assert o["st"]["res"] == pytest.approx(float(case["settle_res"]), rel=2e-2, abs=1e-7)
+        assert o["us"]["iters"] == int(case["ustar_iters"])
+        assert np.allclose(o["hist_u"], case["hist_ustar"], rtol=2e-2, atol=1e-7)
+        if "U" in case:
+            assert relerr(o["U"], case["U"]) < 2e-5
+            assert relerr(o["Us"], case["Ustar"]) < 2e-5
+        assert np.allclose(o["U"].sum(axis=1), case["U_rowsum"], rtol=1e-4, atol=1e-3)
+        assert np.allclose(o["Us"].sum(axis=1), case["Ustar_rowsum"], rtol=1e-4, atol=1e-3)
+        rec = o["rec"]
+        assert rec["deltaH_total"] == pytest.approx(float(case["deltaH"]), rel=TOL)
+        if rc["detail"] == "full":
+            assert rec["coh_drop_sum"] == pytest.approx(float(case["coh_drop_sum"]), rel=TOL)
+            assert len(rec["null_points"]) == int(case["n_nulls"])
+    for o in out[1:]:  # every rank leaves with the same state, bit for bit
+        assert np.array_equal(o["U"], out[0]["U"]) and np.array_equal(o["Us"], out[0]["Us"])
+        assert o["hist"] == out[0]["hist"] and o["rec"]["deltaH_total"] == out[0]["rec"]["deltaH_total"]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("world", WORLDS)
+def test_column_sharded_solves_on_loopback_ranks(amd, name, world, monkeypatch):
+    """Column-sharded CG (the default): rank r owns a column slab (unequal widths at D = 50 / 64 over 3 or 8 ranks),
+    one all-reduce(max) of the residual per iteration, slabs gathered when U / U* are read."""
+    monkeypatch.delenv("OSC_SHARD", raising=False)
+    case = load_case(name)
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    csr = (case["indptr"].astype(np.int64), case["indices"].astype(np.int32), case["A_data"].astype(np.float32))
+
+    def rank_fn(rank, comm):
+        lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], comm=comm, _build_graph=False)
+        lat.set_graph_csr(*csr)
+        _configure(lat, case, rc, psi)
+        return _solve_and_collect(lat, rc)
+
+    _assert_matches_fixture(_ranks(world, rank_fn), case, rc, world, 0)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("world", WORLDS)
+def test_row_sharded_solves_on_loopback_ranks(amd, name, world, monkeypatch):
+    """Row-sharded CG (the north-star wording): rank r owns a row block, exchanges the off-partition rows of the
+    search direction every iteration and completes the column sums with fp64 all-reduces."""
+    monkeypatch.setenv("OSC_SHARD", "row")
+    case = load_case(name)
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    csr = (case["indptr"].astype(np.int64), case["indices"].astype(np.int32), case["A_data"].astype(np.float32))
+
+    def rank_fn(rank, comm):
+        lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], comm=comm, _build_graph=False)
+        lat.set_graph_csr(*csr)
+        _configure(lat, case, rc, psi)
+        return _solve_and_collect(lat, rc)
+
+    _assert_matches_fixture(_ranks(world, rank_fn), case, rc, world, 1)
+
+
+@pytest.mark.parametrize("name", FIXTURES + ["c1_n80_d128_k8", "nondet_n256_d32_k5"])
+@pytest.mark.parametrize("world", WORLDS)
+def test_row_block_sharded_knn_build_on_loopback_ranks(amd, name, world, monkeypatch):
+    """The lattice build under a communicator: each rank computes the top-k lists of its 128-row blocks, one
+    all-gather assembles them, every rank finishes the mutual test / cap / weights -- same graph as the reference's."""
+    monkeypatch.delenv("OSC_SHARD", raising=False)
+    case = load_case(name)
+    rc = case["recipe"]
+    Y, _ = make_inputs(rc)
+
+    def rank_fn(rank, comm):
+        lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], comm=comm)
+        return lat.graph_csr()
+
+    for rowptr, col, a, w, sd in _ranks(world, rank_fn):
+        assert np.array_equal(rowptr, case["indptr"]) and np.array_equal(col, case["indices"])
+        assert np.allclose(a, case["A_data"], rtol=1e-5, atol=1e-8)
+        assert np.allclose(sd, case["sqrt_deg"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["column", "row"])
+def test_end_to_end_sharded_build_and_solve_vs_oracle(amd, orc, mode, monkeypatch):
+    """D = 100 (25 four-column groups over 3 ranks: slabs of 32 / 32 / 36 columns), N = 3000 over three 128-row-block
+    shards, sharded build followed by sharded solves, against the oracle on the same inputs."""
+    monkeypatch.setenv("OSC_SHARD", mode)
+    rng = np.random.default_rng(11)
+    N, D, k, world = 3000, 100, 12, 3
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    gates = rng.uniform(0.2, 1.0, size=N).astype(np.float32)
+    ref = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True, dense=False)
+    ref.set_query(psi, gates=gates)
+    ref.add_chain([5, 900, 2100, 2999], lamP=0.3)
+    rs = ref.settle(max_iters=12, tol=1e-4)
+    U_ref = ref.U.copy()
+    Us_ref = ref.solve_Ustar()
+    dH_ref = ref.deltaH(Us_ref)
+
+    def rank_fn(rank, comm):
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True, comm=comm)
+        lat.set_query(psi, gates=gates)
+        lat.add_chain([5, 900, 2100, 2999], lamP=0.3)
+        st = dict(lat.settle(max_iters=12, tol=1e-4))
+        rows = lat._fetch_rows(1, np.array([0, 1499, 2999]))  # osc_get_rows on a sharded U: collective gather first
+        U = lat.U.copy()
+        Us = lat.solve_Ustar().copy()
+        lat.set_receipt_detail("light")
+        return st, rows, U, Us, lat.receipt()["deltaH_total"], lat.last_ustar["iters"], lat.graph_csr()
+
+    R = ref.A.tocsr()
+    for st, rows, U, Us, dH, ui, (rp, col, a, w, sd) in _ranks(world, rank_fn):
+        assert np.array_equal(rp, R.indptr) and np.array_equal(col, R.indices)
+        assert st["iters"] == rs["iters"] and st["res"] == pytest.approx(rs["res"], rel=2e-2)
+        assert np.array_equal(rows, U[[0, 1499, 2999]])
+        assert relerr(U, U_ref) < 2e-5 and relerr(Us, Us_ref) < 2e-5
+        assert ui == ref.last_ustar["iters"]
+        assert dH == pytest.approx(dH_ref, rel=TOL)
+
+
+@pytest.mark.parametrize("mode", ["column", "row"])
+def test_stop_points_around_the_speculative_iteration(amd, mode, monkeypatch):
+    """The host enqueues iteration it+1 (its kernels AND its collectives) before it reads iteration it's residual.
+    Three stop points on every rank: convergence exactly at max_iters (no speculative iteration was enqueued),
+    convergence before max_iters (the speculative iteration's collectives run gated-off on every rank), and no
+    convergence at all (max_iters hit).  State and iteration counts must equal the single-handle run's."""
+    monkeypatch.setenv("OSC_SHARD", mode)
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    case = load_case("c2_n1200_d128_k16")
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    csr = (case["indptr"].astype(np.int64), case["indices"].astype(np.int32), case["A_data"].astype(np.float32))
+    conv = int(case["settle_iters"])
+
+    def run(lat):
+        out = []
+        for max_iters in (conv, conv + 5, conv - 2):
+            lat.reset_U()
+            st = dict(lat.settle(max_iters=max_iters, tol=rc["settle_tol"]))
+            out.append((st["iters"], st["res"], lat.residual_history(), lat.U.copy()))
+        return out
+
+    single = amd.Oscillink(Y, kneighbors=rc["k"], _build_graph=False)
+    single.set_graph_csr(*csr)
+    single.set_query(psi)
+    want = run(single)
+    assert [w[0] for w in want] == [conv, conv, conv - 2]
+
+    def rank_fn(rank, comm):
+        lat = amd.Oscillink(Y, kneighbors=rc["k"], comm=comm, _build_graph=False)
+        lat.set_graph_csr(*csr)
+        lat.set_query(psi)
+        return run(lat)
+
+    for got in _ranks(4, rank_fn):
+        for (gi, gr, gh, gU), (wi, wr, wh, wU) in zip(got, want):
+            assert gi == wi and len(gh) == len(wh)
+            assert np.allclose(gh, wh, rtol=1e-3 if mode == "row" else 1e-6)
+            assert relerr(gU, wU) < 2e-6  # same recurrences; only the summation order inside a row differs
+
+
+def test_mismatched_collective_sequences_fail_instead_of_hanging(amd, monkeypatch):
+    """A rank that skips a collective must surface as an error on every rank (bounded barrier), not as a hang."""
+    monkeypatch.setenv("OSC_LOOPBACK_TIMEOUT_S", "2")
+    monkeypatch.delenv("OSC_SHARD", raising=False)
+    rng = np.random.default_rng(3)
+    Y = rng.standard_normal((200, 16)).astype(np.float32)
+    from oscillink_amd._native import NativeError
+
+    def rank_fn(rank, comm):
+        lat = amd.Oscillink(Y, kneighbors=5, comm=comm)
+        lat.set_query(Y[0])
+        if rank == 0:
+            return "skipped"
+        with pytest.raises(NativeError):
+            lat.settle()
+        return "raised"
+
+    assert _ranks(2, rank_fn) == ["skipped", "raised"]
