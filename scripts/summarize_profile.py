@@ -66,6 +66,13 @@ for k, cs in pmc.items():
     if "TCC_HIT_sum_mean" in e and "TCC_MISS_sum_mean" in e:
         e["l2_hit_rate"] = e["TCC_HIT_sum_mean"] / max(1.0, e["TCC_HIT_sum_mean"] + e["TCC_MISS_sum_mean"])
     out[k] = e
-json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+# the build the counters belong to: bench.py only quotes `traffic` from a profile whose lib_hash equals the running
+# library's source hash (oscillink_amd/liboscillink_hip.so.stamp)
+try:
+    stamp = open(os.path.join(root, "oscillink_amd", "liboscillink_hip.so.stamp")).read().strip()
+except OSError:
+    stamp = None
+meta = {"lib_hash": stamp, "tag": tag, "workload": "python3 bench.py (config 3, one GPU)"}
+json.dump({"_meta": meta, **out}, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 for k, e in sorted(out.items()):
     print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in e.items()})

@@ -123,3 +123,39 @@ def test_signature_json_fast_path_equals_json_dumps():
               np.array([1.0, 0.0, 1.0], dtype=np.float32)):
         plain = json.dumps({**rest, "B": np.round(B, 6).tolist()}, sort_keys=True)
         assert L._signature_json(rest, B) == plain
+
+
+def _rdzv_worker(rank, world, port, q):
+    import os
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_PORT"] = str(port)
+    import bench
+
+    r = bench.FileRendezvous(rank, world)
+    if rank == 0:
+        r.put("uid", bytes(range(128)))
+    uid = r.get("uid", timeout_s=120)
+    got = r.gather("vals", str(rank * 1.5).encode(), timeout_s=120)
+    r.gather("done", b"1", timeout_s=120)
+    r.close()
+    q.put((rank, uid == bytes(range(128)), [float(g.decode()) for g in got]))
+
+
+def test_bench_file_rendezvous_between_processes():
+    """bench.py's launcher-independent rendezvous (communicator id, fallback barrier / max) across 3 processes."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port = 3, 29000 + os.getpid() % 1000
+    ps = [ctx.Process(target=_rdzv_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=240) for _ in range(world))
+    for p in ps:
+        p.join(30)
+    assert [o[0] for o in out] == [0, 1, 2]
+    assert all(o[1] for o in out)
+    assert all(o[2] == [0.0, 1.5, 3.0] for o in out)
