@@ -19,6 +19,14 @@ namespace osc {
 
 namespace {
 
+// max that PROPAGATES NaN (fmaxf drops it): a column that diverged to NaN / Inf must reach the stop test as NaN, like
+// np.linalg.norm(...).max() of the reference (solver.py:29) -- the solve then runs to max_iters and reports res = NaN.
+// The canonical NaN's bit pattern (0x7FC00000) is above every non-negative float's, so the uint atomicMax keeps it.
+__device__ __forceinline__ float nanmax(float a, float b) {
+  return (a != a || b != b) ? __uint_as_float(0x7FC00000u) : fmaxf(a, b);
+}
+
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // streaming store (written once, not re-read by this kernel): keeps the gathered operand's lines in the caches
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(1024) void k_reduce_beta(const float* part_rr, cons
   }
   if ((threadIdx.x >> 6) == 0) {  // wave 0 holds the 64 column residuals of this block
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) resc = fmaxf(resc, __shfl_xor(resc, o, 64));
+    for (int o = 32; o > 0; o >>= 1) resc = nanmax(resc, __shfl_xor(resc, o, 64));
     if ((threadIdx.x & 63) == 0) {
       atomicMax(res_bits, __float_as_uint(resc));  // non-negative floats order as uints
       if (host_slot != nullptr) {
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(256) void k_finish_beta(const double* srr, const do
     rz[col] = srz[col];
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) resc = fmaxf(resc, __shfl_xor(resc, o, 64));
+  for (int o = 32; o > 0; o >>= 1) resc = nanmax(resc, __shfl_xor(resc, o, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(res_bits, __float_as_uint(resc));
 }
 

@@ -284,11 +284,18 @@ hipEvent_t prof_event(L& h) {
   HIP_CHECK(hipEventCreate(&e));
   return e;
 }
-void prof_drain(L& h) {
+// never throws when `nothrow` (the ProfScope destructor drains on overflow, and destructors must not throw): samples
+// whose events cannot be read are dropped
+void prof_drain(L& h, bool nothrow = false) {
   for (auto& s : h.prof_pending) {
-    HIP_CHECK(hipEventSynchronize(s.b));
     float ms = 0.f;
-    HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));
+    hipError_t e = hipEventSynchronize(s.b);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, s.a, s.b);
+    if (e != hipSuccess) {
+      if (!nothrow) hip_check(e, "profile event read-back", __FILE__, __LINE__);
+      (void)hipGetLastError();
+      s.which = -1;
+    }
     if (s.which >= 0) {
       h.prof_count[s.which] += 1;
       h.prof_ms[s.which] += ms;
@@ -315,7 +322,7 @@ struct ProfScope {
     if (on) {
       (void)hipEventRecord(s.b, h.stream);
       h.prof_pending.push_back(s);
-      if (h.prof_pending.size() > 8192) prof_drain(h);
+      if (h.prof_pending.size() > 8192) prof_drain(h, true);
     }
   }
 };
@@ -899,11 +906,16 @@ struct CgBuffers {  // the arrays one solve works on (all N x ld)
   const float* B;
   const float* psi;
   int32_t ld, c0, c1;
+  // When X aliases x0 / rhsU (the in-place warm-started settle), a path that cannot guarantee it completes -- the
+  // one-launch small kernel may give up at its barrier -- writes here instead and reports it in CgResult::sol, so a
+  // failed attempt never leaves the caller's state partly advanced.  nullptr: X is never aliased.
+  float* Xalt = nullptr;
 };
 
 struct CgResult {
   int iters;
   float res;
+  float* sol = nullptr;  // the buffer that holds the solution (b.X, or b.Xalt)
 };
 
 // cg_solve (solver.py:6-37) on the device; returns after the stream is idle.
@@ -934,8 +946,13 @@ bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, 
   a.col_t = h.ell_col_t.p;
   a.w_t = h.ell_w_t.p;
   a.op = op;
+  float* xout = b.X;
+  if (b.X == b.x0 || b.X == b.rhsU || b.X == b.rhsY) {  // never hand the one-launch kernel an aliased output
+    if (!b.Xalt) return false;
+    xout = b.Xalt;
+  }
   a.x0 = b.x0;
-  a.X = b.X;
+  a.X = xout;
   a.U = b.rhsU;
   a.Y = b.rhsY;
   a.B = b.B;
@@ -954,7 +971,7 @@ bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, 
   std::memcpy(&st, h.res_host + 2 * nslots, 4);
   if (st != 0) return false;  // barrier timeout (GPU shared with other persistent work): take the general path
   h.history.clear();
-  out = CgResult{max_iters, 0.f};
+  out = CgResult{max_iters, 0.f, xout};
   for (int it = 1; it <= max_iters; ++it) {
     const float res = h.res_host[it];
     h.history.push_back(res);
@@ -1089,7 +1106,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   };
 
   h.history.clear();
-  CgResult out{max_iters, 0.f};
+  CgResult out{max_iters, 0.f, b.X};
   const size_t prof_mark = h.prof_pending.size();
   enqueue_iter(1);
   for (int it = 1; it <= max_iters; ++it) {
@@ -1273,7 +1290,7 @@ CgResult run_cg_rows(L& h, const OpParams& op, const CgBuffers& b, bool with_pat
   };
 
   h.history.clear();
-  CgResult out{max_iters, 0.f};
+  CgResult out{max_iters, 0.f, b.X};
   const size_t prof_mark = h.prof_pending.size();
   enqueue_iter(1);
   for (int it = 1; it <= max_iters; ++it) {
@@ -1607,21 +1624,43 @@ int osc_set_csr(osc_handle h, const int64_t* rowptr, const int32_t* col, const f
     }
     const int64_t nnz = rowptr[l.N];
     if (nnz > 0 && (!col || !a)) throw Invalid("osc_set_csr: col / a missing");
-    alloc_ell(l, (int32_t)width);
-    const size_t n = (size_t)l.N * l.width;
+    const size_t W = (size_t)std::max<int64_t>(1, width);  // validated on the host before the handle is touched
+    const size_t n = (size_t)l.N * W;
     std::vector<int32_t> hc(n, 0), hd((size_t)l.N, 0);
     std::vector<float> ha(n, 0.f);
+    // The graph contract of every consumer (GraphView): columns ascending within a row (the reference's argwhere order
+    // for _signature, the first-max tie-break of the null points), no diagonal, no duplicates, symmetric (SPD operator).
+    std::vector<std::pair<int32_t, float>> ent;
     for (int64_t i = 0; i < l.N; ++i) {
-      int cnt = 0;
+      ent.clear();
       for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
         if (col[p] < 0 || col[p] >= l.N) throw Invalid("osc_set_csr: column index out of range");
         if (!(a[p] > 0.f)) continue;  // only strictly positive weights are edges (graph.py:64)
-        hc[(size_t)i * l.width + cnt] = col[p];
-        ha[(size_t)i * l.width + cnt] = a[p];
-        ++cnt;
+        if (col[p] == i) throw Invalid("osc_set_csr: diagonal entry (the lattice adjacency has a zero diagonal)");
+        ent.emplace_back(col[p], a[p]);
       }
-      hd[(size_t)i] = cnt;
+      std::sort(ent.begin(), ent.end());
+      for (size_t e = 1; e < ent.size(); ++e)
+        if (ent[e].first == ent[e - 1].first) throw Invalid("osc_set_csr: duplicate column within a row");
+      for (size_t e = 0; e < ent.size(); ++e) {
+        hc[(size_t)i * W + e] = ent[e].first;
+        ha[(size_t)i * W + e] = ent[e].second;
+      }
+      hd[(size_t)i] = (int32_t)ent.size();
     }
+    for (int64_t i = 0; i < l.N; ++i) {  // symmetry: (j, i) exists with the same weight
+      const int32_t* ci = hc.data() + (size_t)i * W;
+      for (int e = 0; e < hd[(size_t)i]; ++e) {
+        const int32_t j = ci[e];
+        const int32_t* cj = hc.data() + (size_t)j * W;
+        const int32_t* hit = std::lower_bound(cj, cj + hd[(size_t)j], (int32_t)i);
+        if (hit == cj + hd[(size_t)j] || *hit != i) throw Invalid("osc_set_csr: adjacency is not symmetric (missing transposed edge)");
+        const float x = ha[(size_t)i * W + e], y = ha[(size_t)j * W + (hit - cj)];
+        if (std::fabs(x - y) > 1e-6f * std::max(std::fabs(x), std::fabs(y)))
+          throw Invalid("osc_set_csr: adjacency is not symmetric (A_ij != A_ji)");
+      }
+    }
+    alloc_ell(l, (int32_t)W);
     HIP_CHECK(hipMemcpyAsync(l.ell_col.p, hc.data(), n * 4, hipMemcpyHostToDevice, l.stream));
     HIP_CHECK(hipMemcpyAsync(l.ell_a.p, ha.data(), n * 4, hipMemcpyHostToDevice, l.stream));
     HIP_CHECK(hipMemcpyAsync(l.deg.p, hd.data(), (size_t)l.N * 4, hipMemcpyHostToDevice, l.stream));
@@ -1764,9 +1803,10 @@ int osc_settle(osc_handle h, float dt, int32_t max_iters, float tol, int32_t pre
     // (as x0 and as the rhs term), which then has no x0 copy to write, and there is nothing to swap afterwards.
     const bool in_place = x0 == l.U.p && !row_mode(l);
     CgBuffers b{x0, in_place ? l.U.p : l.X.p, l.R.p, l.P.p, l.AP.p, l.U.p, l.Y.p, l.B.p, l.psi.p, l.ld, l.c0, l.c1};
+    if (in_place) b.Xalt = l.X.p;  // free in an in-place solve
     // when x0 aliases AP the INIT pass reads it completely before the first SPMM_AP launch writes AP: same stream
     const CgResult r = run_cg(l, op, b, path_active(l), max_iters, tol);
-    if (!in_place) l.U.swap(l.X);  // U <- U+ (lattice.py:206)
+    if (r.sol == l.X.p) l.U.swap(l.X);  // U <- U+ (lattice.py:206); an in-place solve left it in U already
     if (l.comm && l.world > 1 && l.shard_mode == 0) {
       // the swapped-in buffer only holds this rank's columns; the others are refreshed lazily by osc_get_U.
       l.u_sharded = true;

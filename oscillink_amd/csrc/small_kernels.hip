@@ -171,15 +171,20 @@ __global__ __launch_bounds__(T) void k_settle_small(const SmallArgs a) {
     if (tid == 0) {
       float mx = 0.f;
 #pragma unroll
-      for (int c = 0; c < C; ++c) mx = fmaxf(mx, (float)sqrt(tot[c]));
+      for (int c = 0; c < C; ++c) {  // NaN propagates (fmaxf would drop it): solver.py:29 reports NaN for a diverged column
+        const float v = (float)sqrt(tot[c]);
+        mx = (v != v || mx != mx) ? __uint_as_float(0x7FC00000u) : fmaxf(mx, v);
+      }
       atomicMax(a.res_bits + it, __float_as_uint(mx));
       __threadfence();
       atomicAdd(a.arrive + it, 1u);
-      unsigned spins = 0;
       int fail = 0;
+      const uint64_t t_start = wall_clock64();  // 100 MHz constant clock
       while (__hip_atomic_load(a.arrive + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 24)) {  // never hang the GPU: report and let the host take the general path
+        // never hang the GPU: when the grid is not co-resident (another persistent grid holds CUs) give up after 5 ms,
+        // report, and let the host take the general path (the output buffer is never the caller's state: osc_api.hip)
+        if (wall_clock64() - t_start > 500000ull) {
           fail = 1;
           break;
         }
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(T) void k_settle_small(const SmallArgs a) {
     for (int c = 0; c < C; ++c) rz[c] = tot2[c];
     __syncthreads();
   }
+  if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;  // another block gave up
   for (int row = tid; row < N; row += T) {
 #pragma unroll
     for (int c = 0; c < C; ++c)

@@ -804,17 +804,15 @@ class OscillinkLattice:
     # ------------------------------------------------------------------ rebuild (lattice.py:760-801)
     def rebuild_graph(self, *, row_cap_val: Optional[float] = None, kneighbors: Optional[int] = None,
                       deterministic_k: Optional[bool] = None, neighbor_seed: Optional[int] = None) -> None:
-        if row_cap_val is not None:
-            self._row_cap_val = float(row_cap_val)
-        if kneighbors is not None:
-            self._kneighbors = min(int(kneighbors), max(1, self.N - 1))
-        if deterministic_k is not None:
-            self._deterministic_k = bool(deterministic_k)
-        if neighbor_seed is not None:
-            self._neighbor_seed = neighbor_seed
+        # the new parameters become the object's only after the device accepted them: a failed rebuild must not leave
+        # the Python side describing a graph the device does not hold (_kneighbors feeds _signature and the HMAC payload)
+        cap = self._row_cap_val if row_cap_val is None else float(row_cap_val)
+        k = self._kneighbors if kneighbors is None else min(int(kneighbors), max(1, self.N - 1))
+        det = self._deterministic_k if deterministic_k is None else bool(deterministic_k)
+        seed = self._neighbor_seed if neighbor_seed is None else neighbor_seed
         t0 = time.time()
-        self._call("osc_rebuild_graph", int(self._kneighbors), float(self._row_cap_val), int(self._deterministic_k),
-                   -1 if self._neighbor_seed is None else int(self._neighbor_seed))
+        self._call("osc_rebuild_graph", int(k), float(cap), int(det), -1 if seed is None else int(seed))
+        self._row_cap_val, self._kneighbors, self._deterministic_k, self._neighbor_seed = cap, k, det, seed
         self._graph_build_ms = 1000.0 * (time.time() - t0)
         self._csr = None
         self._touch()

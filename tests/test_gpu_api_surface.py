@@ -307,3 +307,71 @@ def test_signature_edge_prefix_matches_the_full_csr(amd, reorder, monkeypatch):
     assert lean.dtype == np.int64 and np.array_equal(lean, full) and lean.shape == (2048, 2)
     lat._sig_cache = None
     assert lat._signature() == sig_lean
+
+
+def test_injected_csr_is_normalised_and_validated(amd):
+    """set_graph_csr / `lat.A = ...` (from_state, lattice.py:709-713): rows handed over in any column order give the
+    same lattice (state signature, null points) as sorted ones; diagonal entries, duplicate columns and asymmetric
+    input are refused (the CG and the receipts assume a symmetric zero-diagonal adjacency)."""
+    lat = _lattice(amd, N=60, D=10, k=6, deterministic_k=True)
+    rowptr, col, a, _, _ = lat.graph_csr()
+    sig = lat._signature()
+    rng = np.random.default_rng(1)
+    col2, a2 = col.copy(), a.copy()
+    for i in range(lat.N):  # shuffle every row
+        s, e = rowptr[i], rowptr[i + 1]
+        p = rng.permutation(e - s)
+        col2[s:e], a2[s:e] = col[s:e][p], a[s:e][p]
+    other = amd.OscillinkLattice(lat.Y, kneighbors=6, deterministic_k=True, _build_graph=False)
+    other.set_graph_csr(rowptr, col2, a2)
+    other.set_query(lat.psi)
+    r2, c2, w2, _, _ = other.graph_csr()
+    assert np.array_equal(r2, rowptr) and np.array_equal(c2, col) and np.array_equal(w2, a)
+    assert other._signature() == sig
+    # diagonal entry
+    bad_col = col.copy()
+    bad_col[rowptr[3]] = 3
+    with pytest.raises(ValueError):
+        other.set_graph_csr(rowptr, bad_col, a)
+    # duplicate column within a row
+    if rowptr[5 + 1] - rowptr[5] >= 2:
+        dup = col.copy()
+        dup[rowptr[5] + 1] = dup[rowptr[5]]
+        with pytest.raises(ValueError):
+            other.set_graph_csr(rowptr, dup, a)
+    # asymmetric weight, then a missing transposed edge
+    asym = a.copy()
+    asym[0] *= 1.5
+    with pytest.raises(ValueError):
+        other.set_graph_csr(rowptr, col, asym)
+    keep = np.ones(col.size, dtype=bool)
+    keep[0] = False
+    rp = rowptr.copy()
+    rp[1:] -= 1
+    with pytest.raises(ValueError):
+        other.set_graph_csr(rp, col[keep], a[keep])
+    # a refused injection leaves the previous graph in place
+    assert np.array_equal(other.graph_csr()[1], col) and other._signature() == sig
+
+
+@pytest.mark.parametrize("small", ["0", "1"])
+def test_diverged_column_reports_nan_like_the_reference(amd, small, monkeypatch):
+    """solver.py:29: `np.linalg.norm(r, axis=0).max()` propagates NaN, the stop test is never met, the solve runs to
+    max_iters and reports res = NaN.  (A max that drops NaN would report the finite columns' residual and 'converge'.)"""
+    monkeypatch.setenv("OSC_SMALL_PATH", small)
+    lat = _lattice(amd, N=200, D=16, k=6)
+    U = lat.U.copy()
+    U[7, 3] = np.nan
+    lat.U = U
+    st = lat.settle(max_iters=6, tol=1e-3)
+    assert st["iters"] == 6 and np.isnan(st["res"])
+    out = lat.U
+    assert np.isnan(out[:, 3]).any() and np.isfinite(np.delete(out, 3, axis=1)).all()
+
+
+def test_failed_rebuild_keeps_the_python_state(amd):
+    lat = _lattice(amd, N=40, D=12, k=5)
+    before = (lat._kneighbors, lat._row_cap_val, lat._deterministic_k, lat._signature())
+    with pytest.raises(ValueError):
+        lat.rebuild_graph(kneighbors=0)
+    assert (lat._kneighbors, lat._row_cap_val, lat._deterministic_k, lat._signature()) == before
