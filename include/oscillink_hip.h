@@ -197,6 +197,14 @@ int osc_comm_shard(osc_handle h, int32_t* c0, int32_t* c1);
 /* rank / world (0 / 1 without a communicator), shard_mode 0 = column-sharded CG, 1 = row-sharded; kind_out receives
  * "none", "rccl" or "loopback" */
 int osc_comm_info(osc_handle h, int32_t* rank, int32_t* world, int32_t* shard_mode, char* kind_out, int32_t cap);
+/* Row-sharded CG only (OSC_SHARD=row): the halo of this rank -- need_rows = off-partition rows its lattice rows (and
+ * chain) reference, i.e. the rows of the search direction it receives every iteration; need_rows_max = the largest
+ * such count over the ranks; remote_rows = N - own rows; bytes_per_iteration = inbound bytes of one exchange;
+ * full_exchange != 0: the lists cover more than 70 % of the remote rows on some rank (unstructured graph), so whole
+ * row blocks are exchanged instead (OSC_HALO=lists|full forces either).  Builds the plan on first use per graph:
+ * COLLECTIVE (every rank must call it), OSC_E_STATE without a row-sharded communicator. */
+int osc_halo_info(osc_handle h, int64_t* need_rows, int64_t* need_rows_max, int64_t* remote_rows,
+                  int64_t* bytes_per_iteration, int32_t* full_exchange);
 /* Drains the handle's stream, then all-reduces n host doubles in place over the handle's communicator (op 0 = sum,
  * 1 = max); n = 0 is a pure barrier.  Without a communicator: stream drain only.  What a benchmark harness needs for
  * "barrier + max over ranks" without any other distributed runtime. */

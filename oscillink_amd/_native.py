@@ -71,6 +71,7 @@ SIGNATURES = {
     "osc_comm_loopback_id": (C.c_int, [C.c_char_p]),
     "osc_comm_init": (C.c_int, [Handle, C.c_char_p, C.c_int32, C.c_int32]),
     "osc_comm_info": (C.c_int, [Handle, c_i32p, c_i32p, c_i32p, C.c_char_p, C.c_int32]),
+    "osc_halo_info": (C.c_int, [Handle, c_i64p, c_i64p, c_i64p, c_i64p, c_i32p]),
     "osc_comm_allreduce_f64": (C.c_int, [Handle, c_f64p, C.c_int32, C.c_int32]),
     "osc_comm_shard": (C.c_int, [Handle, c_i32p, c_i32p]),
 }

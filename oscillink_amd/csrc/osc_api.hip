@@ -232,6 +232,17 @@ struct osc_lattice {
   int fake_row_shards = 0; // test hook (OSC_ROW_FAKE_SHARDS=V): V row shards on this one GPU, collectives local
   DevBuf<double> sums;     // [2][ld] completed column sums of the row-sharded CG
   DevBuf<float> comm_buf;
+  // halo plan of the row-sharded CG (built on first use per graph / chain / communicator: graph_epoch)
+  uint64_t graph_epoch = 1;
+  struct HaloPlan {
+    uint64_t epoch = 0;                      // graph_epoch it was built for (0 = none)
+    bool full = false;                       // halo ~ everything: exchange whole row blocks instead (all-gather)
+    std::vector<int64_t> give_off, need_off; // [world + 1] offsets of each peer's slice in give_idx / need_idx
+    DevBuf<int32_t> give_idx, need_idx;      // my rows each peer needs (sorted) / the peers' rows I need (sorted)
+    DevBuf<float> send, recv;                // packed rows
+    int64_t need_rows = 0, give_rows = 0;    // this rank
+    int64_t need_rows_max = 0;               // max over ranks
+  } halo;
   // profiling
   bool prof_on = false;
   std::vector<ProfSlot> prof_pending;
@@ -461,6 +472,7 @@ void graph_counts(L& h) {
 
 void alloc_ell(L& h, int32_t width) {
   h.ell_t_ready = false;
+  ++h.graph_epoch;
   h.width = std::max<int32_t>(1, width);
   const size_t n = (size_t)h.N * h.width;
   h.ell_col.alloc(n);
@@ -478,6 +490,7 @@ bool permuted(const L& h) { return !h.perm_h.empty(); }
 
 // path Laplacian structures from the stored chain (graph.py:96-111), in the handle's current row order
 void install_chain(L& l) {
+  ++l.graph_epoch;
   if (!l.chain_present) return;
   const int32_t len = (int32_t)l.chain_nodes.size();
   auto id = [&](int32_t v) { return permuted(l) ? l.inv_h[(size_t)v] : v; };
@@ -559,6 +572,7 @@ void move_state(L& l, const int32_t* from_d, const int32_t* relabel_d) {
   l.ell_t_ready = false;
   l.have_ustar = false;
   l.u_sharded = false;
+  ++l.graph_epoch;
 }
 
 void drop_order(L& l) {  // back to the API's row order
@@ -617,7 +631,9 @@ std::vector<int32_t> bfs_order(L& l) {
 void maybe_reorder(L& l) {
   l.reordered = false;
   l.clustering = 0.0;
-  if (l.reorder == 0 || l.comm != nullptr || l.N < 2) return;
+  // under a communicator only the row-sharded CG re-orders (every rank holds the same graph and takes the same
+  // deterministic decision and order; the halo lists shrink with locality); the column-sharded default keeps API order
+  if (l.reorder == 0 || (l.comm != nullptr && l.shard_mode != 1) || l.N < 2) return;
   if (l.reorder < 0) {
     if (l.N < 8192 || l.nnz == 0) return;  // small lattices run out of LDS / L2 anyway
     DevBuf<unsigned long long> cnt;
@@ -1187,6 +1203,149 @@ void allreduce_sums(L& h, double* buf, size_t n) {
   h.comm->allreduce(buf, n, COMM_F64, COMM_SUM, h.stream);
 }
 
+
+// ---- halo lists ---------------------------------------------------------------------------------------------------
+// Which rows of the search direction a rank needs from its peers: the off-partition column ids its ELL rows (and its
+// rows of the chain's path graph) reference.  The adjacency is symmetric (by construction of the build, enforced on
+// injection), so "peer q needs my row i" == "my row i has a neighbour in q's row block": both lists of a pair of
+// ranks follow from each rank's OWN rows, sorted by row id on both sides, and no index lists are exchanged -- only the
+// counts, once, as a consistency check and to take the same full-exchange decision everywhere.
+void build_halo_plan(L& h) {
+  L::HaloPlan& hp = h.halo;
+  const int G = h.world, me = h.rank;
+  auto lo = [&](int r) { return h.N * r / G; };
+  auto owner = [&](int64_t row) {  // rank whose block [N r / G, N (r+1) / G) holds `row`
+    int r = (int)std::min<int64_t>(G - 1, (row * G + G - 1) / std::max<int64_t>(1, h.N));
+    while (r > 0 && row < lo(r)) --r;
+    while (r + 1 < G && row >= lo(r + 1)) ++r;
+    return r;
+  };
+  const int64_t r0 = lo(me), r1 = lo(me + 1), nloc = r1 - r0;
+  std::vector<int32_t> col((size_t)nloc * h.width), deg((size_t)nloc);
+  if (nloc > 0) {
+    HIP_CHECK(hipMemcpyAsync(col.data(), h.ell_col.p + (size_t)r0 * h.width, col.size() * 4, hipMemcpyDeviceToHost, h.stream));
+    HIP_CHECK(hipMemcpyAsync(deg.data(), h.deg.p + r0, (size_t)nloc * 4, hipMemcpyDeviceToHost, h.stream));
+  }
+  sync(h);
+  std::vector<std::vector<int32_t>> need((size_t)G), give((size_t)G);
+  std::vector<char> need_mark((size_t)h.N, 0);
+  std::vector<int> give_last((size_t)G);
+  auto edge = [&](int64_t i, int64_t j) {  // my row i references row j
+    if (j >= r0 && j < r1) return;
+    if (!need_mark[(size_t)j]) {
+      need_mark[(size_t)j] = 1;
+      need[(size_t)owner(j)].push_back((int32_t)j);
+    }
+  };
+  for (int64_t i = r0; i < r1; ++i) {
+    std::fill(give_last.begin(), give_last.end(), 0);
+    auto touch = [&](int64_t j) {
+      edge(i, j);
+      if (j >= r0 && j < r1) return;
+      const int q = owner(j);
+      if (!give_last[(size_t)q]) {
+        give_last[(size_t)q] = 1;
+        give[(size_t)q].push_back((int32_t)i);
+      }
+    };
+    const int32_t* ci = col.data() + (size_t)(i - r0) * h.width;
+    for (int e = 0; e < deg[(size_t)(i - r0)]; ++e) touch(ci[e]);
+  }
+  if (h.chain_present && h.lamP > 0.0f) {  // path graph: consecutive chain nodes (graph.py:96-111), device row ids
+    auto id = [&](int32_t v) { return permuted(h) ? h.inv_h[(size_t)v] : v; };
+    std::vector<std::vector<int32_t>> extra_give((size_t)G);
+    for (size_t t = 0; t + 1 < h.chain_nodes.size(); ++t) {
+      const int64_t a = id(h.chain_nodes[t]), b = id(h.chain_nodes[t + 1]);
+      for (int dir = 0; dir < 2; ++dir) {
+        const int64_t i = dir ? b : a, j = dir ? a : b;
+        if (i < r0 || i >= r1 || (j >= r0 && j < r1)) continue;
+        edge(i, j);
+        extra_give[(size_t)owner(j)].push_back((int32_t)i);
+      }
+    }
+    for (int q = 0; q < G; ++q)
+      for (int32_t i : extra_give[(size_t)q]) give[(size_t)q].push_back(i);
+  }
+  hp.give_off.assign((size_t)G + 1, 0);
+  hp.need_off.assign((size_t)G + 1, 0);
+  std::vector<int32_t> gi, ni;
+  for (int q = 0; q < G; ++q) {
+    auto& g = give[(size_t)q];
+    std::sort(g.begin(), g.end());
+    g.erase(std::unique(g.begin(), g.end()), g.end());
+    auto& n = need[(size_t)q];
+    std::sort(n.begin(), n.end());
+    gi.insert(gi.end(), g.begin(), g.end());
+    ni.insert(ni.end(), n.begin(), n.end());
+    hp.give_off[(size_t)q + 1] = (int64_t)gi.size();
+    hp.need_off[(size_t)q + 1] = (int64_t)ni.size();
+  }
+  hp.give_rows = (int64_t)gi.size();
+  hp.need_rows = (int64_t)ni.size();
+  // counts of every (rank, peer) pair, all-gathered: row r = [need from 0..G-1 | give to 0..G-1] of rank r
+  DevBuf<int32_t> cnt_d;
+  cnt_d.alloc((size_t)G * 2 * G);
+  std::vector<int32_t> mine((size_t)2 * G), all((size_t)G * 2 * G);
+  for (int q = 0; q < G; ++q) {
+    mine[(size_t)q] = (int32_t)(hp.need_off[(size_t)q + 1] - hp.need_off[(size_t)q]);
+    mine[(size_t)G + q] = (int32_t)(hp.give_off[(size_t)q + 1] - hp.give_off[(size_t)q]);
+  }
+  HIP_CHECK(hipMemcpyAsync(cnt_d.p + (size_t)me * 2 * G, mine.data(), (size_t)2 * G * 4, hipMemcpyHostToDevice, h.stream));
+  h.comm->allgather(cnt_d.p, (size_t)2 * G * 4, h.stream);
+  HIP_CHECK(hipMemcpyAsync(all.data(), cnt_d.p, all.size() * 4, hipMemcpyDeviceToHost, h.stream));
+  sync(h);
+  hp.need_rows_max = 0;
+  bool full = false;
+  for (int r = 0; r < G; ++r) {
+    int64_t tot = 0;
+    for (int q = 0; q < G; ++q) {
+      tot += all[(size_t)r * 2 * G + q];
+      if (all[(size_t)r * 2 * G + q] != all[(size_t)q * 2 * G + G + r])  // r needs from q == q gives to r
+        throw CommError("halo plan: need / give counts of a rank pair differ (asymmetric lattice graph?)");
+    }
+    hp.need_rows_max = std::max(hp.need_rows_max, tot);
+    const int64_t remote = h.N - (lo(r + 1) - lo(r));
+    if (remote > 0 && (double)tot > 0.7 * (double)remote) full = true;  // packing would move ~everything anyway
+  }
+  const char* fe = getenv("OSC_HALO");  // "full" | "lists": force one exchange form (tests, A/B); same on every rank
+  const int force = fe ? (!strcmp(fe, "full") ? 1 : !strcmp(fe, "lists") ? 2 : 0) : 0;
+  if (force == 1) full = true;
+  if (force == 2) full = false;
+  hp.full = full;
+  hp.give_idx.alloc(std::max<size_t>(1, gi.size()));
+  hp.need_idx.alloc(std::max<size_t>(1, ni.size()));
+  if (!gi.empty()) HIP_CHECK(hipMemcpyAsync(hp.give_idx.p, gi.data(), gi.size() * 4, hipMemcpyHostToDevice, h.stream));
+  if (!ni.empty()) HIP_CHECK(hipMemcpyAsync(hp.need_idx.p, ni.data(), ni.size() * 4, hipMemcpyHostToDevice, h.stream));
+  if (!full) {
+    hp.send.alloc(std::max<size_t>(1, gi.size() * (size_t)h.ld));
+    hp.recv.alloc(std::max<size_t>(1, ni.size() * (size_t)h.ld));
+  }
+  sync(h);
+  hp.epoch = h.graph_epoch;
+}
+
+// the per-iteration halo exchange of `arr` (N x ld, every rank's own row block current): afterwards the rows this
+// rank's operator gathers from are current too
+void halo_exchange(L& h, float* arr, int32_t ld) {
+  if (!h.comm) return;
+  if (h.halo.epoch != h.graph_epoch) build_halo_plan(h);
+  L::HaloPlan& hp = h.halo;
+  if (hp.full || ld != h.ld) {
+    exchange_rows(h, arr, ld);
+    return;
+  }
+  if (hp.give_rows > 0) launch_move_rows(hp.send.p, arr, hp.give_idx.p, hp.give_rows, ld, false, h.stream);  // pack
+  std::vector<CommXfer> sends, recvs;
+  for (int q = 0; q < h.world; ++q) {
+    const int64_t g0 = hp.give_off[(size_t)q], g1 = hp.give_off[(size_t)q + 1];
+    const int64_t n0 = hp.need_off[(size_t)q], n1 = hp.need_off[(size_t)q + 1];
+    if (g1 > g0) sends.push_back(CommXfer{hp.send.p + (size_t)g0 * ld, (size_t)(g1 - g0) * ld * 4, q});
+    if (n1 > n0) recvs.push_back(CommXfer{hp.recv.p + (size_t)n0 * ld, (size_t)(n1 - n0) * ld * 4, q});
+  }
+  h.comm->exchange(sends, recvs, h.stream);
+  if (hp.need_rows > 0) launch_move_rows(arr, hp.recv.p, hp.need_idx.p, hp.need_rows, ld, true, h.stream);  // unpack
+}
+
 CgResult run_cg_rows(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol) {
   const std::vector<RowShard> shards = row_shards(h);
   const int V = (int)shards.size();
@@ -1250,7 +1409,7 @@ CgResult run_cg_rows(L& h, const OpParams& op, const CgBuffers& b, bool with_pat
   launch_reduce_sum(h.part0.p, V * grid, b.ld, b.c0, b.c1, s0, h.stream);
   allreduce_sums(h, s0 + b.c0, (size_t)(b.c1 - b.c0));
   launch_finish_init(s0, b.c0, b.c1, h.rz.p, h.stream);
-  exchange_rows(h, b.P, b.ld);
+  halo_exchange(h, b.P, b.ld);
   sa.X = b.P;
   sa.OUT = b.AP;
 
@@ -1267,7 +1426,7 @@ CgResult run_cg_rows(L& h, const OpParams& op, const CgBuffers& b, bool with_pat
         ProfScope ps(h, 2, it);
         for_windows(ua, [&](const UpdateArgs& w) { launch_update_p(w, grid, h.stream); });
       }
-      exchange_rows(h, b.P, b.ld);  // the halo exchange of this iteration
+      halo_exchange(h, b.P, b.ld);  // the halo exchange of this iteration
     }
     for_shards_spmm(SPMM_AP, it);
     launch_reduce_sum_gated(h.part0.p, V * grid, b.ld, b.c0, b.c1, s0, g, h.stream);
@@ -1724,6 +1883,7 @@ int osc_clear_chain(osc_handle h) {
     l.chain_present = false;
     l.lamP = 0.0f;
     l.have_ustar = false;
+    ++l.graph_epoch;
   });
 }
 
@@ -2270,6 +2430,7 @@ int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world)
     }
     if (l.c1 <= l.c0) throw Invalid("osc_comm_init: more ranks than 4-column groups");
     l.comm = comm_create(id, rank, world, l.device);
+    ++l.graph_epoch;
     l.have_ustar = false;
   });
 }
@@ -2303,6 +2464,21 @@ int osc_comm_info(osc_handle h, int32_t* rank, int32_t* world, int32_t* shard_mo
     if (world) *world = l.comm ? l.world : 1;
     if (shard_mode) *shard_mode = l.shard_mode;
     if (kind_out && cap > 0) snprintf(kind_out, (size_t)cap, "%s", l.comm ? l.comm->kind() : "none");
+  });
+}
+
+int osc_halo_info(osc_handle h, int64_t* need_rows, int64_t* need_rows_max, int64_t* remote_rows,
+                  int64_t* bytes_per_iteration, int32_t* full_exchange) {
+  return guarded(h, [&](L& l) {
+    if (!l.comm || l.shard_mode != 1) throw StateError("osc_halo_info: no row-sharded communicator on this handle");
+    require_graph(l);
+    if (l.halo.epoch != l.graph_epoch) build_halo_plan(l);
+    const int64_t own = l.N * (l.rank + 1) / l.world - l.N * l.rank / l.world;
+    if (need_rows) *need_rows = l.halo.need_rows;
+    if (need_rows_max) *need_rows_max = l.halo.need_rows_max;
+    if (remote_rows) *remote_rows = l.N - own;
+    if (bytes_per_iteration) *bytes_per_iteration = (l.halo.full ? (l.N - own) : l.halo.need_rows) * (int64_t)l.ld * 4;
+    if (full_exchange) *full_exchange = l.halo.full ? 1 : 0;
   });
 }
 

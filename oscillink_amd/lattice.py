@@ -227,6 +227,14 @@ class OscillinkLattice:
                 "reordered": int(ro.value), "clustering": float(cc.value), "apply_launches": int(ln.value),
                 "apply_slab_cols": int(sc.value), "apply_xs_workgroups": int(xw.value)}
 
+    def halo_info(self) -> dict[str, int]:
+        """Row-sharded runs (OSC_SHARD=row under a communicator): the rows of the search direction this rank receives
+        per CG iteration.  Collective on first use per graph (include/oscillink_hip.h: osc_halo_info)."""
+        need, need_max, remote, nbytes, full = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        self._call("osc_halo_info", C.byref(need), C.byref(need_max), C.byref(remote), C.byref(nbytes), C.byref(full))
+        return {"need_rows": int(need.value), "need_rows_max": int(need_max.value), "remote_rows": int(remote.value),
+                "bytes_per_iteration": int(nbytes.value), "full_exchange": int(full.value)}
+
     def graph_csr(self):
         """Sparse lattice graph: (rowptr int64 (N+1), col int32, A float32 (capped adjacency), W float32, sqrt_deg)."""
         return self._host_csr()

@@ -115,10 +115,14 @@ def test_column_sharded_solves_on_loopback_ranks(amd, name, world, monkeypatch):
 
 @pytest.mark.parametrize("name", FIXTURES)
 @pytest.mark.parametrize("world", WORLDS)
-def test_row_sharded_solves_on_loopback_ranks(amd, name, world, monkeypatch):
+@pytest.mark.parametrize("halo", ["lists", "full"])
+def test_row_sharded_solves_on_loopback_ranks(amd, name, world, halo, monkeypatch):
     """Row-sharded CG (the north-star wording): rank r owns a row block, exchanges the off-partition rows of the
-    search direction every iteration and completes the column sums with fp64 all-reduces."""
+    search direction every iteration -- as packed halo lists (grouped send / recv of exactly the rows its lattice rows
+    and chain reference) or, where the lists would cover almost everything, as whole row blocks -- and completes the
+    column sums with fp64 all-reduces.  Both exchange forms are forced through every fixture."""
     monkeypatch.setenv("OSC_SHARD", "row")
+    monkeypatch.setenv("OSC_HALO", halo)
     case = load_case(name)
     rc = case["recipe"]
     Y, psi = make_inputs(rc)
@@ -251,3 +255,46 @@ def test_mismatched_collective_sequences_fail_instead_of_hanging(amd, monkeypatc
         return "raised"
 
     assert _ranks(2, rank_fn) == ["skipped", "raised"]
+
+
+def test_halo_lists_shrink_with_graph_locality(amd, monkeypatch):
+    """Clustered anchors handed over in shuffled order (scripts/locality_demo.py's generator, scaled down): the lattice
+    is re-ordered breadth-first on every rank, so a rank's off-partition neighbours are few -- the halo must stay under
+    15 % of the remote rows (north_star: 'halo all-gather for off-partition neighbour rows'), be exchanged as lists, and
+    the row-sharded solve must reproduce the single-handle solve.  i.i.d. anchors of the same size need ~everything
+    and fall back to whole row blocks."""
+    monkeypatch.setenv("OSC_SHARD", "row")
+    monkeypatch.delenv("OSC_HALO", raising=False)
+    monkeypatch.delenv("OSC_REORDER", raising=False)
+    rng = np.random.default_rng(7)
+    N, D, k, world, n_clusters = 16384, 64, 16, 4, 256
+    centers = rng.standard_normal((n_clusters, D)).astype(np.float32)
+    lab = np.repeat(np.arange(n_clusters), N // n_clusters)
+    Yc = (centers[lab] + 0.35 * rng.standard_normal((N, D)).astype(np.float32)).astype(np.float32)
+    Yc = Yc[rng.permutation(N)]
+    Yi = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+
+    for Y, want_lists in ((Yc, True), (Yi, False)):
+        single = amd.Oscillink(Y, kneighbors=k)
+        single.set_query(psi)
+        single.add_chain([3, 9000, 12, 16000], lamP=0.2)
+        ss = dict(single.settle(max_iters=12, tol=1e-4))
+        U_single = single.U.copy()
+
+        def rank_fn(rank, comm, Y=Y):
+            lat = amd.Oscillink(Y, kneighbors=k, comm=comm)
+            lat.set_query(psi)
+            lat.add_chain([3, 9000, 12, 16000], lamP=0.2)
+            info = lat.halo_info()
+            st = dict(lat.settle(max_iters=12, tol=1e-4))
+            return info, lat.build_info()["reordered"], st, lat.U.copy()
+
+        for info, reordered, st, U in _ranks(world, rank_fn):
+            assert st["iters"] == ss["iters"] and relerr(U, U_single) < 2e-5
+            if want_lists:
+                assert reordered == 1 and info["full_exchange"] == 0
+                assert info["need_rows_max"] < 0.15 * info["remote_rows"], info
+                assert info["bytes_per_iteration"] == info["need_rows"] * 64 * 4
+            else:
+                assert info["full_exchange"] == 1 and info["need_rows_max"] > 0.7 * info["remote_rows"]
