@@ -54,9 +54,13 @@ const char* osc_last_error(osc_handle h);               /* h may be NULL: error 
  * :69-83 (row_sum_cap), :86-93 (normalized_laplacian).  k is clamped to [1, N-1] (lattice.py:60).
  * deterministic != 0 -> ties ordered (similarity desc, index asc) (graph.py:46-49); the
  * non-deterministic reference path leaves ties unspecified (graph.py:59) and this build uses the
- * same total order for it.  seed < 0 means None; seed >= 0 is accepted and, like the reference's
- * jitter (graph.py:54-58, magnitude 1e-8 < fp32 resolution of the similarities), only ever affects
- * exact ties, which the total order already resolves.
+ * same total order for it.  seed < 0 means None.  seed >= 0 (`neighbor_seed`): the reference adds a float64
+ * uniform(-1e-8, 1e-8) jitter drawn from default_rng(seed) to all N^2 similarities before its argpartition
+ * (graph.py:54-58).  fp32 similarities below 0.125 are spaced 7.5e-9 apart (3.7e-9 below 0.0625), so that jitter can
+ * reorder exact ties AND candidates within 1-2 ulp of each other at the k-th place; reproducing it bit for bit would
+ * need the same N^2 random stream.  This build treats the seed as a tie-break only: the neighbour lists are those of
+ * the total order above, i.e. they can differ from the reference's seeded lists only where two candidates for the
+ * last list place are 1-2 ulp apart (tests/golden/case_seed_*.npz: identical edge sets on Gaussian anchors).
  * build_graph == 0: no graph yet; call osc_set_csr (from_state / parity tests). */
 int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, int32_t deterministic,
                int64_t seed, int32_t device, int32_t build_graph, osc_handle* out);
@@ -167,6 +171,24 @@ int osc_null_points(osc_handle h, float z_th, int32_t* i_out, int32_t* j_out, fl
 /* components + null points in ONE pass over the edges (what receipt() in "full" detail needs; lattice.py:320-332) */
 int osc_receipt_rows(osc_handle h, float z_th, float* coh_drop, float* anchor_pen, float* query_term, int32_t* i_out,
                      int32_t* j_out, float* z_out, float* r_out, int32_t* count);
+
+/* ---- dynamics snapshot: _compute_dynamics (lattice.py:825-927, env-gated OSCILLINK_RECEIPT_DYNAMICS) -------------- */
+/* U_prev <- U on the device; call right before osc_settle (replaces the reference's `U_prev = self.U.copy()`,
+ * lattice.py:213-216, without moving N x D floats to the host) */
+int osc_dynamics_snapshot(osc_handle h);
+/* Metrics of the step U_prev -> U_next, all on the device.  U_prev / U_next: host N x D arrays, or NULL for the
+ * snapshot taken by osc_dynamics_snapshot / the resident U.
+ *   move2_mean, move2_max : mean and max over nodes of ||U_next_i - U_prev_i||^2 (temperature = move2_mean)
+ *   step_deltaH           : deltaH_trace(U_prev, U_next, ...) (receipts.py:10-25), chain term at any N
+ *   flow_total, top_*     : per directed edge f = max(0, 0.5 lamC A_ij (||Up_i-Up_j||^2 - ||Un_i-Un_j||^2)) with
+ *                           Up = U_prev/(sqrt_deg+1e-12), Un likewise; their sum and the top_cap (<= 32; the reference
+ *                           keeps 16) largest in the reference's order (flow desc, then (i, j) asc)
+ *   radius                : largest BFS hop distance over the lattice graph from the nodes with
+ *                           sqrt(move2 + 1e-12) >= 0.1 * max (0 when nothing moved)
+ * Any output pointer may be NULL. */
+int osc_dynamics(osc_handle h, const float* U_prev_or_null, const float* U_next_or_null, double* move2_mean,
+                 float* move2_max, double* step_deltaH, double* flow_total, int32_t top_cap, int32_t* top_i,
+                 int32_t* top_j, double* top_flow, int32_t* top_n, int32_t* radius);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the handle's own stream.  which: 0 = operator apply inside the CG loop (SpMM, the

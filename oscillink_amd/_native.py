@@ -64,6 +64,9 @@ SIGNATURES = {
     "osc_receipt_components": (C.c_int, [Handle, c_f32p, c_f32p, c_f32p]),
     "osc_null_points": (C.c_int, [Handle, C.c_float, c_i32p, c_i32p, c_f32p, c_f32p, c_i32p]),
     "osc_receipt_rows": (C.c_int, [Handle, C.c_float, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_i32p]),
+    "osc_dynamics_snapshot": (C.c_int, [Handle]),
+    "osc_dynamics": (C.c_int, [Handle, c_f32p, c_f32p, c_f64p, c_f32p, c_f64p, c_f64p, C.c_int32, c_i32p, c_i32p, c_f64p,
+                               c_i32p, c_i32p]),
     "osc_profile_enable": (C.c_int, [Handle, C.c_int32]),
     "osc_profile_reset": (C.c_int, [Handle]),
     "osc_profile_get": (C.c_int, [Handle, C.c_int32, c_i64p, c_f64p]),

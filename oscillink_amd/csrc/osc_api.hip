@@ -15,6 +15,7 @@
 #include "knn.hpp"
 #include "receipts.hpp"
 #include "perm.hpp"
+#include "dynamics.hpp"
 #include "small.hpp"
 
 using namespace osc;
@@ -167,6 +168,8 @@ struct osc_lattice {
   // state (N x ld, row-major)
   DevBuf<float> Y, U, X, R, P, AP, Ustar;
   bool have_ustar = false;
+  DevBuf<float> Uprev;  // state before the last settle (dynamics snapshot, lattice.py:825-927); allocated on first use
+  bool have_uprev = false;
   DevBuf<float> B, psi;
   float lamG = 1.0f, lamC = 0.5f, lamQ = 4.0f;
   // graph (ELL)
@@ -2205,57 +2208,239 @@ int osc_ustar_cosine_to(osc_handle h, const float* psi, float* out) {
   });
 }
 
+// sum (A - B) . M (A - B) with the stationary operator M = lamG I + lamC L + lamQ B (+ lamP L_path)  (receipts.py:21-25)
+// over this rank's share (column window / row block), completed over the communicator
+static double quad_form_of_difference(L& l, const float* A, const float* B) {
+  ensure_cg_scratch(l, 1);
+  launch_axpby(l.P.p, A, 1.0f, B, -1.0f, (int64_t)l.N * l.ld, l.stream);
+  const int grid = cg_grid(l);
+  SpmmArgs sa{};
+  sa.g = graph_view(l, path_active(l));
+  sa.op = ustar_op(l);
+  sa.X = l.P.p;
+  sa.B = l.B.p;
+  sa.psi = l.psi.p;
+  sa.ld = l.ld;
+  sa.c0 = l.c0;
+  sa.c1 = l.c1;
+  sa.gate = nullptr;
+  int nb = grid;
+  if (row_mode(l)) {  // each rank (or fake shard) sums its own rows; the scalar is all-reduced below
+    const std::vector<RowShard> shards = row_shards(l);
+    nb = (int)shards.size() * grid;
+    if (l.part0.n < (size_t)nb * l.ld) l.part0.alloc((size_t)nb * l.ld);
+    for (size_t si = 0; si < shards.size(); ++si) {
+      sa.row0 = shards[si].r0;
+      sa.N = shards[si].r1;
+      sa.part = l.part0.p + si * grid * l.ld;
+      spmm_slabbed(l, SPMM_DOT, sa, grid);
+    }
+  } else {
+    sa.part = l.part0.p;
+    sa.N = l.N;
+    spmm_slabbed(l, SPMM_DOT, sa, grid);
+  }
+  launch_reduce_sum(l.part0.p, nb, l.ld, l.c0, l.c1, l.colsum.p, l.stream);
+  std::vector<double> cs((size_t)l.ld, 0.0);
+  HIP_CHECK(hipMemcpyAsync(cs.data() + l.c0, l.colsum.p + l.c0, (size_t)(l.c1 - l.c0) * 8, hipMemcpyDeviceToHost,
+                           l.stream));
+  sync(l);
+  double tot = 0.0;
+  for (int c = l.c0; c < l.c1; ++c) tot += cs[(size_t)c];
+  if (l.comm) {
+    DevBuf<double> t;
+    t.alloc(1);
+    HIP_CHECK(hipMemcpyAsync(t.p, &tot, 8, hipMemcpyHostToDevice, l.stream));
+    l.comm->allreduce(t.p, 1, COMM_F64, COMM_SUM, l.stream);
+    HIP_CHECK(hipMemcpyAsync(&tot, t.p, 8, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+  }
+  return tot;
+}
+
 int osc_deltaH(osc_handle h, double* dH) {
   return guarded(h, [&](L& l) {
     require_graph(l);
     if (!l.have_ustar) throw StateError("osc_deltaH: no resident U* (call osc_solve_ustar first)");
     if (!dH) throw Invalid("osc_deltaH: dH is NULL");
-    ensure_cg_scratch(l, 1);
-    // diff = U - U*  ;  deltaH = sum diff . M diff   (receipts.py:21-25)
-    launch_axpby(l.P.p, l.U.p, 1.0f, l.Ustar.p, -1.0f, (int64_t)l.N * l.ld, l.stream);
-    const int grid = cg_grid(l);
-    SpmmArgs sa{};
-    sa.g = graph_view(l, path_active(l));
-    sa.op = ustar_op(l);
-    sa.X = l.P.p;
-    sa.B = l.B.p;
-    sa.psi = l.psi.p;
-    sa.ld = l.ld;
-    sa.c0 = l.c0;
-    sa.c1 = l.c1;
-    sa.gate = nullptr;
-    int nb = grid;
-    if (row_mode(l)) {  // each rank (or fake shard) sums its own rows; the scalar is all-reduced below
-      const std::vector<RowShard> shards = row_shards(l);
-      nb = (int)shards.size() * grid;
-      if (l.part0.n < (size_t)nb * l.ld) l.part0.alloc((size_t)nb * l.ld);
-      for (size_t si = 0; si < shards.size(); ++si) {
-        sa.row0 = shards[si].r0;
-        sa.N = shards[si].r1;
-        sa.part = l.part0.p + si * grid * l.ld;
-        spmm_slabbed(l, SPMM_DOT, sa, grid);
-      }
-    } else {
-      sa.part = l.part0.p;
-      sa.N = l.N;
-      spmm_slabbed(l, SPMM_DOT, sa, grid);
+    *dH = quad_form_of_difference(l, l.U.p, l.Ustar.p);  // diff = U - U*
+  });
+}
+
+// N x D host array in API row order -> N x ld device array in device row order (AP is scratch between solves)
+static void upload_api_order(L& l, float* dst, const float* src) {
+  if (permuted(l)) {
+    upload_rows(l, l.AP.p, src);
+    launch_move_rows(dst, l.AP.p, l.perm_d.p, l.N, l.ld, false, l.stream);
+  } else {
+    upload_rows(l, dst, src);
+  }
+}
+
+int osc_dynamics_snapshot(osc_handle h) {
+  return guarded(h, [&](L& l) {
+    if (l.u_sharded) {  // collective in column-sharded runs, like osc_get_U
+      gather_columns(l, l.U.p);
+      l.u_sharded = false;
     }
-    launch_reduce_sum(l.part0.p, nb, l.ld, l.c0, l.c1, l.colsum.p, l.stream);
-    std::vector<double> cs((size_t)l.ld, 0.0);
-    HIP_CHECK(hipMemcpyAsync(cs.data() + l.c0, l.colsum.p + l.c0, (size_t)(l.c1 - l.c0) * 8, hipMemcpyDeviceToHost,
-                             l.stream));
+    l.Uprev.alloc((size_t)l.N * l.ld);
+    HIP_CHECK(hipMemcpyAsync(l.Uprev.p, l.U.p, (size_t)l.N * l.ld * 4, hipMemcpyDeviceToDevice, l.stream));
+    l.have_uprev = true;
+  });
+}
+
+int osc_dynamics(osc_handle h, const float* U_prev, const float* U_next, double* move2_mean, float* move2_max,
+                 double* step_deltaH, double* flow_total, int32_t top_cap, int32_t* top_i, int32_t* top_j,
+                 double* top_flow, int32_t* top_n, int32_t* radius) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (top_cap < 0 || top_cap > 32 || (top_cap > 0 && (!top_i || !top_j || !top_flow || !top_n)))
+      throw Invalid("osc_dynamics: top_cap must be 0..32 with output arrays");
+    const size_t n = (size_t)l.N * l.ld;
+    if (U_prev) {
+      l.Uprev.alloc(n);
+      HIP_CHECK(hipMemsetAsync(l.Uprev.p, 0, n * 4, l.stream));
+      upload_api_order(l, l.Uprev.p, U_prev);
+      l.have_uprev = true;
+    }
+    if (!l.have_uprev) throw StateError("osc_dynamics: no previous state (call osc_dynamics_snapshot before the settle)");
+    if (l.u_sharded) {
+      gather_columns(l, l.U.p);
+      l.u_sharded = false;
+    }
+    const float* next = l.U.p;
+    DevBuf<float> next_buf;
+    if (U_next) {
+      next_buf.alloc(n);
+      HIP_CHECK(hipMemsetAsync(next_buf.p, 0, n * 4, l.stream));
+      upload_api_order(l, next_buf.p, U_next);
+      next = next_buf.p;
+    }
+    // step energy (lattice.py:843-857): the quadratic form of the stationary operator on U_prev - U_next
+    const double dH = quad_form_of_difference(l, l.Uprev.p, next);
+    if (step_deltaH) *step_deltaH = dH;
+    // movement per node and structural energy drop per edge: the receipt-rows pass with (Y, U*) := (U_prev, U_next)
+    DevBuf<float> move2, flows;
+    move2.alloc((size_t)l.N);
+    const size_t ne = (size_t)l.N * l.width;
+    flows.alloc(ne);
+    HIP_CHECK(hipMemsetAsync(flows.p, 0, ne * 4, l.stream));
+    ReceiptArgs a{};
+    a.Y = l.Uprev.p;
+    a.Ustar = next;
+    a.psi = l.psi.p;
+    a.B = l.B.p;
+    a.sqrt_deg = l.sqrt_deg.p;
+    a.col = l.ell_col.p;
+    a.adj = l.ell_a.p;
+    a.deg = l.deg.p;
+    a.width = l.width;
+    a.lamG = 1.0f;  // anchor term of the pass = ||U_next - U_prev||^2 per node
+    a.lamC = l.lamC;
+    a.lamQ = 0.0f;
+    a.z_th = 0.0f;
+    a.anchor = move2.p;
+    a.N = (int32_t)l.N;
+    a.D = l.D;
+    a.ld = l.ld;
+    a.api_id = nullptr;
+    a.edge_flow = flows.p;
+    launch_receipt_rows(a, l.stream);
+    // reductions: sum / max of the movement, sum of the flows
+    const int nb1 = (int)std::max<int64_t>(1, std::min<int64_t>((l.N + 255) / 256, 256));
+    const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ne + 255) / 256, 256));
+    DevBuf<double> ps;
+    DevBuf<float> pm;
+    ps.alloc((size_t)nb1 + nb2);
+    pm.alloc((size_t)nb1 + nb2);
+    launch_sum_max(move2.p, l.N, nb1, ps.p, pm.p, l.stream);
+    launch_sum_max(flows.p, (int64_t)ne, nb2, ps.p + nb1, pm.p + nb1, l.stream);
+    // top flows: per-block candidates (twice the cap, so both directions of a tied pair survive a block's cut)
+    const int K = top_cap > 0 ? 32 : 0;
+    const int nb3 = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ne + 4095) / 4096, 256));
+    DevBuf<float> tv;
+    DevBuf<int64_t> ti;
+    DevBuf<int32_t> tc;
+    std::vector<float> htv;
+    std::vector<int64_t> hti;
+    std::vector<int32_t> htc;
+    if (K > 0) {
+      tv.alloc((size_t)nb3 * K);
+      ti.alloc((size_t)nb3 * K);
+      tc.alloc((size_t)nb3 * K);
+      launch_top_select(flows.p, l.ell_col.p, (int64_t)ne, nb3, K, tv.p, ti.p, tc.p, l.stream);
+      htv.resize((size_t)nb3 * K);
+      hti.resize((size_t)nb3 * K);
+      htc.resize((size_t)nb3 * K);
+      HIP_CHECK(hipMemcpyAsync(htv.data(), tv.p, htv.size() * 4, hipMemcpyDeviceToHost, l.stream));
+      HIP_CHECK(hipMemcpyAsync(hti.data(), ti.p, hti.size() * 8, hipMemcpyDeviceToHost, l.stream));
+      HIP_CHECK(hipMemcpyAsync(htc.data(), tc.p, htc.size() * 4, hipMemcpyDeviceToHost, l.stream));
+    }
+    std::vector<double> hps((size_t)nb1 + nb2);
+    std::vector<float> hpm((size_t)nb1 + nb2);
+    HIP_CHECK(hipMemcpyAsync(hps.data(), ps.p, hps.size() * 8, hipMemcpyDeviceToHost, l.stream));
+    HIP_CHECK(hipMemcpyAsync(hpm.data(), pm.p, hpm.size() * 4, hipMemcpyDeviceToHost, l.stream));
     sync(l);
-    double tot = 0.0;
-    for (int c = l.c0; c < l.c1; ++c) tot += cs[(size_t)c];
-    if (l.comm) {
-      DevBuf<double> t;
-      t.alloc(1);
-      HIP_CHECK(hipMemcpyAsync(t.p, &tot, 8, hipMemcpyHostToDevice, l.stream));
-      l.comm->allreduce(t.p, 1, COMM_F64, COMM_SUM, l.stream);
-      HIP_CHECK(hipMemcpyAsync(&tot, t.p, 8, hipMemcpyDeviceToHost, l.stream));
-      sync(l);
+    double msum = 0.0, fsum = 0.0;
+    float mmax = 0.f;
+    for (int b = 0; b < nb1; ++b) {
+      msum += hps[(size_t)b];
+      mmax = (hpm[(size_t)b] != hpm[(size_t)b] || mmax != mmax) ? NAN : std::max(mmax, hpm[(size_t)b]);
     }
-    *dH = tot;
+    for (int b = 0; b < nb2; ++b) fsum += hps[(size_t)nb1 + b];
+    if (move2_mean) *move2_mean = msum / (double)l.N;
+    if (move2_max) *move2_max = mmax;
+    if (flow_total) *flow_total = fsum;
+    if (K > 0) {
+      struct Cand {
+        double f;
+        int32_t i, j;
+      };
+      std::vector<Cand> cands;
+      for (size_t t = 0; t < hti.size(); ++t) {
+        if (hti[t] < 0) continue;
+        const int32_t row = (int32_t)(hti[t] / l.width);
+        cands.push_back({(double)htv[t], permuted(l) ? l.perm_h[(size_t)row] : row,
+                         permuted(l) ? l.perm_h[(size_t)htc[t]] : htc[t]});
+      }
+      // the reference keeps the flows in argwhere order and sorts them stably by flow, descending (lattice.py:879-881)
+      std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) {
+        if (x.f != y.f) return x.f > y.f;
+        if (x.i != y.i) return x.i < y.i;
+        return x.j < y.j;
+      });
+      const int32_t m = (int32_t)std::min<size_t>((size_t)top_cap, cands.size());
+      for (int32_t t = 0; t < m; ++t) {
+        top_i[t] = cands[(size_t)t].i;
+        top_j[t] = cands[(size_t)t].j;
+        top_flow[t] = cands[(size_t)t].f;
+      }
+      *top_n = m;
+    } else if (top_n) {
+      *top_n = 0;
+    }
+    // coherence radius (lattice.py:885-892, 905-927): BFS from the nodes that moved at least 10 % of the largest move
+    if (radius) {
+      *radius = 0;
+      const float maxinf = std::sqrt(mmax + 1e-12f);
+      if (l.N > 0 && maxinf > 1e-9f) {
+        const float thr = (float)(0.1 * (double)maxinf);
+        DevBuf<int32_t> dist, changed;
+        dist.alloc((size_t)l.N);
+        changed.alloc(1);
+        launch_bfs_seeds(move2.p, l.N, thr, dist.p, l.stream);
+        int32_t level = 0;
+        for (; level < l.N; ++level) {
+          int32_t ch = 0;
+          HIP_CHECK(hipMemsetAsync(changed.p, 0, 4, l.stream));
+          launch_bfs_level(l.ell_col.p, l.deg.p, l.width, l.N, dist.p, level, changed.p, l.stream);
+          HIP_CHECK(hipMemcpyAsync(&ch, changed.p, 4, hipMemcpyDeviceToHost, l.stream));
+          sync(l);
+          if (!ch) break;
+        }
+        *radius = level;
+      }
+    }
   });
 }
 

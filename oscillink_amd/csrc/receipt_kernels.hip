@@ -13,6 +13,16 @@ namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// a * sa - b * sb with both products rounded on their own (no fma contraction): the value for edge (i, j) is then the
+// exact negation of the value for (j, i), like the reference's pre-scaled rows Un = U / (sqrt_deg + 1e-12), so the two
+// directions of an edge get bit-identical energies (the dynamics' flow ranking relies on those ties)
+__device__ __forceinline__ float sdiff(float a, float sa, float b, float sb) {
+#pragma clang fp contract(off)  // (HIP's __fmul_rn is a plain multiply and would be contracted into an fma as well)
+  const float p = a * sa;
+  const float q = b * sb;
+  return p - q;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -79,10 +89,10 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
         if (c < a.ld) {
           const float4 yi = yi_r[ch], ui = ui_r[ch];
           const float4 yj = ld4(a.Y + jo + c), uj = ld4(a.Ustar + jo + c);
-          const float y0 = yi.x * inv_i - yj.x * inv_j, y1 = yi.y * inv_i - yj.y * inv_j;
-          const float y2 = yi.z * inv_i - yj.z * inv_j, y3 = yi.w * inv_i - yj.w * inv_j;
-          const float u0 = ui.x * inv_i - uj.x * inv_j, u1 = ui.y * inv_i - uj.y * inv_j;
-          const float u2 = ui.z * inv_i - uj.z * inv_j, u3 = ui.w * inv_i - uj.w * inv_j;
+          const float y0 = sdiff(yi.x, inv_i, yj.x, inv_j), y1 = sdiff(yi.y, inv_i, yj.y, inv_j);
+          const float y2 = sdiff(yi.z, inv_i, yj.z, inv_j), y3 = sdiff(yi.w, inv_i, yj.w, inv_j);
+          const float u0 = sdiff(ui.x, inv_i, uj.x, inv_j), u1 = sdiff(ui.y, inv_i, uj.y, inv_j);
+          const float u2 = sdiff(ui.z, inv_i, uj.z, inv_j), u3 = sdiff(ui.w, inv_i, uj.w, inv_j);
           dy = fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, fmaf(y3, y3, dy))));
           du = fmaf(u0, u0, fmaf(u1, u1, fmaf(u2, u2, fmaf(u3, u3, du))));
         }
@@ -91,16 +101,20 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
       for (int c = lane * 4; c < a.ld; c += 256) {
         const float4 yi = ld4(a.Y + ro + c), yj = ld4(a.Y + jo + c);
         const float4 ui = ld4(a.Ustar + ro + c), uj = ld4(a.Ustar + jo + c);
-        const float y0 = yi.x * inv_i - yj.x * inv_j, y1 = yi.y * inv_i - yj.y * inv_j;
-        const float y2 = yi.z * inv_i - yj.z * inv_j, y3 = yi.w * inv_i - yj.w * inv_j;
-        const float u0 = ui.x * inv_i - uj.x * inv_j, u1 = ui.y * inv_i - uj.y * inv_j;
-        const float u2 = ui.z * inv_i - uj.z * inv_j, u3 = ui.w * inv_i - uj.w * inv_j;
+        const float y0 = sdiff(yi.x, inv_i, yj.x, inv_j), y1 = sdiff(yi.y, inv_i, yj.y, inv_j);
+        const float y2 = sdiff(yi.z, inv_i, yj.z, inv_j), y3 = sdiff(yi.w, inv_i, yj.w, inv_j);
+        const float u0 = sdiff(ui.x, inv_i, uj.x, inv_j), u1 = sdiff(ui.y, inv_i, uj.y, inv_j);
+        const float u2 = sdiff(ui.z, inv_i, uj.z, inv_j), u3 = sdiff(ui.w, inv_i, uj.w, inv_j);
         dy = fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, fmaf(y3, y3, dy))));
         du = fmaf(u0, u0, fmaf(u1, u1, fmaf(u2, u2, fmaf(u3, u3, du))));
       }
     }
   };
-  auto edge_finish = [&](int j, float w, float dy, float du) {  // in edge order: the reference's column order
+  auto edge_finish = [&](int e_slot, int j, float w, float dy, float du) {  // in edge order: the reference's column order
+    if (a.edge_flow != nullptr && lane == 0) {
+      const double f = 0.5 * (double)a.lamC * (double)w * ((double)dy - (double)du);
+      a.edge_flow[(size_t)row * a.width + e_slot] = (w > 0.f && f > 0.0) ? (float)f : 0.f;
+    }
     if (w > 0.f) {
       coh += 0.5f * a.lamC * w * (dy - du);
       const float R = a.lamC * w * du;
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
       du[u] = wave_sum(du[u]);
     }
 #pragma unroll
-    for (int u = 0; u < EU; ++u) edge_finish(jj[u], ww[u], dy[u], du[u]);
+    for (int u = 0; u < EU; ++u) edge_finish(e + u, jj[u], ww[u], dy[u], du[u]);
   }
   for (; e < deg; ++e) {
     const int j = crow[e];
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
     edge_terms(j, inv_j, dy, du);
     dy = wave_sum(dy);
     du = wave_sum(du);
-    edge_finish(j, w, dy, du);
+    edge_finish(e, j, w, dy, du);
   }
   if (lane == 0) {
     if (a.coh) a.coh[row] = coh;

@@ -22,6 +22,10 @@ struct ReceiptArgs {
   float* null_r;
   int32_t N, D, ld;
   const int32_t* api_id;  // device row -> API row id (nullptr = identity); ties of the argmax go to the smaller API id
+  // dynamics (lattice.py:862-883): with Y := U_prev and Ustar := U_next the per-edge structural energy drop
+  // max(0, 0.5 lamC a_ij (||Up_i - Up_j||^2 - ||Un_i - Un_j||^2)) goes to edge_flow[row * width + e] (ELL-shaped, slots
+  // past the degree untouched); nullptr = not wanted
+  float* edge_flow = nullptr;
 };
 
 void launch_receipt_rows(const ReceiptArgs& a, hipStream_t s);

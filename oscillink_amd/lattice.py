@@ -377,8 +377,9 @@ class OscillinkLattice:
                warm_start: bool = True, inertia: float = 0.0) -> dict[str, Any]:
         """Implicit Euler step (I + dt M) U+ = U + dt (lamG Y + lamQ B 1 psi^T) by Jacobi-PCG on the GPU."""
         dyn = os.getenv("OSCILLINK_RECEIPT_DYNAMICS", "0").strip().lower() in {"1", "true", "yes"}
-        U_prev = self.U.copy() if dyn else None
         self._push_params()
+        if dyn:  # device-side copy of the state before the step (the reference copies U on the host, lattice.py:213-216)
+            self._call("osc_dynamics_snapshot")
         iters, res, ms = C.c_int32(0), C.c_float(0.0), C.c_double(0.0)
         self._call("osc_settle", float(dt), int(max_iters), float(tol), 1 if precond == "jacobi" else 0,
                    int(bool(warm_start)), float(inertia), C.byref(iters), C.byref(res), C.byref(ms))
@@ -389,7 +390,7 @@ class OscillinkLattice:
             self._log("settle_convergence_warn", {"res": self.last["res"], "tol": tol, "iters": self.last["iters"]})
         if dyn:
             try:
-                self._last_dynamics = self._compute_dynamics(U_prev, self.U, self.last["iters"])
+                self._last_dynamics = self._compute_dynamics(None, None, self.last["iters"])
             except Exception:
                 self._last_dynamics = None
         for cb in list(self._settle_callbacks):
@@ -933,46 +934,29 @@ class OscillinkLattice:
         return lat
 
     # ------------------------------------------------------------------ dynamics (lattice.py:825-927), env-gated
-    def _compute_dynamics(self, U_prev: np.ndarray, U_next: np.ndarray, iters: int) -> dict[str, Any]:
-        dU = (U_next - U_prev).astype(np.float32)
-        move2 = np.sum(dU * dU, axis=1)
-        rowptr, col, a, w, sd = self._host_csr()
-        rows = np.repeat(np.arange(self.N), np.diff(rowptr))
-        # step energy: dU . M dU with the sparse operator
-        WX = np.zeros_like(dU)
-        np.add.at(WX, rows, w[:, None] * dU[col])
-        term = self.lamG * dU + self.lamC * (dU - WX) + self.lamQ * (self._B[:, None] * dU)
-        Lp = self.L_path if (self._chain_nodes is not None and self.lamP > 0 and self.N <= _DENSE_VIEW_LIMIT) else None
-        if Lp is not None:
-            term = term + self.lamP * (Lp @ dU)
-        dH_step = float(np.sum(dU * term))
-        di = sd + 1e-12
-        Up, Un = U_prev / di[:, None], U_next / di[:, None]
-        dp, dn = Up[rows] - Up[col], Un[rows] - Un[col]
-        f = np.maximum(0.0, 0.5 * self.lamC * a * (np.einsum("ij,ij->i", dp, dp) - np.einsum("ij,ij->i", dn, dn)))
-        top = np.argsort(-f, kind="stable")[:16]
-        flows = [{"edge": [int(rows[t]), int(col[t])], "flow": float(f[t])} for t in top if f[t] > 0]
-        inf = np.sqrt(move2 + 1e-12)
-        radius = 0
-        if inf.size and float(np.max(inf)) > 1e-9:
-            seeds = np.where(inf >= 0.1 * float(np.max(inf)))[0]
-            dist = np.full(self.N, -1, dtype=np.int64)
-            dist[seeds] = 0
-            frontier = seeds
-            while frontier.size:
-                nxt = []
-                for u in frontier:
-                    for v in col[rowptr[u]: rowptr[u + 1]]:
-                        if dist[v] < 0:
-                            dist[v] = dist[u] + 1
-                            nxt.append(v)
-                frontier = np.array(nxt, dtype=np.int64)
-            radius = int(np.max(dist))
-        return {"temperature": float(np.mean(move2)), "step_deltaH": dH_step,
-                "viscosity_step": float(iters) / (abs(dH_step) + 1e-12), "flow_total": float(np.sum(f)),
-                "top_flows": flows, "radius": int(radius),
-                "move2_mean": float(np.mean(move2) if move2.size else 0.0),
-                "move2_max": float(np.max(move2) if move2.size else 0.0)}
+    def _compute_dynamics(self, U_prev: Optional[np.ndarray], U_next: Optional[np.ndarray], iters: int) -> dict[str, Any]:
+        """Single-step dynamics snapshot (lattice.py:825-927) computed on the device: step energy through the operator
+        kernel, per-node movement and per-edge structural energy flows through the receipt-rows kernel, the coherence
+        radius by a level-synchronous BFS over the device graph.  `None` for U_prev / U_next means the device-side
+        snapshot taken before the settle / the resident U (what settle() uses: no N x D transfer)."""
+        TOP_K = 16
+        m2, mx, dH, ft = C.c_double(0.0), C.c_float(0.0), C.c_double(0.0), C.c_double(0.0)
+        ti = np.zeros(TOP_K, dtype=np.int32)
+        tj = np.zeros(TOP_K, dtype=np.int32)
+        tf = np.zeros(TOP_K, dtype=np.float64)
+        tn, rad = C.c_int32(0), C.c_int32(0)
+        up = None if U_prev is None else np.ascontiguousarray(U_prev, dtype=np.float32)
+        un = None if U_next is None else np.ascontiguousarray(U_next, dtype=np.float32)
+        self._call("osc_dynamics", None if up is None else nat.f32(up), None if un is None else nat.f32(un),
+                   C.byref(m2), C.byref(mx), C.byref(dH), C.byref(ft), TOP_K, nat.i32(ti), nat.i32(tj),
+                   tf.ctypes.data_as(nat.c_f64p), C.byref(tn), C.byref(rad))
+        dH_step = float(np.float32(dH.value))
+        flows = [{"edge": [int(ti[t]), int(tj[t])], "flow": float(tf[t])} for t in range(int(tn.value))]
+        temperature = float(np.float32(m2.value))
+        return {"temperature": temperature, "step_deltaH": dH_step,
+                "viscosity_step": float(iters) / (abs(dH_step) + 1e-12), "flow_total": float(ft.value),
+                "top_flows": flows, "radius": int(rad.value),
+                "move2_mean": temperature, "move2_max": float(mx.value)}
 
     def __repr__(self) -> str:  # pragma: no cover
         parts = [f"N={self.N}", f"D={self.D}", f"k={self._kneighbors}", f"lamG={self.lamG}", f"lamC={self.lamC}",

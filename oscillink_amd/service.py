@@ -1,0 +1,120 @@
+"""Adapter for the reference's cloud service: `_build_lattice` (cloud/app/main.py:887-947) on the MI355X backend.
+
+The service builds one lattice per request from a `SettleRequest` (cloud/app/models.py:26-33: `Y`, `psi`, `gates`,
+`chain`, `params.{lamG,lamC,lamQ,lamP,kneighbors,deterministic_k,neighbor_seed}`), applies optional adaptive-profile
+overrides, clamps k, and returns `(lat, N, D, k_eff, params, profile_id)`.  `build_lattice` does exactly that with
+`oscillink_amd.OscillinkLattice`, so a maintainer switches the service over with
+
+    from oscillink_amd.service import build_lattice, ServiceError      # cloud/app/main.py
+    def _build_lattice(req, api_key=None):
+        try:
+            return build_lattice(req, api_key, propose_overrides=propose_overrides)
+        except ServiceError as e:
+            raise HTTPException(status_code=e.status_code, detail=e.detail)
+
+No FastAPI / pydantic import here: the request is duck-typed (attributes or dict keys).  Environment:
+  OSCILLINK_BACKEND   "hip" (default).  Any other value is refused: this package has no CPU path (the reference itself
+                      is the CPU backend).
+  OSCILLINK_DEVICES   comma-separated HIP device ids lattices are placed on, round-robin per request (default: the
+                      OSCILLINK_DEVICE / LOCAL_RANK device, else 0).
+  OSCILLINK_MAX_NODES, OSCILLINK_MAX_DIM   the service's request limits (cloud/app/config.py:10-11; defaults 5000 / 2048
+                      there -- the device path handles N = 1M, so deployments raise them).
+"""
+from __future__ import annotations
+
+import itertools
+import os
+import threading
+from typing import Any, Callable, Optional
+
+import numpy as np
+
+from .lattice import OscillinkLattice
+
+
+class ServiceError(Exception):
+    """A request the service must answer with an HTTP error (status_code / detail as the reference's HTTPException)."""
+
+    def __init__(self, status_code: int, detail: str):
+        super().__init__(detail)
+        self.status_code = int(status_code)
+        self.detail = detail
+
+
+_rr = itertools.count()
+_rr_lock = threading.Lock()
+
+
+def backend() -> str:
+    b = os.environ.get("OSCILLINK_BACKEND", "hip").strip().lower()
+    if b not in ("hip", "mi355x", "gfx950"):
+        raise ServiceError(500, f"OSCILLINK_BACKEND={b!r}: oscillink_amd only provides the HIP (gfx950) backend")
+    return "hip"
+
+
+def devices() -> list[int]:
+    spec = os.environ.get("OSCILLINK_DEVICES", "").strip()
+    if spec:
+        return [int(t) for t in spec.split(",") if t.strip() != ""]
+    return [int(os.environ.get("OSCILLINK_DEVICE", os.environ.get("LOCAL_RANK", "0")))]
+
+
+def pick_device() -> int:
+    devs = devices()
+    with _rr_lock:
+        return devs[next(_rr) % len(devs)]
+
+
+def _get(obj: Any, name: str, default=None):
+    if isinstance(obj, dict):
+        return obj.get(name, default)
+    return getattr(obj, name, default)
+
+
+def limits() -> tuple[int, int]:
+    return int(os.environ.get("OSCILLINK_MAX_NODES", "5000")), int(os.environ.get("OSCILLINK_MAX_DIM", "2048"))
+
+
+def build_lattice(req: Any, api_key: Optional[str] = None, *,
+                  propose_overrides: Optional[Callable[..., tuple[str, dict]]] = None):
+    """`_build_lattice(req, api_key)` of the reference service: returns (lat, N, D, k_eff, params, profile_id)."""
+    backend()
+    Y = np.array(_get(req, "Y"), dtype=np.float32)
+    if Y.ndim != 2 or Y.shape[0] == 0 or Y.shape[1] == 0:
+        raise ServiceError(400, "Empty matrix")
+    N, D = Y.shape
+    max_nodes, max_dim = limits()
+    if max_nodes < N:
+        raise ServiceError(413, f"N>{max_nodes} exceeds limit")
+    if max_dim < D:
+        raise ServiceError(413, f"D>{max_dim} exceeds limit")
+    p = _get(req, "params", {}) or {}
+    base = {"lamG": _get(p, "lamG", 1.0), "lamC": _get(p, "lamC", 0.5), "lamQ": _get(p, "lamQ", 4.0),
+            "kneighbors": _get(p, "kneighbors", 6)}
+    profile_id, overrides = ("baseline", {}) if propose_overrides is None else propose_overrides(api_key, base=base)
+    lamG = float(overrides.get("lamG", base["lamG"]))
+    lamC = float(overrides.get("lamC", base["lamC"]))
+    lamQ = float(overrides.get("lamQ", base["lamQ"]))
+    k_req = int(overrides.get("kneighbors", base["kneighbors"]))
+    k_eff = min(k_req, max(1, N - 1))
+    lat = OscillinkLattice(Y, kneighbors=k_eff, lamG=lamG, lamC=lamC, lamQ=lamQ,
+                           deterministic_k=bool(_get(p, "deterministic_k", False)),
+                           neighbor_seed=_get(p, "neighbor_seed", None), device=pick_device())
+    psi = _get(req, "psi")
+    if psi is not None:
+        psi = np.array(psi, dtype=np.float32)
+        if psi.shape[0] != D:
+            raise ServiceError(400, "psi dimension mismatch")
+        lat.set_query(psi)
+    gates = _get(req, "gates")
+    if gates is not None:
+        gates = np.array(gates, dtype=np.float32)
+        if gates.shape[0] != N:
+            raise ServiceError(400, "gates length mismatch")
+        lat.set_gates(gates)
+    chain = _get(req, "chain")
+    if chain:
+        if len(chain) < 2:
+            raise ServiceError(400, "chain must have >=2 nodes")
+        lat.add_chain(list(chain), lamP=float(_get(p, "lamP", 0.0)))
+    return lat, N, D, k_eff, {"lamG": lamG, "lamC": lamC, "lamQ": lamQ, "kneighbors": k_eff}, profile_id

@@ -159,3 +159,43 @@ def test_bench_file_rendezvous_between_processes():
     assert [o[0] for o in out] == [0, 1, 2]
     assert all(o[1] for o in out)
     assert all(o[2] == [0.0, 1.5, 3.0] for o in out)
+
+
+def test_reference_signed_receipts_verify_with_the_product_verifier():
+    """Receipts signed by the REFERENCE (tests/golden/make_golden_r2.py, minimal and extended payloads,
+    lattice.py:385-425) are accepted by oscillink_amd.verify_receipt / verify_receipt_mode; tampering is refused."""
+    import copy
+    import json
+
+    from oscillink_amd import verify_receipt, verify_receipt_mode
+
+    r2 = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_r2.json")))
+    for mode in ("minimal", "extended"):
+        rec = r2["signed"][mode]
+        assert verify_receipt(rec, r2["secret"]) and not verify_receipt(rec, "wrong")
+        ok, payload = verify_receipt_mode(rec, r2["secret"], require_mode=mode)
+        assert ok and payload["mode"] == mode and payload["deltaH_total"] == rec["deltaH_total"]
+        assert not verify_receipt_mode(rec, r2["secret"], require_mode="minimal" if mode == "extended" else "extended")[0]
+        bad = copy.deepcopy(rec)
+        bad["meta"]["signature"]["payload"]["deltaH_total"] += 1.0
+        assert not verify_receipt(bad, r2["secret"])
+
+
+def test_product_signed_receipts_were_accepted_by_the_reference_verifier():
+    """tests/golden/product_signed_receipts.json: receipts signed by THIS package on the MI355X
+    (scripts/make_signed_receipt.py), then checked in the build container with the reference's own
+    verify_receipt / verify_receipt_mode (tests/golden/verify_signed_with_reference.py, core/receipts.py:86-179),
+    which recorded its verdicts in the file.  Here: the recorded verdicts, and the product verifier agrees."""
+    import json
+
+    from oscillink_amd import verify_receipt
+
+    path = os.path.join(ROOT, "tests", "golden", "product_signed_receipts.json")
+    fx = json.load(open(path))
+    assert set(fx["receipts"]) == {"minimal", "extended"}
+    for mode, rec in fx["receipts"].items():
+        v = fx["reference_verdicts"][mode]
+        assert v == {"verify_receipt": True, "verify_receipt_wrong_secret": False, "verify_receipt_mode": True,
+                     "tampered": False}
+        assert verify_receipt(rec, fx["secret"])
+        assert rec["meta"]["signature"]["payload"]["mode"] == mode
