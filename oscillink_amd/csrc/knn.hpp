@@ -30,6 +30,11 @@ void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, 
 // small lattices (N <= 4096): dense similarity matrix Sm (N x lds_ floats of scratch) + per-row selection of the k best
 void launch_knn_dense(const float* Yn, int32_t ldn, int32_t N, int32_t k, float* Sm, int32_t lds_, float* out_val,
                       int32_t* out_idx, hipStream_t s);
+// any k (the k > 128 route): rows [row_begin, row_begin + rows) of the dense similarity matrix into the scratch Sm
+// (rows_cap x lds_ floats, rows <= rows_cap, lds_ >= N) and a radix select of each row's k best columns; row_begin must
+// be a multiple of 128.  out_val / out_idx are the full N x k lists.
+void launch_knn_rows_any(const float* Yn, int32_t ldn, int32_t N, int32_t k, int32_t row_begin, int32_t rows, float* Sm,
+                         int32_t lds_, float* out_val, int32_t* out_idx, hipStream_t s);
 // rank-select the best k_out of the S*KC candidates of each row of the plan's range (or of plan.qrows)
 void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* cand_idx, int32_t N, int32_t k_out,
                       float* out_val, int32_t* out_idx, int clip, hipStream_t s);

@@ -354,13 +354,13 @@ __global__ __launch_bounds__(256, 2) void k_knn_topk(const float* __restrict__ Y
 // tile of S = Yn Yn^T (same staging, fragment order and MFMA sequence as knn_topk_body, so S is bitwise symmetric and
 // bit-identical to what the streaming kernel scores), and one wave per row then picks the k best by repeated argmax.
 __global__ __launch_bounds__(256, 2) void k_knn_dense(const float* __restrict__ Yn, int32_t ldn, int32_t N,
-                                                      float* __restrict__ Sm, int32_t lds_) {
+                                                      float* __restrict__ Sm, int32_t lds_, int32_t row_base) {
   __shared__ __attribute__((aligned(16))) float lds[2 * BM * LDT];
   float* As = lds;
   float* Bs = lds + BM * LDT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int row0 = blockIdx.y * BM, ct = blockIdx.x * BN;
+  const int row0 = row_base + blockIdx.y * BM, ct = blockIdx.x * BN;  // Sm holds the rows from row_base on
   const int nkt = ldn / BK;
   int srow[4], sc4[4];
 #pragma unroll
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_dense(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int col = ct + 32 * t + l31;
-      if (col < N) Sm[(size_t)row * lds_ + col] = acc[t][g];
+      if (col < N) Sm[(size_t)(row - row_base) * lds_ + col] = acc[t][g];
     }
   }
 }
@@ -476,6 +476,104 @@ __global__ __launch_bounds__(256) void k_knn_select(const float* __restrict__ Sm
       out_val[(size_t)row * k + r] = fmaxf(wv, 0.f);
       out_idx[(size_t)row * k + r] = wi;
     }
+  }
+}
+
+
+// ---- any k (k > 128): rows of the dense similarity matrix + radix select ------------------------------------------
+// One workgroup per row of Sm (row `row_base + blockIdx.x` of the lattice, N columns).  The k best columns in the order
+// (similarity desc, index asc), diagonal excluded: four 8-bit histogram passes over the order-preserving integer image
+// of the row find the key T of the k-th best entry and how many entries are strictly better; one ordered pass then
+// emits the better entries and, among the entries equal to T, the smallest indices until k are out (exact ties go to
+// the smaller index, graph.py:46-49).  Output lists are in index order within a row (consumers only need membership
+// and values).  Values clipped at 0 (graph.py:62).
+__device__ __forceinline__ uint32_t sim_key(float v) {  // ascending float order == ascending key order
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k_knn_select_any(const float* __restrict__ Sm, int32_t lds_, int32_t N, int32_t k,
+                                                        int32_t row_base, int32_t rows, float* out_val, int32_t* out_idx) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_prefix, s_need, s_wave[4][2], s_base[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= rows) return;
+  const int row = row_base + blockIdx.x;
+  const float* srow = Sm + (size_t)blockIdx.x * lds_;
+  // radix select of the k-th largest key among the N - 1 off-diagonal entries
+  uint32_t prefix = 0, need = (uint32_t)k;  // entries still to be taken from the current prefix class
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[tid] = 0;
+    __syncthreads();
+    const uint32_t mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int c = tid; c < N; c += 256) {
+      if (c == row) continue;
+      const uint32_t key = sim_key(srow[c]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t left = need;
+      int b = 255;
+      for (; b > 0; --b) {
+        if (hist[b] >= left) break;
+        left -= hist[b];
+      }
+      s_prefix = prefix | ((uint32_t)b << shift);
+      s_need = left;  // entries to take from bin b (the bins above it are taken whole)
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    need = s_need;
+    __syncthreads();
+  }
+  const uint32_t T = prefix;        // key of the k-th best entry
+  const uint32_t take_eq = need;    // how many entries with key == T belong to the list (smallest indices first)
+  const uint32_t n_gt = (uint32_t)k - take_eq;
+  // ordered emission: the list comes out sorted by column index (what k_mutual_ell_sorted's binary search needs); of the
+  // entries equal to T only the first take_eq in index order are emitted
+  (void)n_gt;
+  if (tid < 2) s_base[tid] = 0;
+  __syncthreads();
+  float* ov = out_val + (size_t)row * k;
+  int32_t* oi = out_idx + (size_t)row * k;
+  for (int c0 = 0; c0 < N; c0 += 256) {
+    const int c = c0 + tid;
+    float v = 0.f;
+    uint32_t key = 0;
+    const bool valid = c < N && c != row;
+    if (valid) {
+      v = srow[c];
+      key = sim_key(v);
+    }
+    const bool gt = valid && key > T, eq = valid && key == T;
+    const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t pg = (uint32_t)__popcll(bg & below), pe = (uint32_t)__popcll(be & below);
+    if (lane == 0) {
+      s_wave[wave][0] = (uint32_t)__popcll(bg);
+      s_wave[wave][1] = (uint32_t)__popcll(be);
+    }
+    __syncthreads();
+    uint32_t og = s_base[0], oe = s_base[1];  // better / equal entries before this thread's column
+    for (int w = 0; w < wave; ++w) {
+      og += s_wave[w][0];
+      oe += s_wave[w][1];
+    }
+    og += pg;
+    oe += pe;
+    if (gt || (eq && oe < take_eq)) {
+      const uint32_t pos = og + (oe < take_eq ? oe : take_eq);
+      ov[pos] = fmaxf(v, 0.f);
+      oi[pos] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s_base[0] += s_wave[0][0] + s_wave[1][0] + s_wave[2][0] + s_wave[3][0];
+      s_base[1] += s_wave[0][1] + s_wave[1][1] + s_wave[2][1] + s_wave[3][1];
+    }
+    __syncthreads();
   }
 }
 
@@ -1078,7 +1176,7 @@ void launch_knn_dense(const float* Yn, int32_t ldn, int32_t N, int32_t k, float*
                       int32_t* out_idx, hipStream_t s) {
   if (N > 8192) throw std::runtime_error("launch_knn_dense: N > 8192");
   const int nb = (N + BM - 1) / BM;
-  hipLaunchKernelGGL(k_knn_dense, dim3(nb, nb), dim3(256), 0, s, Yn, ldn, N, Sm, lds_);
+  hipLaunchKernelGGL(k_knn_dense, dim3(nb, nb), dim3(256), 0, s, Yn, ldn, N, Sm, lds_, 0);
   const dim3 grid((unsigned)((N + 3) / 4)), block(256);
   const int m = (N + 63) / 64;
 #define OSC_SEL(MM) hipLaunchKernelGGL(k_knn_select<MM>, grid, block, 0, s, Sm, lds_, N, k, out_val, out_idx)
@@ -1094,6 +1192,17 @@ void launch_knn_dense(const float* Yn, int32_t ldn, int32_t N, int32_t k, float*
   else if (m <= 112) OSC_SEL(112);
   else OSC_SEL(128);
 #undef OSC_SEL
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_knn_rows_any(const float* Yn, int32_t ldn, int32_t N, int32_t k, int32_t row_begin, int32_t rows, float* Sm,
+                         int32_t lds_, float* out_val, int32_t* out_idx, hipStream_t s) {
+  if (rows <= 0) return;
+  if (row_begin % BM != 0) throw std::runtime_error("launch_knn_rows_any: row_begin must be a multiple of 128");
+  hipLaunchKernelGGL(k_knn_dense, dim3((N + BN - 1) / BN, (rows + BM - 1) / BM), dim3(256), 0, s, Yn, ldn, N, Sm, lds_,
+                     row_begin);
+  hipLaunchKernelGGL(k_knn_select_any, dim3((unsigned)rows), dim3(256), 0, s, Sm, lds_, N, k, row_begin, rows, out_val,
+                     out_idx);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1133,8 +1242,60 @@ void launch_knn_rescore(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t 
   HIP_CHECK(hipGetLastError());
 }
 
+// the same for lists of any length that are sorted by column index (the k > 128 route): binary search for the back
+// edge; the kept entries are already in ascending column order, so an entry's ELL slot is the count of kept entries
+// before it
+__global__ __launch_bounds__(256) void k_mutual_ell_sorted(const float* kval, const int32_t* kidx, int32_t N, int32_t k,
+                                                           int32_t width, int32_t* ell_col, float* ell_a, int32_t* deg) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  int total = 0;
+  for (int e0 = 0; e0 < k; e0 += 64) {
+    const int e = e0 + lane;
+    bool keep = false;
+    int j = 0;
+    float w = 0.f;
+    if (e < k) {
+      j = kidx[(size_t)row * k + e];
+      const float v = kval[(size_t)row * k + e];
+      if (v > 0.f && j >= 0 && j < N) {
+        const int32_t* lj = kidx + (size_t)j * k;
+        int lo = 0, hi = k;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (lj[mid] < row) lo = mid + 1;
+          else hi = mid;
+        }
+        if (lo < k && lj[lo] == row) {
+          const float back = kval[(size_t)j * k + lo];
+          if (back > 0.f) {
+            keep = true;
+            w = fmaxf(v, back);
+          }
+        }
+      }
+    }
+    const unsigned long long b = __ballot(keep);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (keep) {
+      const int slot = total + __popcll(b & below);
+      ell_col[(size_t)row * width + slot] = j;
+      ell_a[(size_t)row * width + slot] = w;
+    }
+    total += __popcll(b);
+  }
+  if (lane == 0) deg[row] = total;
+}
+
 void launch_mutual_ell(const float* kval, const int32_t* kidx, int32_t N, int32_t k, int32_t width, int32_t* ell_col,
                        float* ell_a, int32_t* deg, hipStream_t s) {
+  if (k > 128) {  // lists of the any-k route (sorted by column index)
+    hipLaunchKernelGGL(k_mutual_ell_sorted, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, kval, kidx, N, k, width,
+                       ell_col, ell_a, deg);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(k_mutual_ell, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, kval, kidx, N, k, width, ell_col,
                      ell_a, deg);
   HIP_CHECK(hipGetLastError());

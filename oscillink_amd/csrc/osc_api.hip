@@ -673,7 +673,9 @@ void build_graph(L& h) {
     return;
   }
   const int32_t k = h.k_eff;
-  if (k > 128) throw Unsupported("kneighbors > 128 is not supported by the device kNN build");
+  // k <= 128: register-resident streaming lists (exact / prefilter / small-dense routes below).  Larger k (the
+  // reference takes any k <= N - 1, lattice.py:60): dense similarity rows in chunks + a radix select per row.
+  const bool any_k = k > 128;
   const int32_t ldn = ((h.D + 31) / 32) * 32;
   DevBuf<float> Yn;
   Yn.alloc((size_t)h.N * ldn);
@@ -711,6 +713,7 @@ void build_graph(L& h) {
     if (!strcmp(e, "exact")) prefilter = false;
     if (!strcmp(e, "prefilter")) prefilter = (keep_f >= k + 8);
   }
+  if (any_k) prefilter = false;
   DevBuf<float> cand_val, cval;
   DevBuf<int32_t> cand_idx, cidx, fail_rows, fail_count;
   DevBuf<float> Yh;  // fp16 image, viewed as float slots
@@ -732,7 +735,21 @@ void build_graph(L& h) {
     if (sharded && part != h.rank) continue;
     const int rb_begin = std::min(all_rb, part * rb_per);
     const int rb_count = std::max(0, std::min(rb_per, all_rb - rb_begin));
-    if (prefilter) {
+    if (any_k) {
+      // chunks of up to ~1 GiB of similarity rows (multiple of 128 rows)
+      const int32_t ldS = ((N + 31) / 32) * 32;
+      const int64_t cap_rows = std::max<int64_t>(128, (((int64_t)1 << 28) / ldS) / 128 * 128);
+      const int32_t row_lo = rb_begin * 128, row_hi = std::min(N, (rb_begin + rb_count) * 128);
+      const int32_t chunk = (int32_t)std::min<int64_t>(cap_rows, ((row_hi - row_lo + 127) / 128) * 128);
+      if (row_hi > row_lo) {
+        DevBuf<float> Sm;
+        Sm.alloc((size_t)chunk * ldS);
+        ProfScope ps(h, 3);
+        for (int32_t r = row_lo; r < row_hi; r += chunk)
+          launch_knn_rows_any(Yn.p, ldn, N, k, r, std::min(chunk, row_hi - r), Sm.p, ldS, h.knn_val.p, h.knn_idx.p, h.stream);
+        sync(h);  // Sm goes back to the pool at scope exit
+      }
+    } else if (prefilter) {
       const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true);
       const size_t ncand = (size_t)h.N * plan.S * plan.KC;
       cand_val.alloc(ncand);

@@ -298,3 +298,21 @@ def test_halo_lists_shrink_with_graph_locality(amd, monkeypatch):
                 assert info["bytes_per_iteration"] == info["need_rows"] * 64 * 4
             else:
                 assert info["full_exchange"] == 1 and info["need_rows_max"] > 0.7 * info["remote_rows"]
+
+
+def test_sharded_build_with_kneighbors_above_128(amd, orc, monkeypatch):
+    """The any-k route (dense similarity rows + radix select) under a communicator: each rank selects the lists of its
+    row blocks, the all-gather assembles them."""
+    monkeypatch.delenv("OSC_SHARD", raising=False)
+    rng = np.random.default_rng(9)
+    N, D, k = 1000, 20, 160
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    ref = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True)
+    r, c, wv = orc._edges(ref.A)
+
+    def rank_fn(rank, comm):
+        return amd.Oscillink(Y, kneighbors=k, deterministic_k=True, comm=comm).graph_csr()
+
+    for rp, col, a, w, sd in _ranks(3, rank_fn):
+        assert np.array_equal(np.repeat(np.arange(N), np.diff(rp)), r) and np.array_equal(col, c)
+        assert np.allclose(a, wv, rtol=1e-5)

@@ -526,10 +526,55 @@ def test_wide_neighbor_lists_against_oracle(amd, orc, N, D, k):
     assert lat.receipt()["deltaH_total"] == pytest.approx(ref.deltaH(), rel=TOL)
 
 
-def test_kneighbors_above_device_limit_is_reported(amd):
-    Y = np.random.default_rng(0).standard_normal((400, 8)).astype(np.float32)
-    with pytest.raises(NotImplementedError):
-        amd.Oscillink(Y, kneighbors=200)
+@pytest.mark.parametrize("N,D,k", [(400, 24, 129), (700, 40, 200), (301, 16, 1000), (9000, 32, 150)])
+def test_kneighbors_above_128_against_oracle(amd, orc, N, D, k):
+    """The reference takes any k <= N - 1 (lattice.py:60).  k > 128 leaves the register-resident lists for the dense
+    similarity rows + radix select route (any N: the last case is past the small-lattice limit, the third clamps k to
+    N - 1 = a complete graph before the mutual test)."""
+    rng = np.random.default_rng(k)
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    ref = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True, dense=False, knn_block=2048)
+    lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+    assert lat._kneighbors == min(k, N - 1)
+    rp, col, a, w, sd = lat.graph_csr()
+    r, c, wv = orc._edges(ref.A)
+    rows = np.repeat(np.arange(N), np.diff(rp))
+    if rows.size == r.size and np.array_equal(rows, r) and np.array_equal(col, c):
+        assert np.allclose(a, wv, rtol=1e-5)
+    else:  # near-tie neighbour flips are legal (sgemm vs MFMA summation order, 81 M similarities at D = 32); bound them
+        dev, cpu = set(zip(rows.tolist(), col.tolist())), set(zip(r.tolist(), c.tolist()))
+        assert N >= 4096 and len(dev & cpu) / len(dev | cpu) > 1 - 1e-4
+        R = ref.A.tocsr()
+        lat.set_graph_csr(R.indptr.astype(np.int64), R.indices.astype(np.int32), R.data.astype(np.float32))
+    for L in (ref, lat):
+        L.set_query(psi)
+    a_ = ref.settle(tol=1e-4)
+    b_ = lat.settle(tol=1e-4)
+    assert a_["iters"] == b_["iters"] and relerr(lat.U, ref.U) < 2e-5
+    assert lat.receipt()["deltaH_total"] == pytest.approx(ref.deltaH(), rel=TOL)
+
+
+def test_kneighbors_above_128_ties_go_to_the_smaller_index(amd, orc):
+    """All rows identical: every similarity ties, so each list must hold the k smallest indices (graph.py:46-49)."""
+    N, D, k = 300, 8, 140
+    Y = np.tile(np.linspace(1.0, 2.0, D, dtype=np.float32), (N, 1))
+    lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+    import ctypes as C
+
+    from oscillink_amd import _native as nat
+
+    idx = np.zeros((N, k), dtype=np.int32)
+    ke = C.c_int32(0)
+    lat._call("osc_get_knn_lists", nat.i32(idx), None, C.byref(ke))
+    assert ke.value == k
+    for i in (0, 1, 139, 140, 141, 299):
+        want = [j for j in range(N) if j != i][:k]
+        assert sorted(idx[i].tolist()) == want
+    ref = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True)
+    rp, col, a, _, _ = lat.graph_csr()
+    r, c, wv = orc._edges(ref.A)
+    assert np.array_equal(np.repeat(np.arange(N), np.diff(rp)), r) and np.array_equal(col, c)
 
 
 def test_config5_shape_gates_chain_properties(amd, orc):
