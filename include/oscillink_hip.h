@@ -72,7 +72,8 @@ int osc_rebuild_graph(osc_handle h, int32_t k, float row_cap, int32_t determinis
 /* nnz = stored directed edges (== count of A > 0), max_deg = widest row, build_ms = device build time */
 int osc_graph_stats(osc_handle h, int64_t* nnz, int32_t* max_deg, double* build_ms);
 
-/* how the last device build ran: prefilter != 0 -> fp16-MFMA prefilter + exact fp32 re-scoring; fallback_rows = rows whose
+/* how the last device build ran: prefilter != 0 -> fp16-MFMA prefilter + exact fp32 re-scoring (2 = the
+ * register-resident-panel GEMM with sampled thresholds, 1 = the 128 x 128 tile with in-kernel lists); fallback_rows = rows whose
  * candidate list could not be proven and were redone by the all-fp32 kernel; small_solves = solves served by the
  * one-launch small-lattice CG since creation */
 int osc_build_info(osc_handle h, int32_t* prefilter, int32_t* fallback_rows, int64_t* small_solves);

@@ -35,6 +35,11 @@ void launch_knn_dense(const float* Yn, int32_t ldn, int32_t N, int32_t k, float*
 // be a multiple of 128.  out_val / out_idx are the full N x k lists.
 void launch_knn_rows_any(const float* Yn, int32_t ldn, int32_t N, int32_t k, int32_t row_begin, int32_t rows, float* Sm,
                          int32_t lds_, float* out_val, int32_t* out_idx, hipStream_t s);
+// exact fp32 lists of a FEW rows (nq <= 32; the prefilter routes' fallback): scores of the listed rows against all
+// columns into Sm (nq x lds_ floats, lds_ >= N) in k_knn_rescore's arithmetic, then each row's k best.  Returns false
+// when the rows are too wide for it (ldn > 1536): the caller then uses the MFMA kernel's row-list form.
+bool launch_knn_few_rows(const float* Yn, int32_t ldn, int32_t N, int32_t k, const int32_t* qrows, int32_t nq, float* Sm,
+                         int32_t lds_, float* out_val, int32_t* out_idx, hipStream_t s);
 // rank-select the best k_out of the S*KC candidates of each row of the plan's range (or of plan.qrows)
 void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* cand_idx, int32_t N, int32_t k_out,
                       float* out_val, int32_t* out_idx, int clip, hipStream_t s);

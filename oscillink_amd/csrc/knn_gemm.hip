@@ -1,0 +1,560 @@
+// The "panel" prefilter of the lattice build (graph.py:35-62, all-pairs cosine similarity -> per-row top-k): an fp16
+// similarity GEMM shaped for gfx950's matrix pipe, with NO list maintenance inside the GEMM.
+//
+//   workgroup = 4 waves, ONE per SIMD (the whole 512-entry register file per wave), 128 query rows (wave w: rows
+//   32 w .. 32 w + 31), persistent over work items (row block, column split) drawn from an atomic queue;
+//   A: the wave's 32 x D fp16 query panel stays in registers for its whole column sweep (D = 768: 48 half8 = 192
+//      VGPRs) -- it never passes through LDS again, which halves the LDS-DMA volume per MFMA of the 128 x 128
+//      two-waves-per-SIMD shape (knn_kernels.hip: k_knn_pref), whose K steps ran at LDS-DMA latency;
+//   B: 128 columns x 64 halfs per K step (16 KB) by global_load_lds_dwordx4 into a 6-stage ring, two K steps per
+//      barrier, the pair fetched during a pair stays in flight across the barrier (counted vmcnt); every address of
+//      the K loop is a register set once per tile plus a compile-time immediate (the K offset rides in the DMA
+//      instruction's immediate, which the hardware also adds to the LDS destination: M0 carries destination - offset);
+//      bank swizzle on the source address, the same xor on the ds_read_b128 fragment reads;
+//   one v_mfma_f32_32x32x16_f16 per (k16 slice, 32-column subtile): 16 per K step and wave.
+//
+// Selection is split off the matrix pipe (at one wave per SIMD every sorted list insert would be fully exposed):
+//   phase A  (k_panel<NKT, 0>): the same GEMM against a strided SAMPLE of the columns; epilogue = per (row, sample tile)
+//            maximum.  tau_row = the r-th largest of its tile maxima: a lower bound of the r-th best sample score, hence
+//            of the row's final keep-th best score whenever at least `keep` columns beat it (checked, not assumed).
+//   phase B  (k_panel<NKT, 1>): the full sweep; epilogue = compare against tau_row (one max + compare per query row and
+//            tile, ballots only for rows with a hit) and APPEND the few hits (row, column, score) to the work item's
+//            private candidate slots: no atomics, no sorted inserts, no threshold updates, so column splits cost
+//            nothing and balance the persistent grid.
+//   select   (k_panel_select): per row the keep best candidates by fp16 score -> the lists k_knn_rescore re-scores in
+//            exact fp32 and proves (unchanged contract: every left-out column has fp16 score <= the list's last).
+//            A row with an overflowed split or fewer than keep candidates goes to the exact kernel's row list.
+// The neighbour lists that come out are therefore those of the exact fp32 scoring, as with the other routes.
+#include "knn_gemm.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace osc {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int RING = 6;
+constexpr unsigned STAGE_BYTES = 16384;  // one K step of a column tile: 128 rows x 128 B
+// MODE 1: each wave appends its hits to a private LDS list (ds_write is not on the vmcnt queue the DMA ring is counted
+// on: global stores in the epilogue made every tile wait for their completion) and flushes it at the end of the item
+constexpr int HB_CAP = 1792;  // entries of 8 bytes per wave: 4 x 14 KB behind the ring
+constexpr size_t PANEL_LDS = (size_t)RING * STAGE_BYTES + 2048;
+constexpr size_t PANEL_LDS_HITS = PANEL_LDS + (size_t)4 * HB_CAP * 8;
+
+struct PanelArgs {
+  const _Float16* A;   // query image, npad rows
+  const _Float16* B;   // column image, ntileB * 128 rows (the query image itself, or the sample)
+  int32_t ldh, N, ntileB, S, tiles_per_split;
+  int32_t rb_begin, rb_count;  // query row blocks this launch covers (a rank's share in a sharded build)
+  int32_t group_tiles, ngroups;  // MODE 0: tile maxima are folded over groups of consecutive sample tiles
+  float* tmax;         // MODE 0: [npad][ngroups]
+  const float* tau;    // MODE 1: [npad]
+  uint2* hit_list;     // MODE 1: [(item * 4 + wave) * HB_CAP + e] = {local row << 27 | column, score bits}
+  int32_t* hit_cnt;    // MODE 1: [item * 4 + wave] hits of that wave in that item (may exceed HB_CAP: overflow)
+  unsigned* queue;
+};
+
+// LDS-DMA of one 1 KiB piece: M0 = LDS destination - K offset, the K offset rides in the immediate
+#define OSC_PIECE(SRC, KT, STAGE, Q)                                                                                  \
+  do {                                                                                                               \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_)                                                                                      \
+                 : "v"(SRC), "s"(fill_base + (unsigned)((STAGE) * STAGE_BYTES + (Q) * 1024) - (unsigned)((KT) * 128)), \
+                   "n"((KT) * 128)                                                                                   \
+                 : "memory");                                                                                        \
+  } while (0)
+
+template <int NKT, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_panel(const PanelArgs a) {
+  static_assert(NKT % RING == 0, "a tile's K steps must be whole laps of the ring (compile-time stage indices)");
+  constexpr int NK16 = NKT * 4;
+  extern __shared__ __attribute__((aligned(1024))) float lds[];  // RING stages x [128 rows][32 float slots] (+2 KB lead)
+  __shared__ int s_item;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int frow = lane >> 3;
+  const int swz = (l31 >> 1) & 7;
+  const unsigned lds_base = (unsigned)(size_t)lds + 2048u;
+  const unsigned fill_base = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(32 * wave * 128));
+  unsigned rd[4];  // fragment read base of k16 slice s: row l31, chunk (2 s + h) ^ swz   (+ stage, + subtile * 4096)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) rd[s] = (unsigned)(l31 * 128 + (((2 * s + h) ^ swz) * 16));
+  const char* ldsc = reinterpret_cast<const char*>(lds) + 2048;
+  const int nitems = a.rb_count * a.S;
+  const size_t ldh = (size_t)a.ldh;
+  const size_t tile_stride = (size_t)128 * ldh;  // halfs between column tiles
+  for (;;) {
+    if (tid == 0) s_item = (int)atomicAdd(a.queue, 1u);
+    __syncthreads();
+    const int item = s_item;
+    __syncthreads();
+    if (item >= nitems) break;
+    // items of one split are consecutive: the workgroups that start together sweep the same column tiles together
+    const int split = item / a.rb_count, rb = a.rb_begin + (item - split * a.rb_count);
+    const int t0 = split * a.tiles_per_split, t1 = min(a.ntileB, t0 + a.tiles_per_split);
+    if (t0 >= t1) continue;
+    const int row = rb * 128 + 32 * wave + l31;
+    half8 areg[NK16];
+#pragma unroll
+    for (int i = 0; i < NK16; ++i) areg[i] = *(const half8*)(a.A + (size_t)row * ldh + i * 16 + h * 8);
+    // per query-row register g of this half-wave: local row (g & 3) + 8 (g >> 2) + 4 h of the wave's 32
+    float taug[16];  // MODE 1: thresholds; MODE 0: running maxima of the current tile group
+    int wcnt = 0;    // MODE 1: hits this wave has appended in this item (wave-uniform)
+    uint2* hitbuf = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds) + PANEL_LDS) + wave * HB_CAP;
+    const int grow0 = rb * 128 + 32 * wave + 4 * h;
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) taug[g] = -3.0e38f;
+    }
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) taug[g] = a.tau[grow0 + (g & 3) + 8 * (g >> 2)];
+    }
+    // source of piece q of this wave's share of a column tile: row 32 wave + 8 q + frow of the tile, swizzled chunk
+    const _Float16* bsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bsrc[q] = a.B + (size_t)t0 * tile_stride + (size_t)(32 * wave + 8 * q + frow) * ldh +
+                ((lane & 7) ^ (((q & 1) << 2) | (frow >> 1))) * 8;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { OSC_PIECE(bsrc[q], st, st, q); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ct = t0; ct < t1; ++ct) {
+      const bool last_tile = ct + 1 == t1;
+      f32x16 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+      const _Float16* nsrc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nsrc[q] = bsrc[q] + tile_stride;
+      // K steps in pairs (one barrier per 32 MFMAs): pair pr reads stages (2 pr) % 6, (2 pr + 1) % 6 and fetches the pair
+      // two pairs ahead (of this tile or the next) into the stages the previous pair has released
+#pragma unroll
+      for (int pr = 0; pr < NKT / 2; ++pr) {
+        const bool next_tile = 2 * pr + 4 >= NKT;
+        const bool fetch = !(next_tile && last_tile);
+        v4f fa[4], fb[4];
+        auto read_frags = [&](int st, int sl, v4f(&bv)[4]) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bv[t] = *(const v4f*)(ldsc + rd[sl] + st * STAGE_BYTES + t * 4096);
+        };
+        read_frags((2 * pr) % RING, 0, fa);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // eight k16 slices: two K steps
+          const int kt = 2 * pr + (u >> 2), sl = u & 3;
+          v4f(&cur)[4] = (u & 1) ? fb : fa;
+          v4f(&nxt)[4] = (u & 1) ? fa : fb;
+          if (u + 1 < 8) read_frags((2 * pr + ((u + 1) >> 2)) % RING, (u + 1) & 3, nxt);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[kt * 4 + sl], __builtin_bit_cast(half8, cur[t]), acc[t], 0,
+                                                            0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (u < 4 && fetch) {  // two DMA pieces behind each of the first four MFMA groups
+            const int fk = (2 * pr + 4 + (u >> 1)) % NKT, fst = (2 * pr + 4 + (u >> 1)) % RING;
+#pragma unroll
+            for (int q = 2 * (u & 1); q < 2 * (u & 1) + 2; ++q) {
+              if (next_tile) { OSC_PIECE(nsrc[q], fk, fst, q); } else { OSC_PIECE(bsrc[q], fk, fst, q); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (fetch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the pair fetched during this pair stays in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // raw barrier: __syncthreads() would make hipcc drain vmcnt for the epilogue's candidate stores, and with them
+        // the DMA pieces meant to stay in flight; every ds_read of the pair has been consumed by its MFMAs already
+        __builtin_amdgcn_s_barrier();
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bsrc[q] = nsrc[q];
+      // ---- epilogue of the 32 x 128 score tile ----------------------------------------------------------------
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          taug[g] = fmaxf(taug[g], fmaxf(fmaxf(acc[0][g], acc[1][g]), fmaxf(acc[2][g], acc[3][g])));
+        if ((ct + 1) % a.group_tiles == 0 || last_tile) {  // close the group: maximum over its columns
+          const int grp = ct / a.group_tiles;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            float m = taug[g];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));  // within the 32 lanes of the half
+            if (l31 == 0) a.tmax[(size_t)(grow0 + (g & 3) + 8 * (g >> 2)) * a.ngroups + grp] = m;
+            taug[g] = -3.0e38f;
+          }
+        }
+      } else {
+        const int cbase = ct * 128 + l31;
+        const bool ragged = (ct + 1) * 128 > a.N;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const float m = fmaxf(fmaxf(acc[0][g], acc[1][g]), fmaxf(acc[2][g], acc[3][g]));
+          if (__ballot(m > taug[g]) == 0ull) continue;  // the common case: nothing of this row beats its threshold
+          const int rl = (g & 3) + 8 * (g >> 2) + 4 * h;  // local row of the wave's 32
+          const int grow = rb * 128 + 32 * wave + rl;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float c = acc[t][g];
+            const int col = cbase + 32 * t;
+            const bool pred = c > taug[g] && col != grow && !(ragged && col >= a.N);  // graph.py:37: no self-similarity
+            const unsigned long long mk = __ballot(pred);
+            if (mk == 0ull) continue;
+            const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            if (pred && pos < HB_CAP) hitbuf[pos] = make_uint2(((unsigned)rl << 27) | (unsigned)col, __float_as_uint(c));
+            wcnt += __popcll(mk);
+          }
+        }
+      }
+    }
+    if constexpr (MODE == 1) {  // flush the wave's hit list (coalesced 8-byte stores) and its count
+      const int n = min(wcnt, HB_CAP);
+      uint2* out = a.hit_list + ((size_t)item * 4 + wave) * HB_CAP;
+      for (int e = lane; e < n; e += 64) out[e] = hitbuf[e];
+      if (lane == 0) a.hit_cnt[item * 4 + wave] = wcnt;
+    }
+    __syncthreads();  // every wave is done with the ring before the next item refills it
+  }
+}
+
+// fp32 unit rows -> fp16 image of 16 * Yn, zero beyond (N, D)
+__global__ void k_panel_image(const float* Yn, int32_t ldn, _Float16* Yh, int32_t ldh, int32_t npad, int32_t N, int32_t D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 halfs
+  const int per_row = ldh / 8;
+  if (i >= (int64_t)npad * per_row) return;
+  const int row = (int)(i / per_row), c0 = (int)(i % per_row) * 8;
+  half8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    v[j] = (row < N && c < D) ? (_Float16)(16.0f * Yn[(size_t)row * ldn + c]) : (_Float16)0.f;
+  }
+  *(half8*)(Yh + (size_t)row * ldh + c0) = v;
+}
+
+__global__ void k_panel_sample(const _Float16* Yh, _Float16* Ys, int32_t ldh, int32_t m, int32_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = ldh / 8;
+  if (i >= (int64_t)m * per_row) return;
+  const int t = (int)(i / per_row), c0 = (int)(i % per_row) * 8;
+  const int64_t src = min((int64_t)N - 1, (int64_t)t * N / m);
+  *(half8*)(Ys + (size_t)t * ldh + c0) = *(const half8*)(Yh + (size_t)src * ldh + c0);
+}
+
+// one wave per row: tau = the rank-th largest of the row's ntile (<= 128) tile maxima
+__global__ __launch_bounds__(256) void k_panel_tau(const float* tmax, int32_t ntile, int32_t rank, int32_t N, float* tau) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float NEGV = -3.0e38f;
+  float v[2];
+  v[0] = lane < ntile ? tmax[(size_t)row * ntile + lane] : NEGV;
+  v[1] = lane + 64 < ntile ? tmax[(size_t)row * ntile + lane + 64] : NEGV;
+  int better[2] = {0, 0};
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2)
+    for (int l = 0; l < 64; ++l) {
+      const float ov = __shfl(v[m2], l, 64);
+      const int oi = l + 64 * m2;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int mi = lane + 64 * m;
+        if (ov > v[m] || (ov == v[m] && oi < mi)) ++better[m];
+      }
+    }
+  float t = NEGV;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+    if (better[m] == rank - 1) t = v[m];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t = fmaxf(t, __shfl_xor(t, o, 64));
+  if (lane == 0) tau[row] = t;
+}
+
+__device__ __forceinline__ unsigned order_key(unsigned bits) {  // ascending float order == ascending key order
+  return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+
+// One workgroup per (row block, wave-of-32-rows, sub-range of those rows).  The rows' candidates sit in the S hit lists of
+// their (row block, wave): the workgroup counting-sorts the entries of ITS rows by row into LDS (two passes over the
+// lists), then each wave takes rows in turn: finds the keep-th largest fp16 score T by a bitwise search (32 ballot
+// counts over the row's entries, held in registers) and writes keep candidates -- those above T, then entries equal to
+// T -- so the last slot holds the list's minimum, the value k_knn_rescore's proof takes as v_last.  The list need not be
+// sorted: the re-scoring ranks by exact score.
+constexpr int SEL_CAP = 1024;    // candidates of one row the select can hold (expected: ~5 keep)
+constexpr int SORT_CAP = 2560;   // entries one workgroup sorts (20 KB of LDS: several workgroups per CU)
+__global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, const int32_t* hit_cnt, int32_t S,
+                                                      int32_t rb_begin, int32_t rb_count, int32_t nsub, int32_t keep,
+                                                      int32_t N, float* cval, int32_t* cidx, int32_t* fail_rows,
+                                                      int32_t* fail_count) {
+  __shared__ uint2 sorted[SORT_CAP];
+  __shared__ int hist[32], start[33], cursor[32], s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = blockIdx.x % nsub, w = (blockIdx.x / nsub) % 4, rbi = blockIdx.x / (4 * nsub);
+  const int rows_here = 32 / nsub, rl0 = sub * rows_here;  // local rows [rl0, rl0 + rows_here) of the wave's 32
+  const int row_base = (rb_begin + rbi) * 128 + 32 * w;
+  if (tid < 32) hist[tid] = 0;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  // pass 1: entries per row
+  for (int s = 0; s < S; ++s) {
+    const size_t li = ((size_t)s * rb_count + rbi) * 4 + w;
+    const int c = hit_cnt[li];
+    if (c > HB_CAP && tid == 0) s_bad = 1;  // the list overflowed: hits were dropped
+    const int n = min(c, HB_CAP);
+    const uint2* list = hit_list + li * HB_CAP;
+    for (int e = tid; e < n; e += 256) {
+      const int rl = (int)(list[e].x >> 27);
+      if (rl >= rl0 && rl < rl0 + rows_here) atomicAdd(&hist[rl], 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int r = 0; r < 32; ++r) {
+      start[r] = acc;
+      cursor[r] = acc;
+      acc += hist[r];
+    }
+    start[32] = acc;
+    if (acc > SORT_CAP) s_bad = 1;
+  }
+  __syncthreads();
+  const bool bad = s_bad != 0;
+  // pass 2: scatter into row order
+  if (!bad) {
+    for (int s = 0; s < S; ++s) {
+      const size_t li = ((size_t)s * rb_count + rbi) * 4 + w;
+      const int n = min(hit_cnt[li], HB_CAP);
+      const uint2* list = hit_list + li * HB_CAP;
+      for (int e = tid; e < n; e += 256) {
+        const uint2 v = list[e];
+        const int rl = (int)(v.x >> 27);
+        if (rl >= rl0 && rl < rl0 + rows_here) sorted[atomicAdd(&cursor[rl], 1)] = make_uint2(v.x & 0x07FFFFFFu, v.y);
+      }
+    }
+  }
+  __syncthreads();
+  for (int rl = rl0 + wave; rl < rl0 + rows_here; rl += 4) {
+    const int row = row_base + rl;
+    if (row >= N) continue;
+    const int m = bad ? 0 : hist[rl];
+    float* ov = cval + (size_t)row * keep;
+    int32_t* oi = cidx + (size_t)row * keep;
+    if (bad || m < keep || m > SEL_CAP) {  // incomplete, too small or too large a candidate set: the exact kernel redoes it
+      if (lane == 0) fail_rows[atomicAdd(fail_count, 1)] = row;
+      for (int e = lane; e < keep; e += 64) oi[e] = -1;
+      continue;
+    }
+    const uint2* ent = sorted + start[rl];
+    constexpr int M = SEL_CAP / 64;
+    unsigned key[M], col[M], bits[M];
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+      const int e = lane + 64 * q;
+      key[q] = 0u;  // below every real key (scores here are > tau; order_key never yields 0 for them)
+      col[q] = 0u;
+      bits[q] = 0u;
+      if (e < m) {
+        const uint2 v = ent[e];
+        col[q] = v.x;
+        bits[q] = v.y;
+        key[q] = order_key(v.y);
+      }
+    }
+    const int mq = (m + 63) / 64;  // registers in use (wave-uniform)
+    unsigned T = 0u;
+    for (int b = 31; b >= 0; --b) {
+      const unsigned cand = T | (1u << b);
+      int ge = 0;
+#pragma unroll
+      for (int q = 0; q < M; ++q)
+        if (q < mq) ge += __popcll(__ballot(key[q] >= cand));
+      if (ge >= keep) T = cand;
+    }
+    int n_gt = 0;
+#pragma unroll
+    for (int q = 0; q < M; ++q)
+      if (q < mq) n_gt += __popcll(__ballot(key[q] > T));
+    int base_gt = 0, base_eq = n_gt;
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+      if (q >= mq) continue;
+      const bool gt = key[q] > T, eq = key[q] == T && key[q] != 0u;
+      const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+      const int pg = base_gt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bg, 0u));
+      const int pe = base_eq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(be >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)be, 0u));
+      if (gt) {
+        ov[pg] = __uint_as_float(bits[q]);
+        oi[pg] = (int32_t)col[q];
+      }
+      if (eq && pe < keep) {
+        ov[pe] = __uint_as_float(bits[q]);
+        oi[pe] = (int32_t)col[q];
+      }
+      base_gt += __popcll(bg);
+      base_eq += __popcll(be);
+    }
+  }
+}
+
+template <int MODE>
+void launch_panel(const PanelArgs& a, int nkt, int grid, hipStream_t s) {
+#define OSC_PANEL(NKT)                                                                                              \
+  do {                                                                                                              \
+    constexpr size_t lds_bytes = MODE == 1 ? PANEL_LDS_HITS : PANEL_LDS;                                            \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NKT, MODE>),                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                     \
+    hipLaunchKernelGGL((k_panel<NKT, MODE>), dim3(grid), dim3(256), lds_bytes, s, a);                              \
+  } while (0)
+  if (nkt == 6) OSC_PANEL(6);
+  else if (nkt == 12) OSC_PANEL(12);
+  else throw std::runtime_error("launch_panel: unsupported K depth");
+#undef OSC_PANEL
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+int knn_panel_nkt(int32_t D) { return D <= 384 ? 6 : D <= 768 ? 12 : 0; }
+
+KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus) {
+  KnnPanelPlan p{};
+  p.nkt = knn_panel_nkt(D);
+  p.ldh = 64 * p.nkt;
+  p.npad = ((N + 127) / 128) * 128;
+  p.nrb = p.npad / 128;
+  p.keep = keep;
+  // Thresholds: the sample holds one column in rho; tau = the 16th largest tile maximum ~ the 17th-20th best sample
+  // score, so about rho * 18 columns of the full sweep beat it (gamma-distributed: 0.1 % of the rows see fewer than
+  // rho * 6 or more than rho * 35).  rho = keep / 4 puts `keep` at the low tail and 10 keep slots above the high one.
+  const double rho = std::max(6.0, keep / 4.0);
+  p.sample_tiles = (int32_t)std::max(24.0, std::min(p.nrb / 2.0, std::round(p.nrb / rho)));
+  // tile maxima are folded over groups of consecutive sample tiles so that a row has at most 128 of them (the r-th
+  // largest group maximum is still a lower bound of the r-th best sample score)
+  // (small lattices cannot afford a sparse enough sample: with fewer than keep / 8 columns per sampled one, too many rows
+  // would end with fewer than keep candidates -- the tile prefilter serves those)
+  p.ok = (double)p.nrb / p.sample_tiles * 8.0 >= (double)keep;
+  p.group_tiles = (p.sample_tiles + 127) / 128;
+  p.sample_groups = (p.sample_tiles + p.group_tiles - 1) / p.group_tiles;
+  p.sample_rank = 16;
+  // column splits: whatever leaves the smallest idle tail on `cus` persistent workgroups (per-item overhead ~1 %)
+  // ... and few enough hits per wave and item for its LDS list: 32 rows x ~5 keep / S <= ~2/3 of HB_CAP
+  const int s_min = std::max(1, (int)std::ceil(32.0 * 5.0 * keep / (0.66 * HB_CAP)));
+  double best = 1e30;
+  p.S = s_min;
+  for (int S = s_min; S <= s_min + 8; ++S) {
+    if (p.nrb / S < 16 && S > s_min) break;
+    const double rounds = (double)p.nrb * S / std::max(1, cus);
+    const double cost = std::ceil(rounds) / rounds * (1.0 + 0.01 * S);
+    if (cost < best - 1e-9) {
+      best = cost;
+      p.S = S;
+    }
+  }
+  p.tiles_per_split = (p.nrb + p.S - 1) / p.S;
+  // phase A: splits of whole tile groups, again for the tail of the persistent grid
+  best = 1e30;
+  p.SA = 1;
+  for (int S = 1; S <= 6 && S <= p.sample_groups; ++S) {
+    const double rounds = (double)p.nrb * S / std::max(1, cus);
+    const double cost = std::ceil(rounds) / rounds * (1.0 + 0.03 * S);
+    if (cost < best - 1e-9) {
+      best = cost;
+      p.SA = S;
+    }
+  }
+  p.sample_tiles_per_split = ((p.sample_groups + p.SA - 1) / p.SA) * p.group_tiles;
+  p.hit_cap = HB_CAP;
+  return p;
+}
+
+void launch_panel_image(const float* Yn, int32_t ldn, void* Yh, const KnnPanelPlan& p, int32_t N, int32_t D, hipStream_t s) {
+  const int64_t n = (int64_t)p.npad * (p.ldh / 8);
+  hipLaunchKernelGGL(k_panel_image, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Yn, ldn,
+                     static_cast<_Float16*>(Yh), p.ldh, p.npad, N, D);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_panel_sample(const void* Yh, void* Ys, const KnnPanelPlan& p, int32_t N, hipStream_t s) {
+  const int32_t m = p.sample_tiles * 128;
+  const int64_t n = (int64_t)m * (p.ldh / 8);
+  hipLaunchKernelGGL(k_panel_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                     static_cast<const _Float16*>(Yh), static_cast<_Float16*>(Ys), p.ldh, m, N);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_panel_tilemax(const void* Yh, const void* Ys, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count,
+                          float* tmax, unsigned* queue, int grid, hipStream_t s) {
+  if (rb_count <= 0) return;
+  PanelArgs a{};
+  a.A = static_cast<const _Float16*>(Yh);
+  a.B = static_cast<const _Float16*>(Ys);
+  a.ldh = p.ldh;
+  a.N = N;
+  a.rb_begin = rb_begin;
+  a.rb_count = rb_count;
+  a.ntileB = p.sample_tiles;
+  a.S = p.SA;
+  a.tiles_per_split = p.sample_tiles_per_split;
+  a.group_tiles = p.group_tiles;
+  a.ngroups = p.sample_groups;
+  a.tmax = tmax;
+  a.queue = queue;
+  HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
+  launch_panel<0>(a, p.nkt, grid, s);
+}
+
+void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float* tau, hipStream_t s) {
+  hipLaunchKernelGGL(k_panel_tau, dim3((unsigned)((p.npad + 3) / 4)), dim3(256), 0, s, tmax, p.sample_groups, p.sample_rank,
+                     p.npad, tau);
+  (void)N;
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count, const float* tau,
+                         void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s) {
+  if (rb_count <= 0) return;
+  PanelArgs a{};
+  a.A = static_cast<const _Float16*>(Yh);
+  a.B = a.A;
+  a.ldh = p.ldh;
+  a.N = N;
+  a.rb_begin = rb_begin;
+  a.rb_count = rb_count;
+  a.ntileB = p.nrb;
+  a.S = p.S;
+  a.tiles_per_split = p.tiles_per_split;
+  a.tau = tau;
+  a.hit_list = static_cast<uint2*>(hit_list);
+  a.hit_cnt = hit_cnt;
+  a.queue = queue;
+  HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
+  launch_panel<1>(a, p.nkt, grid, s);
+}
+
+void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int32_t N, const void* hit_list,
+                         const int32_t* hit_cnt, float* cval, int32_t* cidx, int32_t* fail_rows, int32_t* fail_count,
+                         hipStream_t s) {
+  if (rb_count <= 0) return;
+  // rows of one wave-of-32 a workgroup sorts: as many as keeps ~5 keep entries per row within 3/4 of its LDS array
+  int nsub = 1;
+  while (nsub < 8 && 5.0 * p.keep * (32 / nsub) > 0.75 * SORT_CAP) nsub *= 2;
+  hipLaunchKernelGGL(k_panel_select, dim3((unsigned)(rb_count * 4 * nsub)), dim3(256), 0, s,
+                     static_cast<const uint2*>(hit_list), hit_cnt, p.S, rb_begin, rb_count, nsub, p.keep, N, cval, cidx,
+                     fail_rows, fail_count);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace osc

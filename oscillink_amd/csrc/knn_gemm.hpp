@@ -1,0 +1,51 @@
+// Prefilter route "panel": fp16 similarity GEMM with the query panel register-resident (knn_gemm.hip).
+#pragma once
+#include "common.hpp"
+
+namespace osc {
+
+// K steps of 64 halfs the panel kernel is built for: 6 (D <= 384) or 12 (D <= 768); 0 = D not served by this route
+int knn_panel_nkt(int32_t D);
+
+struct KnnPanelPlan {
+  bool ok;             // the lattice is large enough for sampled thresholds (else: use the tile prefilter)
+  int nkt;             // 6 or 12
+  int32_t ldh;         // pitch of the fp16 images in halfs = 64 * nkt
+  int32_t npad;        // rows of the query image (N rounded up to 128), zero-filled beyond N
+  int32_t nrb;         // query row blocks (npad / 128)
+  int32_t sample_tiles;  // 128-column tiles of the strided column sample the thresholds come from
+  int32_t group_tiles;   // sample tiles per maximum (so that a row has <= 128 maxima)
+  int32_t sample_groups;
+  int32_t sample_rank;   // threshold = sample_rank-th largest group maximum of the sample
+  int32_t S;           // column splits of the main sweep
+  int32_t tiles_per_split;
+  int32_t SA;          // column splits of the sample sweep
+  int32_t sample_tiles_per_split;
+  int32_t hit_cap;     // entries of one hit list (one per work item and wave)
+  int32_t keep;        // candidates handed to the exact re-scoring
+};
+KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus);
+
+// fp32 unit rows -> fp16 image of 16 * Yn with pitch plan.ldh, rows [N, npad) zero
+void launch_panel_image(const float* Yn, int32_t ldn, void* Yh, const KnnPanelPlan& p, int32_t N, int32_t D, hipStream_t s);
+// the column sample: row t of the sample image = row min(N - 1, t * stride) of the query image
+void launch_panel_sample(const void* Yh, void* Ys, const KnnPanelPlan& p, int32_t N, hipStream_t s);
+// phase A: per (query row, group of sample tiles) maximum fp16 score -> tmax [npad][sample_groups], for the query row
+// blocks [rb_begin, rb_begin + rb_count)
+void launch_panel_tilemax(const void* Yh, const void* Ys, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count,
+                          float* tmax, unsigned* queue, int grid, hipStream_t s);
+// threshold per row = sample_rank-th largest of its tile maxima
+void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float* tau, hipStream_t s);
+// phase B: every (row, column) with fp16 score > tau[row] (diagonal excluded) is appended to the hit list of its
+// (work item, wave): hit_list [(item * 4 + wave) * hit_cap + e] = 8-byte entries {local row << 27 | column, score bits},
+// hit_cnt [item * 4 + wave] (may exceed hit_cap: overflow); item = split * rb_count + (row block - rb_begin)
+void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count, const float* tau,
+                         void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s);
+// per row: `keep` candidates holding the keep best fp16 scores (unsorted, the minimum in the last slot) -> cval / cidx
+// [N][keep]; rows whose candidate set is incomplete (a list overflowed) or too small (< keep) are appended to fail_rows
+// and get an empty list
+void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int32_t N, const void* hit_list,
+                         const int32_t* hit_cnt, float* cval, int32_t* cidx, int32_t* fail_rows, int32_t* fail_count,
+                         hipStream_t s);
+
+}  // namespace osc

@@ -493,12 +493,13 @@ __device__ __forceinline__ uint32_t sim_key(float v) {  // ascending float order
 }
 
 __global__ __launch_bounds__(256) void k_knn_select_any(const float* __restrict__ Sm, int32_t lds_, int32_t N, int32_t k,
-                                                        int32_t row_base, int32_t rows, float* out_val, int32_t* out_idx) {
+                                                        int32_t row_base, int32_t rows, float* out_val, int32_t* out_idx,
+                                                        const int32_t* __restrict__ qrows) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t s_prefix, s_need, s_wave[4][2], s_base[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= rows) return;
-  const int row = row_base + blockIdx.x;
+  const int row = qrows ? qrows[blockIdx.x] : row_base + (int)blockIdx.x;  // qrows: Sm row b scores lattice row qrows[b]
   const float* srow = Sm + (size_t)blockIdx.x * lds_;
   // radix select of the k-th largest key among the N - 1 off-diagonal entries
   uint32_t prefix = 0, need = (uint32_t)k;  // entries still to be taken from the current prefix class
@@ -943,6 +944,65 @@ __global__ __launch_bounds__(256) void k_knn_rescore(const float* __restrict__ Y
   }
 }
 
+// ---- exact scores of a FEW query rows against all columns (the prefilter routes' fallback when only a handful of rows
+// could not be proven): a wave keeps up to four query rows in registers and streams over its share of the columns; the
+// per-lane partial sums and the butterfly are those of k_knn_rescore, so the scores are bit-identical to the re-scored
+// rows'.  Sm[q][j] = <Yn_qrows[q], Yn_j>; k_knn_select_any then picks each row's k best.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_rows_scores(const float* __restrict__ Yn, int32_t ldn, int32_t N,
+                                                     const int32_t* __restrict__ qrows, int32_t nq, float* __restrict__ Sm,
+                                                     int32_t lds_) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  const int q0 = blockIdx.y * 4;
+  float4 yq[4][NCH];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int q = min(q0 + u, nq - 1);
+    const float* yi = Yn + (size_t)qrows[q] * ldn;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = lane * 4 + ch * 256;
+      yq[u][ch] = c < ldn ? ld4(yi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int j = wid; j < N; j += nw) {
+    const float* yj = Yn + (size_t)j * ldn;
+    float4 b[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = lane * 4 + ch * 256;
+      b[ch] = c < ldn ? ld4(yj + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float ss[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c = lane * 4 + ch * 256;
+        if (c < ldn) {
+          const float4 a = yq[u][ch];
+          s = fmaf(a.x, b[ch].x, s);
+          s = fmaf(a.y, b[ch].y, s);
+          s = fmaf(a.z, b[ch].z, s);
+          s = fmaf(a.w, b[ch].w, s);
+        }
+      }
+      ss[u] = s;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ss[u] += __shfl_xor(ss[u], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + u < nq) Sm[(size_t)(q0 + u) * lds_ + j] = ss[u];
+    }
+  }
+}
+
 // one wave per row: rank-select the k best of the S*KC candidates -> sorted (sim desc, idx asc), clipped at 0
 __global__ __launch_bounds__(256) void k_knn_merge(const float* cand_val, const int32_t* cand_idx, int32_t ncand,
                                                    int32_t row_begin, int32_t N, int32_t k, float* out_val,
@@ -1101,7 +1161,11 @@ KnnPlan knn_plan(int32_t N, int32_t keep, int32_t slots, int rb_begin, int rb_co
   // the per-item list warm-up (k log) small.
   int best_S = 1;
   double best_cost = 1e300;
-  for (int S = 1; S <= std::min(col_tiles, 16); ++S) {
+  // a handful of row blocks (the per-row exact fallback of the prefilter routes): up to 64 splits, so that the sweep
+  // of one 128-row block is spread over 64 workgroups instead of 16 (3.5 -> 0.9 ms at N = 100k)
+  // (bounded by the merge's candidate count S x KC <= 2048: its rank-select is quadratic in it)
+  const int max_S = (!f16 && p.row_blocks * 16 < slots / 2) ? std::max(16, std::min(64, 2048 / p.KC)) : 16;
+  for (int S = 1; S <= std::min(col_tiles, max_S); ++S) {
     const int tiles_per = (col_tiles + S - 1) / S;
     const int S_eff = (col_tiles + tiles_per - 1) / tiles_per;
     if (S_eff != S) continue;
@@ -1202,8 +1266,25 @@ void launch_knn_rows_any(const float* Yn, int32_t ldn, int32_t N, int32_t k, int
   hipLaunchKernelGGL(k_knn_dense, dim3((N + BN - 1) / BN, (rows + BM - 1) / BM), dim3(256), 0, s, Yn, ldn, N, Sm, lds_,
                      row_begin);
   hipLaunchKernelGGL(k_knn_select_any, dim3((unsigned)rows), dim3(256), 0, s, Sm, lds_, N, k, row_begin, rows, out_val,
-                     out_idx);
+                     out_idx, nullptr);
   HIP_CHECK(hipGetLastError());
+}
+
+bool launch_knn_few_rows(const float* Yn, int32_t ldn, int32_t N, int32_t k, const int32_t* qrows, int32_t nq, float* Sm,
+                         int32_t lds_, float* out_val, int32_t* out_idx, hipStream_t s) {
+  const int nch = (ldn + 255) / 256;
+  if (nq <= 0 || nch > 6) return false;
+  const dim3 grid(256, (unsigned)((nq + 3) / 4)), block(256);
+#define OSC_RS(NN) hipLaunchKernelGGL(k_rows_scores<NN>, grid, block, 0, s, Yn, ldn, N, qrows, nq, Sm, lds_)
+  if (nch <= 1) OSC_RS(1);
+  else if (nch == 2) OSC_RS(2);
+  else if (nch == 3) OSC_RS(3);
+  else if (nch == 4) OSC_RS(4);
+  else OSC_RS(6);
+#undef OSC_RS
+  hipLaunchKernelGGL(k_knn_select_any, dim3((unsigned)nq), dim3(256), 0, s, Sm, lds_, N, k, 0, nq, out_val, out_idx, qrows);
+  HIP_CHECK(hipGetLastError());
+  return true;
 }
 
 void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* cand_idx, int32_t N, int32_t k_out,
@@ -1216,6 +1297,9 @@ void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* ca
     row_end = p.nq;
   }
   if (row_end <= row_begin) return;
+  if (shmem > 48 * 1024)
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_merge), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)shmem));
   hipLaunchKernelGGL(k_knn_merge, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), shmem, s, cand_val,
                      cand_idx, ncand, row_begin, row_end, k_out, out_val, out_idx, clip, p.qrows);
   HIP_CHECK(hipGetLastError());

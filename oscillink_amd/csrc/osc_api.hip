@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "comm.hpp"
 #include "knn.hpp"
+#include "knn_gemm.hpp"
 #include "receipts.hpp"
 #include "perm.hpp"
 #include "dynamics.hpp"
@@ -186,6 +187,7 @@ struct osc_lattice {
   int32_t knn_k = 0;
   int32_t knn_fallback_rows = 0;  // rows of the last build the prefilter could not prove and the exact kernel redid
   bool knn_prefilter = false;     // the last build used the fp16 prefilter
+  bool knn_panel = false;         // ... in its register-resident-panel shape (knn_gemm.hip)
   double build_ms = 0.0;
   int64_t nnz = 0;
   int32_t max_deg = 0;
@@ -714,15 +716,43 @@ void build_graph(L& h) {
     if (!strcmp(e, "prefilter")) prefilter = (keep_f >= k + 8);
   }
   if (any_k) prefilter = false;
+  // The prefilter's GEMM has two shapes: "panel" (knn_gemm.hip: query panel in registers, thresholds from a column
+  // sample, hits appended -- D <= 768 and enough row blocks for the sample) and the older 128 x 128 tile with
+  // register-resident sorted lists (k_knn_pref), which serves everything else.
+  static const int panel_min = [] { const char* e = getenv("OSC_KNN_PANEL_MIN"); return e ? std::max(6144, atoi(e)) : 16384; }();
+  bool panel = prefilter && knn_panel_nkt(h.D) != 0 && N >= panel_min &&
+               knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount).ok;
+  if (const char* e = getenv("OSC_KNN_MODE")) {
+    if (!strcmp(e, "panel")) panel = prefilter = (keep_f >= k + 8) && !any_k && knn_panel_nkt(h.D) != 0 && N >= 6144;
+    if (!strcmp(e, "prefilter")) panel = false;
+  }
+  h.knn_panel = panel;
   DevBuf<float> cand_val, cval;
   DevBuf<int32_t> cand_idx, cidx, fail_rows, fail_count;
   DevBuf<float> Yh;  // fp16 image, viewed as float slots
   const int32_t ldh = ((h.D + 63) / 64) * 64;
   h.knn_fallback_rows = 0;
   h.knn_prefilter = prefilter;
+  KnnPanelPlan pp{};
+  DevBuf<float> p_img, p_smp, p_tmax, p_tau;
+  DevBuf<unsigned long long> p_hits;
+  DevBuf<int32_t> p_hcnt;
+  DevBuf<unsigned> p_queue;
+  if (panel) {
+    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount);
+    p_img.alloc((size_t)pp.npad * pp.ldh / 2);
+    p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
+    p_tmax.alloc((size_t)pp.npad * pp.sample_groups);
+    p_tau.alloc((size_t)pp.npad);
+    p_queue.alloc(1);
+    launch_panel_image(Yn.p, ldn, p_img.p, pp, N, h.D, h.stream);
+    launch_panel_sample(p_img.p, p_smp.p, pp, N, h.stream);
+  }
   if (prefilter) {
-    Yh.alloc((size_t)h.N * ldh / 2);
-    launch_to_f16(Yn.p, ldn, Yh.p, ldh, h.N, h.D, h.stream);
+    if (!panel) {
+      Yh.alloc((size_t)h.N * ldh / 2);
+      launch_to_f16(Yn.p, ldn, Yh.p, ldh, h.N, h.D, h.stream);
+    }
     cval.alloc((size_t)h.N * keep_f);
     cidx.alloc((size_t)h.N * keep_f);
     fail_rows.alloc((size_t)h.N);
@@ -749,6 +779,32 @@ void build_graph(L& h) {
           launch_knn_rows_any(Yn.p, ldn, N, k, r, std::min(chunk, row_hi - r), Sm.p, ldS, h.knn_val.p, h.knn_idx.p, h.stream);
         sync(h);  // Sm goes back to the pool at scope exit
       }
+    } else if (panel) {
+      const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true);  // row range + keep for the re-scoring
+      const int grid = std::max(1, std::min(prop.multiProcessorCount, rb_count * pp.S));
+      {
+        ProfScope ps(h, 3);
+        launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
+                             std::max(1, std::min(prop.multiProcessorCount, rb_count * pp.SA)), h.stream);
+        launch_panel_tau(p_tmax.p, pp, N, p_tau.p, h.stream);
+        if (getenv("OSC_PANEL_DEBUG")) {
+          fprintf(stderr, "panel plan: nkt %d npad %d nrb %d sample_tiles %d groups %d x %d rank %d SA %d S %d tiles/split %d keep %d\n",
+                  pp.nkt, pp.npad, pp.nrb, pp.sample_tiles, pp.sample_groups, pp.group_tiles, pp.sample_rank, pp.SA, pp.S,
+                  pp.tiles_per_split, pp.keep);
+          if (const char* e = getenv("OSC_PANEL_NOHITS")) {
+            std::vector<float> big((size_t)pp.npad, (float)atof(e));
+            HIP_CHECK(hipMemcpyAsync(p_tau.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, h.stream));
+            sync(h);
+          }
+        }
+        p_hits.alloc((size_t)rb_count * pp.S * 4 * pp.hit_cap);  // one list per (work item, wave)
+        p_hcnt.alloc((size_t)rb_count * pp.S * 4);
+        launch_panel_filter(p_img.p, pp, N, rb_begin, rb_count, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, grid, h.stream);
+      }
+      launch_panel_select(pp, rb_begin, rb_count, N, p_hits.p, p_hcnt.p, cval.p, cidx.p, fail_rows.p, fail_count.p,
+                          h.stream);
+      launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
+                         fail_count.p, h.stream);
     } else if (prefilter) {
       const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true);
       const size_t ncand = (size_t)h.N * plan.S * plan.KC;
@@ -787,7 +843,15 @@ void build_graph(L& h) {
     HIP_CHECK(hipMemcpyAsync(&nfail, fail_count.p, 4, hipMemcpyDeviceToHost, h.stream));
     sync(h);
     h.knn_fallback_rows = nfail;
-    if (nfail > 0) {  // redo the unproven rows with the exact kernel (ties / dense clusters of near-equal scores)
+    bool few_done = false;
+    if (nfail > 0 && nfail <= 32) {  // a handful of rows: stream the columns once, select per row (0.15 vs 3.9 ms at N = 100k)
+      const int32_t ldS = ((N + 31) / 32) * 32;
+      DevBuf<float> Sm;
+      Sm.alloc((size_t)nfail * ldS);
+      few_done = launch_knn_few_rows(Yn.p, ldn, N, k, fail_rows.p, nfail, Sm.p, ldS, h.knn_val.p, h.knn_idx.p, h.stream);
+      if (few_done) sync(h);  // Sm goes back to the pool at scope exit
+    }
+    if (nfail > 0 && !few_done) {  // redo the unproven rows with the exact kernel (ties / dense clusters of near-equal scores)
       KnnPlan plan = knn_plan(N, k, slots, 0, (nfail + 127) / 128, false);
       plan.qrows = fail_rows.p;
       plan.nq = nfail;
@@ -1689,7 +1753,7 @@ int osc_graph_stats(osc_handle h, int64_t* nnz, int32_t* max_deg, double* build_
 
 int osc_build_info(osc_handle h, int32_t* prefilter, int32_t* fallback_rows, int64_t* small_solves) {
   return guarded(h, [&](L& l) {
-    if (prefilter) *prefilter = l.knn_prefilter ? 1 : 0;
+    if (prefilter) *prefilter = l.knn_prefilter ? (l.knn_panel ? 2 : 1) : 0;
     if (fallback_rows) *fallback_rows = l.knn_fallback_rows;
     if (small_solves) *small_solves = l.small_solves;
   });

@@ -455,7 +455,8 @@ def test_full_config3_properties(amd, orc, monkeypatch):
     psi = Y[:32].mean(axis=0)
     psi = (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
     lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
-    assert lat.build_info()["prefilter"] == 1 and lat.build_info()["fallback_rows"] == 0
+    # the default route at this size: the register-resident-panel prefilter (2); a handful of rows may fail the proof
+    assert lat.build_info()["prefilter"] == 2 and lat.build_info()["fallback_rows"] <= 8
     rp, col, a, w, sd = lat.graph_csr()
     deg = np.diff(rp)
     assert deg.max() <= k and a.min() > 0
@@ -808,6 +809,63 @@ def test_random_shapes_prefilter_vs_exact_vs_oracle(amd, orc, monkeypatch):
             eo = set(zip(r.tolist(), c.tolist()))
             eb = set(zip(np.repeat(np.arange(N), np.diff(b[0])).tolist(), b[1].tolist()))
             assert len(eo ^ eb) <= 4, (N, D, k, len(eo ^ eb))
+
+
+def _knn_sets(lat, N, k):
+    import ctypes as C
+
+    from oscillink_amd import _native as nat
+
+    idx = np.zeros((N, k), dtype=np.int32)
+    ke = C.c_int32(0)
+    lat._call("osc_get_knn_lists", nat.i32(idx), None, C.byref(ke))
+    assert ke.value == k
+    return np.sort(idx, axis=1)
+
+
+@pytest.mark.parametrize("N,D,k,kind", [(16500, 300, 16, "iid"), (20000, 600, 32, "iid"), (40000, 768, 64, "iid"),
+                                        (16384, 384, 8, "iid"), (20000, 700, 32, "clustered"),
+                                        (16400, 130, 24, "dups")])
+def test_panel_prefilter_route_gives_the_exact_lists(amd, N, D, k, kind, monkeypatch):
+    """The three device routes to the per-row top-k lists -- panel prefilter (register-resident query panel, sampled
+    thresholds, appended hits; the default from N = 16384 at D <= 768), tile prefilter (in-kernel sorted lists) and the
+    all-fp32 kernel -- on inputs that stress the panel route's assumptions: ragged N and D (both K depths, 6 and 12
+    steps), k up to 64 (keep 96: narrower sub-ranges in the select), tight clusters (thresholds near the top of the
+    range, most rows fail the proof and are redone exactly) and exact duplicates (ties at the threshold).  A row may
+    differ between routes only by a rank-k near-tie (gap below fp32 summation noise)."""
+    rng = np.random.default_rng(N + D + k)
+    if kind == "iid":
+        Y = rng.standard_normal((N, D), dtype=np.float32)
+    elif kind == "clustered":
+        nc = N // 100
+        Y = rng.standard_normal((nc, D), dtype=np.float32)[np.repeat(np.arange(nc), 100)][:N]
+        Y = (Y + 0.35 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+    else:  # every row appears 40 times: more exact ties than k
+        base = rng.standard_normal((N // 40 + 1, D), dtype=np.float32)
+        Y = base[np.arange(N) % base.shape[0]].copy()
+    lists, info = {}, {}
+    for mode in ("panel", "prefilter", "exact"):
+        monkeypatch.setenv("OSC_KNN_MODE", mode)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        info[mode] = lat.build_info()
+        lists[mode] = (_knn_sets(lat, N, k), lat.graph_csr())
+        lat.close()
+    assert info["panel"]["prefilter"] == 2 and info["prefilter"]["prefilter"] == 1 and info["exact"]["prefilter"] == 0
+    if kind == "dups":  # ties are broken by index in every route: the lattice must be identical
+        assert np.array_equal(lists["panel"][1][0], lists["exact"][1][0])
+        assert np.array_equal(lists["panel"][1][1], lists["exact"][1][1])
+        return
+    # in tight clusters the k-th and (k+1)-th neighbours are often within fp32 summation noise of each other
+    allowed = N // 200 if kind == "clustered" else max(8, N // 2000)
+    for mode in ("panel", "prefilter"):
+        differ = int((lists[mode][0] != lists["exact"][0]).any(axis=1).sum())
+        assert differ <= allowed, (mode, differ)
+    # the two prefilter routes re-score with the same arithmetic; which rows they can prove (and which go to the exact
+    # kernel instead) may differ in tight clusters
+    differ = int((lists["panel"][0] != lists["prefilter"][0]).any(axis=1).sum())
+    assert differ <= (allowed if kind == "clustered" else max(4, N // 4000)), differ
+    if kind == "iid":
+        assert info["panel"]["fallback_rows"] <= 8
 
 
 def test_internal_row_order_is_invisible(amd, orc, monkeypatch):
