@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 namespace osc {
 namespace {
@@ -36,6 +37,14 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {  // f(std::integral_constant<int, I>{}) for I in [I, N): compile-time indices
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 constexpr int RING = 6;
 constexpr unsigned STAGE_BYTES = 16384;  // one K step of a column tile: 128 rows x 128 B
@@ -127,21 +136,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int q = 0; q < 4; ++q) { OSC_PIECE(bsrc[q], st, st, q); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int ct = t0; ct < t1; ++ct) {
+    // ---- one column tile: the K loop into acc[CUR]; in MODE 1 the hit test of the PREVIOUS tile (acc[CUR ^ 1]) is
+    // spread over the K loop, one query-row register per MFMA group: its VALU work issues in the shadow of the matrix
+    // pipe instead of between tiles (at one wave per SIMD nothing else would hide it: 16.6 -> 14 ms at config 3)
+    // (the overlapped form needs both accumulator sets and the 192-register panel live at once: hipcc spills 93
+    // registers at D = 768, so it stays off; the plain form below tests the tile's own accumulators after its K loop)
+#ifdef OSC_PANEL_PIPE
+    constexpr bool PIPE = MODE == 1;
+#else
+    constexpr bool PIPE = false;
+#endif
+    f32x16 acc[PIPE ? 2 : 1][4];
+    // A wave-level decision (VALU compare -> scalar branch) costs ~25 cycles at one wave per SIMD, a taken branch more,
+    // so the test is hierarchical and its compares are issued in batches ahead of the branches that consume them:
+    // 16 row-register tests (maximum of the register's four subtile values against the row's threshold), then, for the
+    // ~7 registers per tile with a hit, the four subtile masks, then the hits (about 9 per wave and tile).
+    auto row_mask = [&](auto GC, const f32x16(&pa)[4]) -> unsigned long long {
+      constexpr int g = decltype(GC)::value;
+      return __ballot(fmaxf(fmaxf(pa[0][g], pa[1][g]), fmaxf(pa[2][g], pa[3][g])) > taug[g]);
+    };
+    auto hit_rows = [&](auto GC, const f32x16(&pa)[4], int pct) {  // query-row register g of the tile pct has a hit
+      constexpr int g = decltype(GC)::value;
+      const int rl = (g & 3) + 8 * (g >> 2) + 4 * h;  // local row of the wave's 32
+      const int grow = rb * 128 + 32 * wave + rl;
+      const int cbase = pct * 128 + l31;
+      const bool special = pct == rb || (pct + 1) * 128 > a.N;  // the tile holds the diagonal or the ragged tail
+      unsigned long long mk[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bool pred = pa[t][g] > taug[g];
+        if (special) pred = pred && (cbase + 32 * t) != grow && (cbase + 32 * t) < a.N;  // graph.py:37: no self-similarity
+        mk[t] = __ballot(pred);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (mk[t] == 0ull) continue;
+        const bool pred = (mk[t] >> lane) & 1ull;
+        const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[t] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[t], 0u));
+        if (pred && pos < HB_CAP)
+          hitbuf[pos] = make_uint2(((unsigned)rl << 27) | (unsigned)(cbase + 32 * t), __float_as_uint(pa[t][g]));
+        wcnt += __popcll(mk[t]);
+      }
+    };
+    auto hit_test = [&](auto GC, const f32x16(&pa)[4], int pct) {  // one register: test + hits (the overlapped form)
+      if (row_mask(GC, pa) != 0ull) hit_rows(GC, pa, pct);
+    };
+    auto hit_test_tile = [&](const f32x16(&pa)[4], int pct) {  // all 16 registers, compares batched ahead of the branches
+      unsigned long long fm[16];
+      static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, pa); });
+      static_for<0, 16>([&](auto GC) {
+        if (fm[decltype(GC)::value] != 0ull) hit_rows(GC, pa, pct);
+      });
+    };
+    auto k_loop = [&](auto CC, int ct, bool have_prev) {
+      constexpr int CUR = decltype(CC)::value;
       const bool last_tile = ct + 1 == t1;
-      f32x16 acc[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
       const _Float16* nsrc[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) nsrc[q] = bsrc[q] + tile_stride;
       // K steps in pairs (one barrier per 32 MFMAs): pair pr reads stages (2 pr) % 6, (2 pr + 1) % 6 and fetches the pair
       // two pairs ahead (of this tile or the next) into the stages the previous pair has released
-#pragma unroll
-      for (int pr = 0; pr < NKT / 2; ++pr) {
-        const bool next_tile = 2 * pr + 4 >= NKT;
+      static_for<0, NKT / 2>([&](auto PR) {
+        constexpr int pr = decltype(PR)::value;
+        constexpr bool next_tile = 2 * pr + 4 >= NKT;
         const bool fetch = !(next_tile && last_tile);
         v4f fa[4], fb[4];
         auto read_frags = [&](int st, int sl, v4f(&bv)[4]) {
@@ -149,41 +206,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int t = 0; t < 4; ++t) bv[t] = *(const v4f*)(ldsc + rd[sl] + st * STAGE_BYTES + t * 4096);
         };
         read_frags((2 * pr) % RING, 0, fa);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {  // eight k16 slices: two K steps
-          const int kt = 2 * pr + (u >> 2), sl = u & 3;
+        static_for<0, 8>([&](auto UU) {  // eight k16 slices: two K steps
+          constexpr int u = decltype(UU)::value;
+          constexpr int kt = 2 * pr + (u >> 2), sl = u & 3;
           v4f(&cur)[4] = (u & 1) ? fb : fa;
           v4f(&nxt)[4] = (u & 1) ? fa : fb;
-          if (u + 1 < 8) read_frags((2 * pr + ((u + 1) >> 2)) % RING, (u + 1) & 3, nxt);
+          if constexpr (u + 1 < 8) read_frags((2 * pr + ((u + 1) >> 2)) % RING, (u + 1) & 3, nxt);
           __builtin_amdgcn_sched_barrier(0);
+          // The MFMAs are written as asm to pin the register classes: the panel (srcA) in ACCUMULATION registers, the
+          // accumulators in VECTOR registers.  hipcc's own choice was the reverse for the accumulators, which cost a
+          // v_accvgpr_read per value in the hit test (VALU compares cannot read AGPRs) and shuffled panel slices
+          // between the two files every tile.  The tile's first slice starts from C = 0 (inline constant).
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[kt * 4 + sl], __builtin_bit_cast(half8, cur[t]), acc[t], 0,
-                                                            0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (u < 4 && fetch) {  // two DMA pieces behind each of the first four MFMA groups
-            const int fk = (2 * pr + 4 + (u >> 1)) % NKT, fst = (2 * pr + 4 + (u >> 1)) % RING;
-#pragma unroll
-            for (int q = 2 * (u & 1); q < 2 * (u & 1) + 2; ++q) {
-              if (next_tile) { OSC_PIECE(nsrc[q], fk, fst, q); } else { OSC_PIECE(bsrc[q], fk, fst, q); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+          for (int t = 0; t < 4; ++t) {
+            if constexpr (pr == 0 && u == 0)
+              asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[CUR][t]) : "a"(areg[kt * 4 + sl]), "v"(cur[t]));
+            else
+              asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[CUR][t]) : "a"(areg[kt * 4 + sl]), "v"(cur[t]));
           }
-        }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (u < 4) {
+            if (fetch) {  // two DMA pieces behind each of the first four MFMA groups
+              constexpr int fk = (2 * pr + 4 + (u >> 1)) % NKT, fst = (2 * pr + 4 + (u >> 1)) % RING;
+              constexpr int qa = 2 * (u & 1);
+              if constexpr (next_tile) {
+                OSC_PIECE(nsrc[qa], fk, fst, qa);
+                OSC_PIECE(nsrc[qa + 1], fk, fst, qa + 1);
+              } else {
+                OSC_PIECE(bsrc[qa], fk, fst, qa);
+                OSC_PIECE(bsrc[qa + 1], fk, fst, qa + 1);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if constexpr (PIPE) {  // the previous tile's hit test, one query-row register per slot
+            constexpr int STRIDE = NKT * 4 / 16;
+            constexpr int slot = pr * 8 + u;
+            if constexpr (slot % STRIDE == 0 && slot / STRIDE < 16) {
+              if (have_prev) hit_test(std::integral_constant<int, slot / STRIDE>{}, acc[CUR ^ 1], ct - 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        });
         if (fetch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the pair fetched during this pair stays in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // raw barrier: __syncthreads() would make hipcc drain vmcnt for the epilogue's candidate stores, and with them
-        // the DMA pieces meant to stay in flight; every ds_read of the pair has been consumed by its MFMAs already
+        // raw barrier: __syncthreads() would make hipcc drain vmcnt for later stores, and with them the DMA pieces meant
+        // to stay in flight; every ds_read of the pair has been consumed by its MFMAs already
         __builtin_amdgcn_s_barrier();
-      }
+      });
 #pragma unroll
       for (int q = 0; q < 4; ++q) bsrc[q] = nsrc[q];
-      // ---- epilogue of the 32 x 128 score tile ----------------------------------------------------------------
-      if constexpr (MODE == 0) {
+    };
+    if constexpr (PIPE) {
+      int ct = t0;
+      bool have_prev = false;
+      for (;;) {
+        k_loop(std::integral_constant<int, 0>{}, ct, have_prev);
+        have_prev = true;
+        if (++ct >= t1) {
+          asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#define OSC_HT(G) hit_test(std::integral_constant<int, G>{}, acc[0], ct - 1);
+          OSC_HT(0) OSC_HT(1) OSC_HT(2) OSC_HT(3) OSC_HT(4) OSC_HT(5) OSC_HT(6) OSC_HT(7)
+          OSC_HT(8) OSC_HT(9) OSC_HT(10) OSC_HT(11) OSC_HT(12) OSC_HT(13) OSC_HT(14) OSC_HT(15)
+#undef OSC_HT
+          break;
+        }
+        k_loop(std::integral_constant<int, 1>{}, ct, true);
+        if (++ct >= t1) {
+          asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#define OSC_HT(G) hit_test(std::integral_constant<int, G>{}, acc[1], ct - 1);
+          OSC_HT(0) OSC_HT(1) OSC_HT(2) OSC_HT(3) OSC_HT(4) OSC_HT(5) OSC_HT(6) OSC_HT(7)
+          OSC_HT(8) OSC_HT(9) OSC_HT(10) OSC_HT(11) OSC_HT(12) OSC_HT(13) OSC_HT(14) OSC_HT(15)
+#undef OSC_HT
+          break;
+        }
+      }
+    } else if constexpr (MODE == 1) {
+      for (int ct = t0; ct < t1; ++ct) {
+        k_loop(std::integral_constant<int, 0>{}, ct, false);
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the asm MFMAs' results -> VALU reads: hipcc pads nothing for asm
+        hit_test_tile(acc[0], ct);
+      }
+    } else {
+      for (int ct = t0; ct < t1; ++ct) {
+        k_loop(std::integral_constant<int, 0>{}, ct, false);
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        // ---- tile maxima of the sample sweep --------------------------------------------------------------------
 #pragma unroll
         for (int g = 0; g < 16; ++g)
-          taug[g] = fmaxf(taug[g], fmaxf(fmaxf(acc[0][g], acc[1][g]), fmaxf(acc[2][g], acc[3][g])));
-        if ((ct + 1) % a.group_tiles == 0 || last_tile) {  // close the group: maximum over its columns
+          taug[g] = fmaxf(taug[g], fmaxf(fmaxf(acc[0][0][g], acc[0][1][g]), fmaxf(acc[0][2][g], acc[0][3][g])));
+        if ((ct + 1) % a.group_tiles == 0 || ct + 1 == t1) {  // close the group: maximum over its columns
           const int grp = ct / a.group_tiles;
 #pragma unroll
           for (int g = 0; g < 16; ++g) {
@@ -192,28 +304,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));  // within the 32 lanes of the half
             if (l31 == 0) a.tmax[(size_t)(grow0 + (g & 3) + 8 * (g >> 2)) * a.ngroups + grp] = m;
             taug[g] = -3.0e38f;
-          }
-        }
-      } else {
-        const int cbase = ct * 128 + l31;
-        const bool ragged = (ct + 1) * 128 > a.N;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const float m = fmaxf(fmaxf(acc[0][g], acc[1][g]), fmaxf(acc[2][g], acc[3][g]));
-          if (__ballot(m > taug[g]) == 0ull) continue;  // the common case: nothing of this row beats its threshold
-          const int rl = (g & 3) + 8 * (g >> 2) + 4 * h;  // local row of the wave's 32
-          const int grow = rb * 128 + 32 * wave + rl;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float c = acc[t][g];
-            const int col = cbase + 32 * t;
-            const bool pred = c > taug[g] && col != grow && !(ragged && col >= a.N);  // graph.py:37: no self-similarity
-            const unsigned long long mk = __ballot(pred);
-            if (mk == 0ull) continue;
-            const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
-                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-            if (pred && pos < HB_CAP) hitbuf[pos] = make_uint2(((unsigned)rl << 27) | (unsigned)col, __float_as_uint(c));
-            wcnt += __popcll(mk);
           }
         }
       }

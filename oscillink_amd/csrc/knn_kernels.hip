@@ -492,11 +492,12 @@ __device__ __forceinline__ uint32_t sim_key(float v) {  // ascending float order
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ __launch_bounds__(256) void k_knn_select_any(const float* __restrict__ Sm, int32_t lds_, int32_t N, int32_t k,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_knn_select_any(const float* __restrict__ Sm, int32_t lds_, int32_t N, int32_t k,
                                                         int32_t row_base, int32_t rows, float* out_val, int32_t* out_idx,
                                                         const int32_t* __restrict__ qrows) {
   __shared__ uint32_t hist[256];
-  __shared__ uint32_t s_prefix, s_need, s_wave[4][2], s_base[2];
+  __shared__ uint32_t s_prefix, s_need, s_wave[NT / 64][2], s_base[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= rows) return;
   const int row = qrows ? qrows[blockIdx.x] : row_base + (int)blockIdx.x;  // qrows: Sm row b scores lattice row qrows[b]
@@ -505,10 +506,10 @@ __global__ __launch_bounds__(256) void k_knn_select_any(const float* __restrict_
   uint32_t prefix = 0, need = (uint32_t)k;  // entries still to be taken from the current prefix class
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
-    hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const uint32_t mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-    for (int c = tid; c < N; c += 256) {
+    for (int c = tid; c < N; c += NT) {
       if (c == row) continue;
       const uint32_t key = sim_key(srow[c]);
       if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256) void k_knn_select_any(const float* __restrict_
   __syncthreads();
   float* ov = out_val + (size_t)row * k;
   int32_t* oi = out_idx + (size_t)row * k;
-  for (int c0 = 0; c0 < N; c0 += 256) {
+  for (int c0 = 0; c0 < N; c0 += NT) {
     const int c = c0 + tid;
     float v = 0.f;
     uint32_t key = 0;
@@ -571,8 +572,10 @@ __global__ __launch_bounds__(256) void k_knn_select_any(const float* __restrict_
     }
     __syncthreads();
     if (tid == 0) {
-      s_base[0] += s_wave[0][0] + s_wave[1][0] + s_wave[2][0] + s_wave[3][0];
-      s_base[1] += s_wave[0][1] + s_wave[1][1] + s_wave[2][1] + s_wave[3][1];
+      for (int w2 = 0; w2 < NT / 64; ++w2) {
+        s_base[0] += s_wave[w2][0];
+        s_base[1] += s_wave[w2][1];
+      }
     }
     __syncthreads();
   }
@@ -1265,7 +1268,7 @@ void launch_knn_rows_any(const float* Yn, int32_t ldn, int32_t N, int32_t k, int
   if (row_begin % BM != 0) throw std::runtime_error("launch_knn_rows_any: row_begin must be a multiple of 128");
   hipLaunchKernelGGL(k_knn_dense, dim3((N + BN - 1) / BN, (rows + BM - 1) / BM), dim3(256), 0, s, Yn, ldn, N, Sm, lds_,
                      row_begin);
-  hipLaunchKernelGGL(k_knn_select_any, dim3((unsigned)rows), dim3(256), 0, s, Sm, lds_, N, k, row_begin, rows, out_val,
+  hipLaunchKernelGGL(k_knn_select_any<256>, dim3((unsigned)rows), dim3(256), 0, s, Sm, lds_, N, k, row_begin, rows, out_val,
                      out_idx, nullptr);
   HIP_CHECK(hipGetLastError());
 }
@@ -1282,7 +1285,9 @@ bool launch_knn_few_rows(const float* Yn, int32_t ldn, int32_t N, int32_t k, con
   else if (nch == 4) OSC_RS(4);
   else OSC_RS(6);
 #undef OSC_RS
-  hipLaunchKernelGGL(k_knn_select_any, dim3((unsigned)nq), dim3(256), 0, s, Sm, lds_, N, k, 0, nq, out_val, out_idx, qrows);
+  // few rows, each a pass over all N scores: 1024 threads per row
+  hipLaunchKernelGGL(k_knn_select_any<1024>, dim3((unsigned)nq), dim3(1024), 0, s, Sm, lds_, N, k, 0, nq, out_val, out_idx,
+                     qrows);
   HIP_CHECK(hipGetLastError());
   return true;
 }
