@@ -102,12 +102,8 @@ __device__ __forceinline__ void block_fold(float4 (&dot)[NCH], float* red /*[4][
   }
 }
 
-#ifndef OSC_SPMM_U1
-#define OSC_SPMM_U1 2
-#endif
-#ifndef OSC_SPMM_U8
-#define OSC_SPMM_U8 2  // 8 lanes per row (xs mode): 8 rows per wave, 2 neighbour rows of each in flight (4 and 8: slower)
-#endif
+constexpr int OSC_SPMM_U1 = 2;
+constexpr int OSC_SPMM_U8 = 2;  // 8 lanes per row (xs mode): 8 rows per wave, 2 neighbour rows of each in flight (4 and 8: slower)
 template <int NCH>
 struct Unroll {  // neighbour rows fetched per batch (all loads in flight together)
   static constexpr int U = NCH == 1 ? OSC_SPMM_U1 : (NCH <= 3 ? 4 : (NCH <= 6 ? 2 : 1));

@@ -136,21 +136,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int q = 0; q < 4; ++q) { OSC_PIECE(bsrc[q], st, st, q); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- one column tile: the K loop into acc[CUR]; in MODE 1 the hit test of the PREVIOUS tile (acc[CUR ^ 1]) is
-    // spread over the K loop, one query-row register per MFMA group: its VALU work issues in the shadow of the matrix
-    // pipe instead of between tiles (at one wave per SIMD nothing else would hide it: 16.6 -> 14 ms at config 3)
-    // (the overlapped form needs both accumulator sets and the 192-register panel live at once: hipcc spills 93
-    // registers at D = 768, so it stays off; the plain form below tests the tile's own accumulators after its K loop)
-#ifdef OSC_PANEL_PIPE
-    constexpr bool PIPE = MODE == 1;
-#else
-    constexpr bool PIPE = false;
-#endif
-    f32x16 acc[PIPE ? 2 : 1][4];
-    // A wave-level decision (VALU compare -> scalar branch) costs ~25 cycles at one wave per SIMD, a taken branch more,
-    // so the test is hierarchical and its compares are issued in batches ahead of the branches that consume them:
-    // 16 row-register tests (maximum of the register's four subtile values against the row's threshold), then, for the
-    // ~7 registers per tile with a hit, the four subtile masks, then the hits (about 9 per wave and tile).
+    // ---- one column tile: the K loop, then the tile's epilogue on its accumulators.  (Spreading the PREVIOUS tile's
+    // hit test over the K loop -- its VALU work in the shadow of the matrix pipe -- needs two accumulator sets next to
+    // the 192-register panel: hipcc spills 51 registers at D = 768 even with the register classes pinned, so the test
+    // runs between tiles.)
+    f32x16 acc[4];
     auto row_mask = [&](auto GC, const f32x16(&pa)[4]) -> unsigned long long {
       constexpr int g = decltype(GC)::value;
       return __ballot(fmaxf(fmaxf(pa[0][g], pa[1][g]), fmaxf(pa[2][g], pa[3][g])) > taug[g]);
@@ -178,9 +168,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         wcnt += __popcll(mk[t]);
       }
     };
-    auto hit_test = [&](auto GC, const f32x16(&pa)[4], int pct) {  // one register: test + hits (the overlapped form)
-      if (row_mask(GC, pa) != 0ull) hit_rows(GC, pa, pct);
-    };
     auto hit_test_tile = [&](const f32x16(&pa)[4], int pct) {  // all 16 registers, compares batched ahead of the branches
       unsigned long long fm[16];
       static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, pa); });
@@ -188,8 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (fm[decltype(GC)::value] != 0ull) hit_rows(GC, pa, pct);
       });
     };
-    auto k_loop = [&](auto CC, int ct, bool have_prev) {
-      constexpr int CUR = decltype(CC)::value;
+    auto k_loop = [&](int ct) {
       const bool last_tile = ct + 1 == t1;
       const _Float16* nsrc[4];
 #pragma unroll
@@ -220,9 +206,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             if constexpr (pr == 0 && u == 0)
-              asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[CUR][t]) : "a"(areg[kt * 4 + sl]), "v"(cur[t]));
+              asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[t]) : "a"(areg[kt * 4 + sl]), "v"(cur[t]));
             else
-              asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[CUR][t]) : "a"(areg[kt * 4 + sl]), "v"(cur[t]));
+              asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[t]) : "a"(areg[kt * 4 + sl]), "v"(cur[t]));
           }
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (u < 4) {
@@ -239,14 +225,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               __builtin_amdgcn_sched_barrier(0);
             }
           }
-          if constexpr (PIPE) {  // the previous tile's hit test, one query-row register per slot
-            constexpr int STRIDE = NKT * 4 / 16;
-            constexpr int slot = pr * 8 + u;
-            if constexpr (slot % STRIDE == 0 && slot / STRIDE < 16) {
-              if (have_prev) hit_test(std::integral_constant<int, slot / STRIDE>{}, acc[CUR ^ 1], ct - 1);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
         });
         if (fetch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the pair fetched during this pair stays in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -257,44 +235,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int q = 0; q < 4; ++q) bsrc[q] = nsrc[q];
     };
-    if constexpr (PIPE) {
-      int ct = t0;
-      bool have_prev = false;
-      for (;;) {
-        k_loop(std::integral_constant<int, 0>{}, ct, have_prev);
-        have_prev = true;
-        if (++ct >= t1) {
-          asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-#define OSC_HT(G) hit_test(std::integral_constant<int, G>{}, acc[0], ct - 1);
-          OSC_HT(0) OSC_HT(1) OSC_HT(2) OSC_HT(3) OSC_HT(4) OSC_HT(5) OSC_HT(6) OSC_HT(7)
-          OSC_HT(8) OSC_HT(9) OSC_HT(10) OSC_HT(11) OSC_HT(12) OSC_HT(13) OSC_HT(14) OSC_HT(15)
-#undef OSC_HT
-          break;
-        }
-        k_loop(std::integral_constant<int, 1>{}, ct, true);
-        if (++ct >= t1) {
-          asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-#define OSC_HT(G) hit_test(std::integral_constant<int, G>{}, acc[1], ct - 1);
-          OSC_HT(0) OSC_HT(1) OSC_HT(2) OSC_HT(3) OSC_HT(4) OSC_HT(5) OSC_HT(6) OSC_HT(7)
-          OSC_HT(8) OSC_HT(9) OSC_HT(10) OSC_HT(11) OSC_HT(12) OSC_HT(13) OSC_HT(14) OSC_HT(15)
-#undef OSC_HT
-          break;
-        }
-      }
-    } else if constexpr (MODE == 1) {
+    if constexpr (MODE == 1) {
       for (int ct = t0; ct < t1; ++ct) {
-        k_loop(std::integral_constant<int, 0>{}, ct, false);
+        k_loop(ct);
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the asm MFMAs' results -> VALU reads: hipcc pads nothing for asm
-        hit_test_tile(acc[0], ct);
+        hit_test_tile(acc, ct);
       }
     } else {
       for (int ct = t0; ct < t1; ++ct) {
-        k_loop(std::integral_constant<int, 0>{}, ct, false);
+        k_loop(ct);
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
         // ---- tile maxima of the sample sweep --------------------------------------------------------------------
 #pragma unroll
         for (int g = 0; g < 16; ++g)
-          taug[g] = fmaxf(taug[g], fmaxf(fmaxf(acc[0][0][g], acc[0][1][g]), fmaxf(acc[0][2][g], acc[0][3][g])));
+          taug[g] = fmaxf(taug[g], fmaxf(fmaxf(acc[0][g], acc[1][g]), fmaxf(acc[2][g], acc[3][g])));
         if ((ct + 1) % a.group_tiles == 0 || ct + 1 == t1) {  // close the group: maximum over its columns
           const int grp = ct / a.group_tiles;
 #pragma unroll

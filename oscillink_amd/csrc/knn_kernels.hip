@@ -246,12 +246,7 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
         *reinterpret_cast<float4*>(Bs + srow[q] * LDT + sc4[q]) = rb[q];
       }
       __syncthreads();
-#ifndef OSC_KNN_NOGLOAD  // experiment switch: reuse the first tile's registers (results are wrong)
-      if (kt + 1 < nkt)  // issue next tile's global loads; they land under the MFMAs below
-#else
-      if (false)
-#endif
-      {
+      if (kt + 1 < nkt) {  // issue next tile's global loads; they land under the MFMAs below
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           ra[q] = ld4(a_ptr[q] + (kt + 1) * BK);
@@ -262,17 +257,10 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
       const float* bp = Bs + l31 * LDT + 4 * h;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-#ifndef OSC_KNN_NOLDSREAD
         const float4 av = ld4(ap + 8 * s);
         float4 bv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) bv[t] = ld4(bp + 32 * t * LDT + 8 * s);
-#else  // experiment switch: MFMA on register operands only (results are wrong)
-        const float4 av = ra[s & 3];
-        float4 bv[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bv[t] = rb[(s + t) & 3];
-#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           if constexpr (F16) {
@@ -300,12 +288,7 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ Yn, int3
         const int ccol = ct + 32 * t + l31;
         if (need_mask && (ccol >= cend || ccol == grow)) c = NEG;  // graph.py:37 (diag = -inf) and the ragged tail
         // prefilter scores only pick candidates (ties at the list boundary are covered by the margin): strict test
-#ifdef OSC_KNN_NOEPI  // experiment: GEMM + filter only, no list maintenance (results are wrong)
-        const bool pred = false && (c > thr[g]);
-        asm volatile("" ::"v"(c));
-#else
         const bool pred = (F16 ? (c > thr[g]) : (c >= thr[g])) && (c > NEG);
-#endif
         unsigned long long m = __ballot(pred);
         unsigned m0 = (unsigned)m, m1 = (unsigned)(m >> 32);  // wave-uniform (SGPR) candidate masks of the two halves
         if (m0 | m1) {
@@ -726,28 +709,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_knn_pref(const flo
     const int stage = step % NST;
     // prefetch into the stage whose readers finished before the barrier that ended step-1
     bool issued_now = false;
-#ifndef OSC_PF_NODMA  // experiment switches (wrong results): no DMA after the prologue / no fragment reads / no list update
     if (issued < total) {
       issue_next();
       issued_now = true;
     }
-#endif
     const float* Asw = lds + stage * PF_STAGE + (32 * wave + l31) * BK;
     const float* Bsw = lds + stage * PF_STAGE + BMX * BK + l31 * BK;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int co = (((2 * s + h) ^ swz)) * 4;
-#ifndef OSC_PF_NOLDSREAD
       const float4 av = ld4(Asw + co);
       float4 bv[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) bv[t] = ld4(Bsw + 32 * t * BK + co);
-#else
-      const float4 av = make_float4(co + 1.f, s, h, 1.f);
-      float4 bv[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) bv[t] = make_float4(t, co, 2.f, s);
-#endif
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, av), __builtin_bit_cast(half8, bv[t]),
@@ -769,12 +743,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_knn_pref(const flo
           }
         }
         const float cmax = fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3]));
-#ifdef OSC_PF_NOEPI
-        asm volatile("" ::"v"(cmax));
-        if (false) {
-#else
-        if (__ballot(cmax > thr[g]) != 0ull) {
-#endif  // some column of this row (either half) may enter its list
+        if (__ballot(cmax > thr[g]) != 0ull) {  // some column of this row (either half) may enter its list
           bool touched = false;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -1201,11 +1170,6 @@ void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, 
   if (p.f16) {
     if (p.qrows) throw std::runtime_error("the prefilter kernel has no row-list variant");
     if (p.E > 3) throw std::runtime_error("f16 prefilter supports at most 96 kept candidates");
-#ifdef OSC_KNN_PREF_OLD  // register-staged prefilter (kept for A/B runs)
-    if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
-    else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
-    else if (p.E == 3) hipLaunchKernelGGL((k_knn_topk<3, true, false>), grid, block, 0, s, OSC_KNN_ARGS);
-#else
     static const bool wide = [] { const char* e = getenv("OSC_KNN_PREF_WG"); return e && atoi(e) == 8; }();
     if (!wide) {
       constexpr size_t lds = (size_t)2 * (128 + 128) * BK * 4;
@@ -1225,7 +1189,6 @@ void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, 
       else if (p.E == 2) hipLaunchKernelGGL((k_knn_pref<2, 8, 3>), grid8, block8, lds, s, OSC_KNN_PREF_ARGS);
       else if (p.E == 3) hipLaunchKernelGGL((k_knn_pref<3, 8, 3>), grid8, block8, lds, s, OSC_KNN_PREF_ARGS);
     }
-#endif
   } else if (p.qrows) {
     if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, false, true>), grid, block, 0, s, OSC_KNN_ARGS);
     else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, false, true>), grid, block, 0, s, OSC_KNN_ARGS);

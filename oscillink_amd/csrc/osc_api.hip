@@ -787,16 +787,6 @@ void build_graph(L& h) {
         launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
                              std::max(1, std::min(prop.multiProcessorCount, rb_count * pp.SA)), h.stream);
         launch_panel_tau(p_tmax.p, pp, N, p_tau.p, h.stream);
-        if (getenv("OSC_PANEL_DEBUG")) {
-          fprintf(stderr, "panel plan: nkt %d npad %d nrb %d sample_tiles %d groups %d x %d rank %d SA %d S %d tiles/split %d keep %d\n",
-                  pp.nkt, pp.npad, pp.nrb, pp.sample_tiles, pp.sample_groups, pp.group_tiles, pp.sample_rank, pp.SA, pp.S,
-                  pp.tiles_per_split, pp.keep);
-          if (const char* e = getenv("OSC_PANEL_NOHITS")) {
-            std::vector<float> big((size_t)pp.npad, (float)atof(e));
-            HIP_CHECK(hipMemcpyAsync(p_tau.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, h.stream));
-            sync(h);
-          }
-        }
         p_hits.alloc((size_t)rb_count * pp.S * 4 * pp.hit_cap);  // one list per (work item, wave)
         p_hcnt.alloc((size_t)rb_count * pp.S * 4);
         launch_panel_filter(p_img.p, pp, N, rb_begin, rb_count, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, grid, h.stream);

@@ -22,10 +22,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-#ifndef OSC_SMALL_T
-#define OSC_SMALL_T 512
-#endif
-constexpr int T = OSC_SMALL_T;  // threads per workgroup: one row per thread per sweep keeps the gather latency chain short
+constexpr int T = 512;  // threads per workgroup: one row per thread per sweep keeps the gather latency chain short
 constexpr int NW = T / 64;
 
 // block-wide sum of C per-thread partials -> every thread gets the totals
