@@ -218,6 +218,7 @@ struct osc_lattice {
   DevBuf<double> rz, colsum;
   DevBuf<uint32_t> res_bits, arrive;  // arrive: per-iteration barrier counters (+1 status word) of the one-launch path
   bool small_path = true;             // OSC_SMALL_PATH=0 disables the one-launch CG for small lattices
+  int predicted_iters = 0;            // iterations the last general-path solve of this handle took (0 = unknown)
   DevBuf<int32_t> ell_col_t;          // transposed ELL for the one-launch path (built on first use per graph)
   DevBuf<float> ell_w_t;
   bool ell_t_ready = false;
@@ -949,7 +950,8 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   if (h.spmm_xs == 0) return 0;
   if (h.spmm_xs == 1) return nb;
   if (h.spmm_slab != 0 || h.reordered || (h.ld & 31) != 0 || (h.c0 & 31) != 0) return 0;
-  if (h.N < 32768 || ncols < 96) return 0;
+  // from N = 32768 on, and from 16384 for windows of >= 256 columns (N = 20000, D = 256: apply 43.5 -> 31.4 us)
+  if (h.N < 16384 || (h.N < 32768 && ncols < 256) || ncols < 96) return 0;
   if (xs_groups_for(h, ncols) == 0) return 0;
   return nb;
 }
@@ -1081,8 +1083,8 @@ bool row_mode(const L& h);
 CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol) {
   if (row_mode(h) && b.ld == h.ld) return run_cg_rows(h, op, b, with_path, max_iters, tol);
   {
-    CgResult small{};
-    if (run_cg_small(h, op, b, with_path, max_iters, tol, small)) return small;
+    CgResult one{};
+    if (run_cg_small(h, op, b, with_path, max_iters, tol, one)) return one;
   }
   const int grid = cg_grid(h);
   const size_t nslots = (size_t)max_iters + 2;
@@ -1198,9 +1200,16 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   h.history.clear();
   CgResult out{max_iters, 0.f, b.X};
   const size_t prof_mark = h.prof_pending.size();
+  // Iteration it + 1 is enqueued before iteration it's residual is read -- except behind the iteration the previous
+  // solve of this handle converged in: repeated settles of one lattice take the same count, and the five gated-off
+  // launches of a needless speculative iteration cost ~22 us (8 % of a settle at N = 20000, D = 128).  A wrong guess
+  // costs one host round trip: the iteration is then enqueued after its predecessor's residual has been read.
+  // (Every rank of a sharded solve sees the same residuals, hence takes the same decisions.)
+  const int stop_guess = h.predicted_iters;
+  int enqueued = 1;
   enqueue_iter(1);
   for (int it = 1; it <= max_iters; ++it) {
-    if (it < max_iters) enqueue_iter(it + 1);  // speculative: no-ops if iteration `it` converged
+    if (it < max_iters && it != stop_guess && enqueued == it) enqueue_iter(++enqueued);  // speculative: no-ops if `it` converged
     const float res = wait_residual(it);
     h.history.push_back(res);
     out.res = res;
@@ -1208,7 +1217,9 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       out.iters = it;
       break;
     }
+    if (it < max_iters && enqueued == it) enqueue_iter(++enqueued);  // the guess was wrong: go on
   }
+  h.predicted_iters = out.iters;
   // The solution is complete once the last residual is out; what may still be queued are the gated-off launches of
   // the speculative iteration (they return at once and write nothing).  With the mapped read-back the stream is left
   // to drain on its own -- later calls are ordered behind it anyway; the copy + event path keeps its full wait.

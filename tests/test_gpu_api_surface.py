@@ -375,3 +375,28 @@ def test_failed_rebuild_keeps_the_python_state(amd):
     with pytest.raises(ValueError):
         lat.rebuild_graph(kneighbors=0)
     assert (lat._kneighbors, lat._row_cap_val, lat._deterministic_k, lat._signature()) == before
+
+
+def test_iteration_count_prediction_is_invisible(amd, monkeypatch):
+    """The general CG path skips the speculative launch of the iteration behind the one the previous solve of the handle
+    converged in; when the guess is wrong (different tolerance, different state) the solve must still run to the same
+    iteration count and state as a fresh handle's."""
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    rng = np.random.default_rng(3)
+    Y = rng.normal(size=(900, 24)).astype(np.float32)
+    psi = rng.normal(size=24).astype(np.float32)
+
+    def fresh(tol, max_iters):
+        lat = amd.OscillinkLattice(Y, kneighbors=7)
+        lat.set_query(psi)
+        st = dict(lat.settle(tol=tol, max_iters=max_iters))
+        return st["iters"], lat.residual_history(), lat.U.copy()
+
+    lat = amd.OscillinkLattice(Y, kneighbors=7)
+    lat.set_query(psi)
+    for tol, max_iters in ((1e-3, 12), (1e-3, 12), (1e-6, 12), (1e-1, 12), (1e-9, 5), (1e-3, 12)):
+        lat.reset_U()
+        st = dict(lat.settle(tol=tol, max_iters=max_iters))
+        it, hist, U = fresh(tol, max_iters)
+        assert st["iters"] == it and lat.residual_history() == hist
+        assert np.array_equal(lat.U, U)
