@@ -480,9 +480,9 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus) {
   p.npad = ((N + 127) / 128) * 128;
   p.nrb = p.npad / 128;
   p.keep = keep;
-  // Thresholds: the sample holds one column in rho; tau = the 16th largest tile maximum ~ the 17th-20th best sample
-  // score, so about rho * 18 columns of the full sweep beat it (gamma-distributed: 0.1 % of the rows see fewer than
-  // rho * 6 or more than rho * 35).  rho = keep / 4 puts `keep` at the low tail and 10 keep slots above the high one.
+  // Thresholds: the sample holds one column in rho; tau = the 14th largest tile maximum ~ the 15th-17th best sample
+  // score, so about rho * 16 columns of the full sweep beat it (gamma-distributed: 0.1 % of the rows see fewer than
+  // rho * 6 or more than rho * 32).  rho = keep / 4 puts `keep` at the low tail and 8 keep slots above the high one.
   const double rho = std::max(6.0, keep / 4.0);
   p.sample_tiles = (int32_t)std::max(24.0, std::min(p.nrb / 2.0, std::round(p.nrb / rho)));
   // tile maxima are folded over groups of consecutive sample tiles so that a row has at most 128 of them (the r-th
@@ -492,7 +492,9 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus) {
   p.ok = (double)p.nrb / p.sample_tiles * 8.0 >= (double)keep;
   p.group_tiles = (p.sample_tiles + 127) / 128;
   p.sample_groups = (p.sample_tiles + p.group_tiles - 1) / p.group_tiles;
-  p.sample_rank = 16;
+  // rank 14 (measured at config 3: rank 16 / 14 / 12 / 10 -> build 22.5 / 22.1 / 21.7 / 26.0 ms with 2 / 2 / 21 / 346 rows
+  // short of candidates: below 14 the low tail of the candidate count reaches `keep`)
+  p.sample_rank = 14;
   // column splits: whatever leaves the smallest idle tail on `cus` persistent workgroups (per-item overhead ~1 %)
   // ... and few enough hits per wave and item for its LDS list: 32 rows x ~5 keep / S <= ~2/3 of HB_CAP
   const int s_min = std::max(1, (int)std::ceil(32.0 * 5.0 * keep / (0.66 * HB_CAP)));
