@@ -283,9 +283,11 @@ def extras(lat, N, D, args, sharded):
     lat._call("osc_profile_get", 3, C.byref(launches), C.byref(total_ms))
     lat._call("osc_profile_enable", 0)
     info = lat.build_info()
-    gemm_ms = total_ms.value / 3.0  # per build
-    route = "prefilter: fp16 MFMA top-(k+16) + exact fp32 re-scoring" if info["prefilter"] else (
-        "dense fp32 MFMA + argmax select" if N <= 8192 else "exact fp32 MFMA + running top-k")
+    gemm_ms = total_ms.value / 3.0  # per build: the GEMM + selection kernels (panel route: sample sweep + thresholds + main sweep)
+    route = ("panel prefilter: fp16 MFMA GEMM (query panel in registers) + sampled thresholds + exact fp32 re-scoring"
+             if info["prefilter"] == 2 else
+             "tile prefilter: fp16 MFMA top-(k+16) lists + exact fp32 re-scoring" if info["prefilter"] else
+             "dense fp32 MFMA + argmax select" if N <= 8192 else "exact fp32 MFMA + running top-k")
     peak = MFMA_F16_DENSE_TFLOPS if info["prefilter"] else MFMA_F32_TFLOPS
     flops = 2.0 * N * N * D
     tf = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
