@@ -80,9 +80,17 @@ class FileRendezvous:
         self.put(f"{name}.{self.rank}", blob)
         return [self.get(f"{name}.{r}", timeout_s) for r in range(self.world)]
 
-    def close(self):
-        if self.rank == 0:
-            shutil.rmtree(self.dir, ignore_errors=True)
+    def close(self, timeout_s=60.0):
+        """Leave the rendezvous.  Rank 0 removes the directory, but only after every other rank has said it will not
+        read from it again (a rank still polling a file would otherwise wait for its timeout)."""
+        if self.rank != 0:
+            self.put(f"bye.{self.rank}", b"1")
+            return
+        t0 = time.time()
+        while time.time() - t0 < timeout_s and not all(
+                os.path.exists(os.path.join(self.dir, f"bye.{r}")) for r in range(1, self.world)):
+            time.sleep(0.002)
+        shutil.rmtree(self.dir, ignore_errors=True)
 
 
 def main():
@@ -105,6 +113,8 @@ def main():
     os.environ["OSC_SHARD"] = args.shard
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("OSC_BENCH_ONE_DEVICE"):  # rehearsal on a one-GPU box: every rank on device 0 (RCCL then refuses
+        local_rank = 0                          # the communicator and the ranks fall back to independent replicas)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -265,7 +275,6 @@ def main():
     if launched:
         sync_all()
         lat.close()
-        rdzv.gather("done", b"1")
         rdzv.close()
 
 

@@ -316,3 +316,26 @@ def test_sharded_build_with_kneighbors_above_128(amd, orc, monkeypatch):
     for rp, col, a, w, sd in _ranks(3, rank_fn):
         assert np.array_equal(np.repeat(np.arange(N), np.diff(rp)), r) and np.array_equal(col, c)
         assert np.allclose(a, wv, rtol=1e-5)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_panel_prefilter_build_on_loopback_ranks(amd, world, monkeypatch):
+    """The default build route of the benchmark sizes (panel prefilter, N >= 16384 at D <= 768) under a communicator:
+    every rank runs the sample sweep, thresholds, main sweep, select and re-scoring for ITS row blocks only, the lists are
+    all-gathered -- the lattice must equal the single-handle build's, edge for edge."""
+    monkeypatch.delenv("OSC_SHARD", raising=False)
+    monkeypatch.delenv("OSC_KNN_MODE", raising=False)
+    rng = np.random.default_rng(17)
+    N, D, k = 16500, 300, 16
+    Y = rng.standard_normal((N, D), dtype=np.float32)
+    single = amd.Oscillink(Y, kneighbors=k)
+    assert single.build_info()["prefilter"] == 2
+    want = single.graph_csr()
+
+    def rank_fn(rank, comm):
+        lat = amd.Oscillink(Y, kneighbors=k, comm=comm)
+        return lat.build_info()["prefilter"], lat.graph_csr()
+
+    for route, (rp, col, a, w, sd) in _ranks(world, rank_fn):
+        assert route == 2
+        assert np.array_equal(rp, want[0]) and np.array_equal(col, want[1]) and np.array_equal(a, want[2])

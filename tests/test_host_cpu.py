@@ -138,7 +138,11 @@ def _rdzv_worker(rank, world, port, q):
         r.put("uid", bytes(range(128)))
     uid = r.get("uid", timeout_s=120)
     got = r.gather("vals", str(rank * 1.5).encode(), timeout_s=120)
-    r.gather("done", b"1", timeout_s=120)
+    if rank == 2:
+        import time
+
+        time.sleep(0.5)  # a slow reader: rank 0 must not remove the directory under it
+        assert r.get("vals.0", timeout_s=5) == b"0.0"
     r.close()
     q.put((rank, uid == bytes(range(128)), [float(g.decode()) for g in got]))
 
