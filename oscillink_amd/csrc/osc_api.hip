@@ -721,7 +721,8 @@ void build_graph(L& h) {
   // sample, hits appended -- D <= 768 and enough row blocks for the sample) and the older 128 x 128 tile with
   // register-resident sorted lists (k_knn_pref), which serves everything else.
   static const int panel_min = [] { const char* e = getenv("OSC_KNN_PANEL_MIN"); return e ? std::max(6144, atoi(e)) : 16384; }();
-  bool panel = prefilter && knn_panel_nkt(h.D) != 0 && N >= panel_min &&
+  // (a hit entry packs the column index into 27 bits)
+  bool panel = prefilter && knn_panel_nkt(h.D) != 0 && N >= panel_min && N < (1 << 27) &&
                knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount).ok;
   if (const char* e = getenv("OSC_KNN_MODE")) {
     if (!strcmp(e, "panel")) panel = prefilter = (keep_f >= k + 8) && !any_k && knn_panel_nkt(h.D) != 0 && N >= 6144;

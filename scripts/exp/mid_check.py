@@ -2,7 +2,7 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from oscillink_amd import Oscillink
+from oscillink_amd import Oscillink  # noqa: E402
 rng = np.random.default_rng(0)
 for N, D, k in [(8000, 128, 16), (20000, 128, 16), (20000, 64, 16), (20000, 256, 16), (40000, 128, 16)]:
     Y = rng.standard_normal((N, D), dtype=np.float32)
