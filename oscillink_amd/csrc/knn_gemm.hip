@@ -494,7 +494,8 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus) {
   p.sample_groups = (p.sample_tiles + p.group_tiles - 1) / p.group_tiles;
   // rank 14 (measured at config 3: rank 16 / 14 / 12 / 10 -> build 22.5 / 22.1 / 21.7 / 26.0 ms with 2 / 2 / 21 / 346 rows
   // short of candidates: below 14 the low tail of the candidate count reaches `keep`)
-  p.sample_rank = 14;
+  // -- where the sample is denser than planned relative to keep (small lattices with a large k), rank 16 keeps the margin
+  p.sample_rank = ((double)p.nrb / p.sample_tiles * 6.5 >= (double)keep) ? 14 : 16;
   // column splits: whatever leaves the smallest idle tail on `cus` persistent workgroups (per-item overhead ~1 %)
   // ... and few enough hits per wave and item for its LDS list: 32 rows x ~5 keep / S <= ~2/3 of HB_CAP
   const int s_min = std::max(1, (int)std::ceil(32.0 * 5.0 * keep / (0.66 * HB_CAP)));
