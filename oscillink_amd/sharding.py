@@ -84,3 +84,36 @@ def run_loopback_ranks(world: int, fn, timeout_s: float = 300.0) -> list:
         if e is not None:
             raise e
     return out
+
+
+def row_block(N: int, rank: int, world: int) -> tuple[int, int]:
+    """Row range [r0, r1) owned by `rank` in the row-sharded CG (the split osc_api.hip uses: N r / G)."""
+    return (N * rank) // world, (N * (rank + 1)) // world
+
+
+def halo_lists(rowptr, col, N: int, rank: int, world: int, extra_edges=()):
+    """The halo plan of one rank of the row-sharded CG, from ITS OWN rows only (what build_halo_plan in
+    csrc/osc_api.hip computes): need[q] = sorted rows of rank q that this rank's rows reference, give[q] = sorted own
+    rows that have a neighbour in rank q's block.  Because the adjacency is symmetric, give[q] of rank r equals
+    need[r] of rank q -- no index lists ever travel.  `extra_edges`: (i, j) pairs of a chain's path graph (both
+    directions are taken)."""
+    import numpy as np
+
+    r0, r1 = row_block(N, rank, world)
+    bounds = np.array([(N * r) // world for r in range(world + 1)])
+    need = [set() for _ in range(world)]
+    give = [set() for _ in range(world)]
+
+    def touch(i, j):
+        if r0 <= i < r1 and not (r0 <= j < r1):
+            q = int(np.searchsorted(bounds, j, side="right") - 1)
+            need[q].add(int(j))
+            give[q].add(int(i))
+
+    for i in range(r0, r1):
+        for j in col[rowptr[i]: rowptr[i + 1]]:
+            touch(i, int(j))
+    for a, b in extra_edges:
+        touch(int(a), int(b))
+        touch(int(b), int(a))
+    return [sorted(s) for s in need], [sorted(s) for s in give]
