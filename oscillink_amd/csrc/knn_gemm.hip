@@ -136,10 +136,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int q = 0; q < 4; ++q) { OSC_PIECE(bsrc[q], st, st, q); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- one column tile: the K loop, then the tile's epilogue on its accumulators.  (Spreading the PREVIOUS tile's
-    // hit test over the K loop -- its VALU work in the shadow of the matrix pipe -- needs two accumulator sets next to
-    // the 192-register panel: hipcc spills 51 registers at D = 768 even with the register classes pinned, so the test
-    // runs between tiles.)
+    // ---- one column tile: the K loop, then the tile's epilogue on its accumulators.  Moving the hit test into the
+    // next tile's K loop was tried twice and dropped: with a second accumulator set hipcc spills 51 registers next to the
+    // 192-register panel; with the hit row-registers parked in LDS (20 bytes per lane) and taken apart behind the MFMA
+    // groups it runs, correctly, no faster (17.6 vs 17.0 ms) -- the K loop of a lone wave per SIMD is bound by its own
+    // instruction issue (32 MFMAs, 32 fragment reads, 8 DMA pieces of ~5 instructions per pair), not by the matrix pipe,
+    // so VALU work placed there is not hidden.
     f32x16 acc[4];
     auto row_mask = [&](auto GC, const f32x16(&pa)[4]) -> unsigned long long {
       constexpr int g = decltype(GC)::value;
