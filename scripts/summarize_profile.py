@@ -23,20 +23,26 @@ def short(name):
     return n.split("(")[0]
 
 
+def newest(pattern_dir, pattern):
+    """gpurun merges every call's output into the same local directory: only the newest run of a pass counts."""
+    files = glob.glob(os.path.join(pattern_dir, "**", pattern), recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 for sub, name in (("trace", "kernel_stats"), ("trace_knn_exact", "knn_exact_kernel_stats")):
-    stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    stats = newest(os.path.join(src, sub), "*kernel_stats.csv")
     if stats:
         with open(stats[0]) as f, open(os.path.join(dst, f"{tag}_{name}.csv"), "w") as g:
             g.write(f.read())
 
 pmc = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> values
 for d in glob.glob(os.path.join(src, "pmc_*")):
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(d, "*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
             pmc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
 
 dur = defaultdict(list)
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+for f in newest(os.path.join(src, "trace"), "*kernel_trace.csv"):
     for row in csv.DictReader(open(f)):
         dur[short(row["Kernel_Name"])].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
 
