@@ -32,6 +32,7 @@ import copy
 import ctypes as C
 import glob
 import json
+import math
 import os
 import shutil
 import sys
@@ -230,6 +231,24 @@ def main():
     bytes_settle = (20.0 + 44.0 * iters_mean) * N * D + 8.0 * nnz * (iters_mean + 1.0)
     settle_gbs = (world if replicas else 1) * bytes_settle / (ms_per_step * 1e-3) / 1e9  # all GPUs together
 
+    # The same launch against the bound that applies to a gather (profiles/r02_gather_bench.txt):
+    # a CU retires one random 128-byte row per `ceiling` clocks for the footprint an XCD gathers from (its 32-column slab,
+    # N x 128 B) -- measured with scripts/exp/gather_bench.hip on this part, no index loads; 256 CUs at 2.4 GHz.
+    request_rate = None
+    if spmm_kernel and world == 1 and mv_ms > 0:
+        rows = float(nnz) * ((d_local + 31) // 32)                       # gathered neighbour rows per launch
+        mb = N * 128.0 / 2 ** 20
+        pts = [(3.6, 2.4), (6.4, 4.0), (12.8, 7.0), (32.0, 9.3), (200.0, 10.9)]  # MB per XCD -> clk per row per CU
+        ceil_clk = pts[0][1] if mb <= pts[0][0] else pts[-1][1]
+        for (m0, c0_), (m1, c1_) in zip(pts, pts[1:]):
+            if m0 < mb <= m1:
+                ceil_clk = c0_ + (c1_ - c0_) * (math.log(mb / m0) / math.log(m1 / m0))
+        clk = mv_ms * 1e-3 * 2.4e9 * 256 / rows
+        request_rate = {"gathered_rows_per_launch": rows, "footprint_MB_per_xcd": mb, "achieved_clk_per_row_per_cu": clk,
+                        "ceiling_clk_per_row_per_cu": ceil_clk, "frac": ceil_clk / clk,
+                        "source": "profiles/r02_gather_bench.txt (gathers only; the apply also issues edge-list, own-row "
+                                  "and output requests, ~14 % of its L2 requests)"}
+
     out = {
         "metric": "settles/sec",
         # sharded: all ranks settle ONE lattice together; replicas (fallback only): every rank settles its own copy
@@ -261,6 +280,7 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_mv, "mean_launch_ms": mv_ms,
                      "launches_per_apply": slabs, "apply_ms": apply_ms, "applies_timed": int(launches.value),
                      "achieved_traffic_GBs": (traffic / (mv_ms * 1e-3) / 1e9) if (traffic and mv_ms > 0) else None,
+                     "request_rate": request_rate,
                      "settle": {"algorithmic_bytes": bytes_settle, "achieved": settle_gbs,
                                 "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                                 "frac": settle_gbs / (HBM_PEAK_GBS * world)}},
