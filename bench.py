@@ -218,7 +218,8 @@ def main():
     # row; per launch = per apply / launches.
     plan = lat.build_info()
     slabs = max(1, plan["apply_launches"])
-    spmm_kernel = "k_spmm<8, 1, 0>" if plan["apply_xs_workgroups"] else None
+    spmm_kernel = ("k_apply_blocked<17>" if plan.get("apply_src_blocks") else
+                   "k_spmm<8, 1, 0>" if plan["apply_xs_workgroups"] else None)
     bytes_apply = 8.0 * n_local * d_local + (8.0 * nnz + 12.0 * N) * (n_local / N)
     apply_ms = total_ms.value / max(1, launches.value)
     bytes_mv = bytes_apply / slabs
@@ -272,7 +273,9 @@ def main():
         "lattice_create_ms": lattice_create_ms,  # first call in the process: HIP context + code objects + upload + build
         "graph_build_device_ms": dev_build_ms,
         "roofline": {"bound": "hbm",
-                     "kernel": ("k_spmm<8,1,AP> (operator apply / CG matvec; one launch, XCD-affine 32-column slabs)"
+                     "kernel": (f"k_apply_blocked<17> (operator apply / CG matvec; one launch, XCD-affine 32-column slabs, "
+                                f"source rows walked in {plan['apply_src_blocks']} blocks)" if plan.get("apply_src_blocks") else
+                                "k_spmm<8,1,AP> (operator apply / CG matvec; one launch, XCD-affine 32-column slabs)"
                                 if spmm_kernel else "k_spmm (operator apply / CG matvec; one column-slab launch)"),
                      "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

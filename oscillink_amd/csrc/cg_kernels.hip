@@ -293,6 +293,272 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Operator apply, source-blocked (CG matvec on unstructured lattices whose 32-column slab, N x 128 B, is several times
+// an XCD's 4 MB L2).  Measured (scripts/exp/gather_bench.hip, profiles/r02_gather_bench.txt): a CU completes a random
+// 128-byte row gather every 2.4 clk when the rows come from <= 3.6 MB per XCD, every 7.0 clk from a 12.8 MB slab -- the
+// request rate, not the bytes, is what the plain apply pays for.  Here the neighbour rows are visited block by block:
+//   * source rows are cut into nb blocks of ~1.65 MB of slab rows;
+//   * every gathering wave owns a fixed set of row groups (8 rows each, dealt round-robin) per slice of the destination
+//     rows and runs  for block b: for my groups: gather the edges that point into b,  the per-row sums staying in
+//     registers across the blocks (no partial results through memory); the destination rows are cut into slices so that
+//     the rows in flight on an XCD fit its waves' registers.  All waves of an XCD walk the same (slab, slice, block)
+//     sequence from the same start, so what they gather from at any time is a few neighbouring blocks rather than the
+//     whole slab (L2 hits 25 -> 54 M, misses 58 -> 31 M per launch at config 3);
+//   * loads of one wave complete in issue order, so a miss in a gathering wave's stream holds up every L2 hit behind it.
+//     Hence two roles per workgroup: waves 0-2 gather (LDS reads and slab rows only), wave 3 reads the next block's edge
+//     lists (block-major copy of the graph, BlockedView: always misses) into registers while the others gather and
+//     writes them to the other half of an LDS staging area; one workgroup barrier per block.
+// What was tried on top and did not pay (scripts/exp/blocked_apply/README.md): pulling the next block into the L2 with
+// dword-per-line loads, gated or not by a progress counter in the XCD's L2 (no change: 877-890 us either way), and
+// holding leaders back at that counter (stragglers fall out of the resident set and get later still: 1.8-2.3 ms).
+// Same terms per row as k_spmm, added in ascending column order except for the (rare) edges beyond OSC_BLK_SLOTS per
+// (row, block), which are added last.  No chain prior here (lattices with one use k_spmm).
+constexpr int kBlkGroups = 17;   // row groups per gathering wave (4 registers each for the sums)
+constexpr int kBlkPair = 1;      // groups whose gathers are in flight together (2 with 12 groups: 0.96-0.99 ms vs 0.88)
+constexpr int kBlkGatherWaves = 3;
+
+__device__ __forceinline__ float4 ld4_at(const float* base, uint32_t byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float ld1_at(const float* base, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ int2 ld2_at(const int2* base, uint32_t byte_off) {
+  return *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ int opaque(int v) {  // a wave-uniform value the optimiser must not fold into hoisted products
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+struct BlkPhase {  // sub-phase ph = (slab, slice, block): every wave of the XCD walks the same sequence
+  int sc0, slice, b;
+};
+
+template <int GM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_apply_blocked(const BlkArgs a) {
+  constexpr int CW = kBlkGatherWaves, SL = OSC_BLK_SLOTS;
+  __shared__ __attribute__((aligned(16))) float red[4 * 32];
+  // per gathering wave: the slots of each of its rows in the current block, and (other half) in the next one
+  __shared__ int2 stage[2][CW][GM][8 * SL];
+  if (a.gate != nullptr && *a.gate <= a.gate_tol) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane >> 3, lr = lane & 7;
+  const int32_t ld = a.ld;
+  for (int c = a.c0 + threadIdx.x; c < a.c1; c += 256) a.part[(size_t)blockIdx.x * ld + c] = 0.f;
+  if ((int)(blockIdx.x >> 3) >= a.xs) return;
+  const int xcd = (int)(blockIdx.x & 7), wgx = (int)(blockIdx.x >> 3);
+  const int xgroups = a.xs_groups, xgrp = xcd % xgroups, xpart = xcd / xgroups, parts = 8 / xgroups;
+  const int rlo = (int)((int64_t)a.N * xpart / parts), rhi = (int)((int64_t)a.N * (xpart + 1) / parts);
+  const int nb = a.nb, ng = a.groups;
+  const int W8 = a.xs * CW * 8;  // rows one "deal" of groups covers (8 per gathering wave of the XCD)
+  const int slice_rows = W8 * ng;
+  const int nslab = a.c1 - a.c0 > xgrp * 32 ? ((a.c1 - a.c0 - xgrp * 32 + xgroups * 32 - 1) / (xgroups * 32)) : 0;
+  const int per_slab = a.slices * nb, nphase = nslab * per_slab;
+  auto phase = [&](int ph) {
+    BlkPhase p;
+    const int q = ph / per_slab, r = ph - q * per_slab;
+    p.sc0 = a.c0 + (xgrp + q * xgroups) * 32;
+    p.slice = r / nb;
+    p.b = r - p.slice * nb;
+    return p;
+  };
+  auto slab_base = [&](int sc0) { return a.X + (size_t)(sc0 >> 5) * (size_t)a.N * 32; };
+
+  if (wave == CW) {
+    // ---- wave 3: the edge lists ---------------------------------------------------------------------------------------
+    const uint32_t lslot = (uint32_t)min(lr, SL - 1) * 8u;
+    // slots of gathering wave cw's rows in sub-phase p: lane (sub, lr) gets slot lr of row `sub` of each group
+    auto load_slots = [&](const BlkPhase& p, int cw, int2 (&en)[GM]) {
+      const int2* sb = a.slots + (size_t)p.b * (size_t)a.N * SL;
+      const int w8 = opaque(W8);
+      int r = rlo + p.slice * slice_rows + ((wgx * CW + cw) << 3) + sub;
+#pragma unroll
+      for (int g = 0; g < GM; ++g) {
+        en[g] = ld2_at(sb, (uint32_t)min(r, rhi - 1) * (8u * SL) + lslot);
+        r += w8;
+      }
+    };
+    auto stage_slots = [&](int half, const BlkPhase& p, int cw, int2 (&en)[GM]) {
+      const int w8 = opaque(W8);
+      int r = rlo + p.slice * slice_rows + ((wgx * CW + cw) << 3) + sub;
+#pragma unroll
+      for (int g = 0; g < GM; ++g) {
+        if (g >= ng || r >= rhi) en[g].x = -1;  // groups / rows the wave does not have in this slice: no edges
+        if (lr < SL) stage[half][cw][g][sub * SL + lr] = en[g];
+        r += w8;
+      }
+    };
+    static_assert(kBlkGatherWaves == 3, "the hand-over below is written for three gathering waves");
+    auto fetch_slots = [&](int ph) {  // all three waves' slots of sub-phase ph: global -> registers -> stage[ph & 1]
+      const BlkPhase p = phase(ph);
+      int2 ea[GM], eb[GM];
+      load_slots(p, 0, ea);
+      load_slots(p, 1, eb);
+      stage_slots(ph & 1, p, 0, ea);
+      load_slots(p, 2, ea);
+      stage_slots(ph & 1, p, 1, eb);
+      stage_slots(ph & 1, p, 2, ea);
+    };
+    float4 zero[1] = {f4(0.f)};
+    if (nphase > 0) fetch_slots(0);
+    __syncthreads();
+    for (int ph = 0; ph < nphase; ++ph) {
+      if (ph + 1 < nphase) fetch_slots(ph + 1);
+      __syncthreads();
+      if ((ph + 1) % per_slab == 0) {
+        const int sc0 = phase(ph).sc0;
+        block_fold<8, 1>(zero, red, a.part, ld, sc0, min(a.c1, sc0 + 32));
+      }
+    }
+    return;
+  }
+
+  // ---- waves 0-2: gather (L2 hits and LDS reads) ------------------------------------------------------------------------
+  const uint32_t lr16 = (uint32_t)lr * 16u;
+  float4 acc[GM];
+  float4 dot[1] = {f4(0.f)};
+  __syncthreads();
+  for (int ph = 0; ph < nphase; ++ph) {
+    const BlkPhase p = phase(ph);
+    const bool cok = p.sc0 + lr * 4 < a.c1;
+    const float* xbase = slab_base(p.sc0);
+    if (p.b == 0) {
+#pragma unroll
+      for (int g = 0; g < GM; ++g) acc[g] = f4(0.f);
+    }
+    const int2(*st)[8 * SL] = stage[ph & 1][wave];
+#pragma unroll
+    for (int g0 = 0; g0 < GM; g0 += kBlkPair) {  // kBlkPair groups at a time: all slots of their rows in flight together
+      if (g0 >= ng) continue;
+      float4 v[kBlkPair][SL];
+      float wv[kBlkPair][SL];
+#pragma unroll
+      for (int i = 0; i < kBlkPair; ++i) {
+#pragma unroll
+        for (int u = 0; u < SL; ++u) {
+          v[i][u] = f4(0.f);
+          wv[i][u] = 0.f;
+          if (g0 + i < GM) {
+            const int2 e = st[g0 + i][sub * SL + u];
+            if (e.x >= 0) {
+              wv[i][u] = __int_as_float(e.y);
+              if (cok) v[i][u] = ld4_at(xbase, (uint32_t)e.x * 128u + lr16);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kBlkPair; ++i)
+#pragma unroll
+        for (int u = 0; u < SL; ++u)
+          if (g0 + i < GM) acc[g0 + i] = fma4(wv[i][u], v[i][u], acc[g0 + i]);
+    }
+    if (p.b == nb - 1) {  // the rows of this slice are complete: the rest of long lists, diagonal term, output, p.Ap
+      const int w8 = opaque(W8);
+      const int row_first = rlo + p.slice * slice_rows + ((wgx * CW + wave) << 3) + sub;
+      constexpr int EC = 4;  // groups whose own rows / gates / rest descriptors are fetched together (these loads miss)
+#pragma unroll
+      for (int g0 = 0; g0 < GM; g0 += EC) {
+        float4 xs[EC];
+        int2 rr[EC];
+        float bv[EC];
+#pragma unroll
+        for (int i = 0; i < EC; ++i) {
+          const int g = g0 + i, row = row_first + g * w8;
+          xs[i] = f4(0.f);
+          rr[i] = make_int2(0, 0);
+          bv[i] = 0.f;
+          if (g < GM && g < ng && row < rhi && cok) {
+            xs[i] = ld4_at(xbase, (uint32_t)row * 128u + lr16);
+            rr[i] = ld2_at(a.rest, (uint32_t)row * 8u);  // edges beyond SL per block: {first, count}, ascending columns
+            bv[i] = ld1_at(a.B, (uint32_t)row * 4u);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < EC; ++i) {
+          const int g = g0 + i, row = row_first + g * w8;
+          if (g >= GM) continue;
+          if (g >= ng || row >= rhi || !cok) continue;
+          for (int e = 0; e < rr[i].y; ++e) {
+            const int2 en = ld2_at(a.over, (uint32_t)(rr[i].x + e) * 8u);
+            acc[g] = fma4(__int_as_float(en.y), ld4_at(xbase, (uint32_t)en.x * 128u + lr16), acc[g]);
+          }
+          const float cs = fmaf(a.cs_B, bv[i], a.cs_const);
+          float4 o;
+          o.x = cs * xs[i].x - a.cW * acc[g].x;
+          o.y = cs * xs[i].y - a.cW * acc[g].y;
+          o.z = cs * xs[i].z - a.cW * acc[g].z;
+          o.w = cs * xs[i].w - a.cW * acc[g].w;
+          st4_stream(a.OUT + ((size_t)(uint32_t)row * (uint32_t)ld + (uint32_t)(p.sc0 + lr * 4)), o);
+          dot[0] = mulacc4(xs[i], o, dot[0]);
+        }
+      }
+    }
+    __syncthreads();
+    if ((ph + 1) % per_slab == 0) {  // the slab's column sums
+      block_fold<8, 1>(dot, red, a.part, ld, p.sc0, min(a.c1, p.sc0 + 32));
+      dot[0] = f4(0.f);
+    }
+  }
+}
+
+// ---- build of the block-major graph copy ----------------------------------------------------
+__device__ __forceinline__ int blk_of(int col, int rpb, int nb) { return min(nb - 1, col / rpb); }
+
+// edges beyond the 8 slots of their (row, block), in total
+__global__ void k_blk_count(const int32_t* col, const int32_t* deg, int32_t width, int32_t N, int32_t nb, int32_t rpb,
+                            unsigned* over_count) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  int c[OSC_MAX_SRC_BLOCKS];
+#pragma unroll
+  for (int k = 0; k < OSC_MAX_SRC_BLOCKS; ++k) c[k] = 0;
+  const int d = deg[row];
+  for (int e = 0; e < d; ++e) {
+    const int b = blk_of(col[(size_t)row * width + e], rpb, nb);
+#pragma unroll
+    for (int k = 0; k < OSC_MAX_SRC_BLOCKS; ++k) c[k] += (k == b);
+  }
+  unsigned over = 0;
+#pragma unroll
+  for (int k = 0; k < OSC_MAX_SRC_BLOCKS; ++k) over += (unsigned)max(0, c[k] - OSC_BLK_SLOTS);
+  if (over) atomicAdd(over_count, over);
+}
+
+// *over_count must be zero on entry (it hands out the ranges of `over`); slots must be pre-filled with {-1, x}
+__global__ void k_blk_fill(const int32_t* col, const float* w, const int32_t* deg, int32_t width, int32_t N, int32_t nb,
+                           int32_t rpb, int2* slots, int2* rest, int2* over, unsigned* over_count) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  int c[OSC_MAX_SRC_BLOCKS], k[OSC_MAX_SRC_BLOCKS];
+#pragma unroll
+  for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q) c[q] = 0, k[q] = 0;
+  const int d = deg[row];
+  for (int e = 0; e < d; ++e) {
+    const int b = blk_of(col[(size_t)row * width + e], rpb, nb);
+#pragma unroll
+    for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q) c[q] += (q == b);
+  }
+  int total = 0;
+#pragma unroll
+  for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q) total += max(0, c[q] - OSC_BLK_SLOTS);
+  unsigned at = total ? atomicAdd(over_count, (unsigned)total) : 0u;
+  rest[row] = make_int2((int)at, total);
+  for (int e = 0; e < d; ++e) {
+    const int j = col[(size_t)row * width + e];
+    const int b = blk_of(j, rpb, nb);
+    int kb = 0;
+#pragma unroll
+    for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q)
+      if (q == b) kb = k[q]++;
+    const int2 ent = make_int2(j, __float_as_int(w[(size_t)row * width + e]));
+    if (kb < OSC_BLK_SLOTS) slots[((size_t)b * N + row) * OSC_BLK_SLOTS + kb] = ent;
+    else over[at++] = ent;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int LPR, int NCH>
 __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
   constexpr int RPW = 64 / LPR;
@@ -555,6 +821,42 @@ int spmm_grid(int64_t N, int32_t ncols) {
   const int rpw = 64 / sh.lpr;
   const int64_t need = (N + 4 * rpw - 1) / (4 * rpw);
   return (int)std::max<int64_t>(1, std::min<int64_t>(need, 1024));
+}
+
+static void blocked_check(int32_t N, int32_t width, int32_t nb) {
+  if (nb < 1 || nb > OSC_MAX_SRC_BLOCKS) throw std::runtime_error("blocked graph copy: too many source blocks");
+  if ((int64_t)N * width >= ((int64_t)1 << 28) || (int64_t)N >= ((int64_t)1 << 24))  // 32-bit byte offsets in the apply
+    throw std::runtime_error("blocked graph copy: lattice too large");
+}
+void launch_blocked_count(const int32_t* col, const int32_t* deg, int32_t width, int32_t N, int32_t nb,
+                          unsigned* over_count, hipStream_t s) {
+  blocked_check(N, width, nb);
+  hipLaunchKernelGGL(k_blk_count, dim3((N + 255) / 256), dim3(256), 0, s, col, deg, width, N, nb, (N + nb - 1) / nb,
+                     over_count);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_blocked_fill(const int32_t* col, const float* w, const int32_t* deg, int32_t width, int32_t N, int32_t nb,
+                         int2* slots, int2* rest, int2* over, unsigned* over_count, hipStream_t s) {
+  blocked_check(N, width, nb);
+  hipLaunchKernelGGL(k_blk_fill, dim3((N + 255) / 256), dim3(256), 0, s, col, w, deg, width, N, nb, (N + nb - 1) / nb,
+                     slots, rest, over, over_count);
+  HIP_CHECK(hipGetLastError());
+}
+int blocked_groups_max() { return kBlkGroups; }
+int blocked_gather_waves() { return kBlkGatherWaves; }
+int blocked_resident_per_cu() {
+  int n = 0;
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_apply_blocked<kBlkGroups>, 256, 0));
+  return n;
+}
+
+void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s) {
+  if (grid < 8 || (grid & 7) != 0 || a.xs < 1 || a.xs > grid / 8 || a.xs_groups < 1 || 8 % a.xs_groups != 0 || a.groups < 1 ||
+      a.groups > kBlkGroups || a.slices < 1 || a.nb < 1 || a.nb > OSC_MAX_SRC_BLOCKS || !a.slots || !a.rest ||
+      (int64_t)a.N * a.ld * 4 >= ((int64_t)1 << 32) || (a.c0 & 31) != 0)
+    throw std::runtime_error("blocked apply: unsupported arguments");
+  hipLaunchKernelGGL((k_apply_blocked<kBlkGroups>), dim3(grid), dim3(256), 0, s, a);
+  HIP_CHECK(hipGetLastError());
 }
 
 void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s) {

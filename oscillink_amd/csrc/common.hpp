@@ -89,6 +89,37 @@ struct GraphView {
   int32_t pwidth;
 };
 
+// The lattice graph a second time, split by SOURCE-row block (k_spmm_blocked): block b holds the edges whose neighbour row
+// lies in [b * rows_per_block, (b + 1) * rows_per_block), rows_per_block = ceil(N / nb).  Fixed-width: every (block, row)
+// owns OSC_BLK_SLOTS slots {neighbour row, bits of W_ij}, filled in the order of the ELL row, unused slots {-1, x}; what a row has
+// beyond that many edges into one block goes, in ascending column order, to over[rest[row].x .. + rest[row].y) and is added
+// after the blocks (so such a row's sum is formed in a different order than k_spmm's: same terms, last-bit differences).
+constexpr int OSC_MAX_SRC_BLOCKS = 16;
+constexpr int OSC_BLK_SLOTS = 6;
+struct BlockedView {
+  const int2* slots;    // [nb][N][OSC_BLK_SLOTS]
+  const int2* rest;     // [N] {first, count} into over
+  const int2* over;
+  int32_t nb;           // source blocks; 0 = no blocked copy
+};
+
+// arguments of the source-blocked CG matvec (k_apply_blocked): out = (cs_const + cs_B B_i) x_i - cW sum_j W_ij x_j
+struct BlkArgs {
+  const float* X;   // operand, slab-major [ld / 32][N][32]
+  float* OUT;       // result, row-major with pitch ld
+  const float* B;   // [N]
+  float* part;      // [grid][ld] column partial sums of x . out
+  const int2* slots;
+  const int2* rest;
+  const int2* over;
+  const float* gate;  // see SpmmArgs
+  float gate_tol;
+  float cs_const, cs_B, cW;
+  int32_t N, ld, c0, c1;
+  int32_t xs, xs_groups;  // workgroups per XCD that take part, slab groups (as in SpmmArgs)
+  int32_t nb, groups, slices;  // source blocks; row groups (of 8 rows) per gathering wave and slice; dest-row slices
+};
+
 enum SpmmMode { SPMM_AP = 0, SPMM_INIT = 1, SPMM_DOT = 2 };
 
 struct SpmmArgs {
@@ -151,6 +182,16 @@ struct Gate {
 
 // launchers implemented in cg_kernels.hip
 int spmm_grid(int64_t N, int32_t ncols);
+// source-blocked copy of an ELL graph (BlockedView): count the overflow entries (-> *over_count, device), then fill
+void launch_blocked_count(const int32_t* col, const int32_t* deg, int32_t width, int32_t N, int32_t nb,
+                          unsigned* over_count, hipStream_t s);
+void launch_blocked_fill(const int32_t* col, const float* w, const int32_t* deg, int32_t width, int32_t N, int32_t nb,
+                         int2* slots, int2* rest, int2* over, unsigned* over_count, hipStream_t s);
+// row groups per wave the blocked apply holds in registers, and the workgroups per CU it needs resident
+int blocked_groups_max();
+int blocked_gather_waves();
+void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s);
+int blocked_resident_per_cu();
 void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s);
 void launch_update_xr(const UpdateArgs& a, int grid, hipStream_t s);
 void launch_update_p(const UpdateArgs& a, int grid, hipStream_t s);

@@ -222,6 +222,14 @@ struct osc_lattice {
   DevBuf<int32_t> ell_col_t;          // transposed ELL for the one-launch path (built on first use per graph)
   DevBuf<float> ell_w_t;
   bool ell_t_ready = false;
+  // block-major copy of the graph for the source-blocked CG matvec (k_spmm_blocked), built on first use per graph
+  DevBuf<int2> blk_slots, blk_rest, blk_over;
+  int blk_nb = 0;          // blocks of the copy held (0 = none / stale)
+  int spmm_blocked = -1;   // -1 by lattice size, 0 off, > 0 = that many source blocks (OSC_SPMM_BLOCKED)
+  double blk_mb = 1.65;    // size of a source block (rows x 128 B) of the blocked apply: two are L2-resident (OSC_BLK_MB)
+  int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
+  int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
+  int64_t blk_applies = 0; // blocked matvecs enqueued since creation
   int64_t small_solves = 0;
   float* res_host = nullptr;  // pinned, host-mapped mirror of res_bits for the per-iteration read-back
   float* res_host_dev = nullptr;  // the device's address of it
@@ -478,6 +486,7 @@ void graph_counts(L& h) {
 
 void alloc_ell(L& h, int32_t width) {
   h.ell_t_ready = false;
+  h.blk_nb = 0;
   ++h.graph_epoch;
   h.width = std::max<int32_t>(1, width);
   const size_t n = (size_t)h.N * h.width;
@@ -576,6 +585,7 @@ void move_state(L& l, const int32_t* from_d, const int32_t* relabel_d) {
   l.ell_w.swap(w2);
   l.deg.swap(deg2);
   l.ell_t_ready = false;
+  l.blk_nb = 0;
   l.have_ustar = false;
   l.u_sharded = false;
   ++l.graph_epoch;
@@ -957,6 +967,51 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   return nb;
 }
 
+// Source blocks of the blocked CG matvec: 0 = use the plain apply.  Pays once the 32-column slab an XCD gathers from
+// (N x 128 B) no longer fits its L2.  The slab is cut into resident sets of ~blk_mb MB and each set into blocks small
+// enough that a row rarely has more than 8 edges into one block (the width of the block-major copy's slot rows).
+int blocked_plan(const L& h, bool with_path) {
+  if (h.spmm_blocked == 0 || with_path || (int64_t)h.N * h.width >= ((int64_t)1 << 28) || h.N >= ((int64_t)1 << 24) ||
+      (int64_t)h.N * h.ld * 4 >= ((int64_t)1 << 32))
+    return 0;
+  if (h.spmm_blocked > 0) return std::min(h.spmm_blocked, OSC_MAX_SRC_BLOCKS);
+  const double slab = (double)h.N * 128.0, blk = h.blk_mb * 1024.0 * 1024.0;
+  if (slab <= 2.2 * blk) return 0;  // the whole slab (nearly) fits the L2 anyway
+  return (int)std::min<double>(OSC_MAX_SRC_BLOCKS, std::ceil(slab / blk));
+}
+
+BlockedView blocked_view(L& h, int nb) {
+  if (h.blk_nb != nb) {
+    DevBuf<unsigned> cnt;
+    cnt.alloc(1);
+    HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4, h.stream));
+    launch_blocked_count(h.ell_col.p, h.deg.p, h.width, (int32_t)h.N, nb, cnt.p, h.stream);
+    unsigned over = 0;
+    HIP_CHECK(hipMemcpyAsync(&over, cnt.p, 4, hipMemcpyDeviceToHost, h.stream));
+    sync(h);
+    h.blk_slots.alloc((size_t)nb * h.N * OSC_BLK_SLOTS);
+    h.blk_over.alloc((size_t)over + 1);
+    h.blk_rest.alloc((size_t)h.N);
+    HIP_CHECK(hipMemsetAsync(h.blk_slots.p, 0xFF, h.blk_slots.n * sizeof(int2), h.stream));  // {-1, NaN bits}: unused
+    HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4, h.stream));
+    launch_blocked_fill(h.ell_col.p, h.ell_w.p, h.deg.p, h.width, (int32_t)h.N, nb, h.blk_slots.p, h.blk_rest.p, h.blk_over.p, cnt.p,
+                        h.stream);
+    sync(h);  // cnt goes out of scope
+    h.blk_nb = nb;
+  }
+  if (h.blk_resident < 0) {
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, h.device));
+    h.blk_resident = blocked_resident_per_cu() * std::max(1, prop.multiProcessorCount / 8);  // per XCD
+  }
+  BlockedView v{};
+  v.slots = h.blk_slots.p;
+  v.rest = h.blk_rest.p;
+  v.over = h.blk_over.p;
+  v.nb = nb;
+  return v;
+}
+
 void spmm_slabbed(L& h, int mode, SpmmArgs sa, int grid, int iter = 0) {
   const int32_t c0 = sa.c0, c1 = sa.c1;
   ProfScope ps(h, mode == SPMM_INIT ? 4 : 0, iter);  // slot 0: AP applies (the CG matvec); slot 4: the INIT apply
@@ -1146,7 +1201,40 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   sa.OUT = b.AP;
   sa.xblk = pblk ? h.N : 0;
   sa.pblk = 0;
+  // source-blocked CG matvec (k_apply_blocked) where the slab an XCD gathers from is far larger than its L2
+  BlkArgs ba{};
+  if (pblk && b.c0 == h.c0 && b.c1 == h.c1) {
+    if (const int nb = blocked_plan(h, with_path)) {
+      const BlockedView bv = blocked_view(h, nb);
+      ba.X = b.P;
+      ba.OUT = b.AP;
+      ba.B = b.B;
+      ba.part = h.part0.p;
+      ba.slots = bv.slots;
+      ba.rest = bv.rest;
+      ba.over = bv.over;
+      ba.cs_const = op.cs_const;
+      ba.cs_B = op.cs_B;
+      ba.cW = op.cW;
+      ba.N = (int32_t)h.N;
+      ba.ld = b.ld;
+      ba.c0 = b.c0;
+      ba.c1 = b.c1;
+      ba.nb = nb;
+      // workgroups per XCD: what is resident at once
+      ba.xs = std::min(std::min(grid / 8, 128), std::max(1, h.blk_resident));
+      const int xg = xs_groups_for(h, b.c1 - b.c0);
+      ba.xs_groups = xg > 0 ? xg : xs_groups(b.c1 - b.c0, h.xs_groups_cap);
+      // slices of the destination rows: as few as the row groups a wave can hold allow, evenly filled
+      const int64_t gmax = blocked_groups_max();
+      const int64_t rows = (h.N + 8 / ba.xs_groups - 1) / (8 / ba.xs_groups), per_group = (int64_t)ba.xs * blocked_gather_waves() * 8;
+      const int64_t nsl = (rows + per_group * gmax - 1) / (per_group * gmax);
+      ba.slices = (int32_t)nsl;
+      ba.groups = (int32_t)std::max<int64_t>(1, (rows + nsl * per_group - 1) / (nsl * per_group));
+    }
+  }
 
+  h.blk_last = ba.nb;
   auto enqueue_iter = [&](int it) {  // everything of iteration `it` up to its residual, gated on iteration it-1
     const Gate g{it > 1 ? res_dev + (it - 1) : nullptr, tol};
     sa.gate = g.p;
@@ -1157,7 +1245,15 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       ProfScope ps(h, 2, it);
       for_windows(ua, [&](const UpdateArgs& w) { launch_update_p(w, grid, h.stream); });  // p = z + beta p (solver.py:32-36)
     }
-    spmm_slabbed(h, SPMM_AP, sa, grid, it);  // Ap and column sums of p.Ap
+    if (ba.nb > 0) {  // Ap and column sums of p.Ap
+      ProfScope ps(h, 0, it);
+      ba.gate = g.p;
+      ba.gate_tol = tol;
+      launch_apply_blocked(ba, grid, h.stream);
+      h.blk_applies += 1;
+    } else {
+      spmm_slabbed(h, SPMM_AP, sa, grid, it);
+    }
     launch_reduce_alpha(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
     {
       ProfScope ps(h, 1, it);
@@ -1686,6 +1782,8 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
       h->xs_groups_cap = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;
     }
     if (const char* e = getenv("OSC_P_BLOCKED")) h->p_blocked = atoi(e) != 0;
+    if (const char* e = getenv("OSC_SPMM_BLOCKED")) h->spmm_blocked = atoi(e);
+    if (const char* e = getenv("OSC_BLK_MB")) h->blk_mb = std::max(0.25, atof(e));
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
     if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
@@ -1758,6 +1856,13 @@ int osc_build_info(osc_handle h, int32_t* prefilter, int32_t* fallback_rows, int
     if (prefilter) *prefilter = l.knn_prefilter ? (l.knn_panel ? 2 : 1) : 0;
     if (fallback_rows) *fallback_rows = l.knn_fallback_rows;
     if (small_solves) *small_solves = l.small_solves;
+  });
+}
+
+int osc_apply_info(osc_handle h, int32_t* src_blocks, int64_t* blocked_applies) {
+  return guarded(h, [&](L& l) {
+    if (src_blocks) *src_blocks = l.blk_last;
+    if (blocked_applies) *blocked_applies = l.blk_applies;
   });
 }
 

@@ -223,9 +223,12 @@ class OscillinkLattice:
         self._call("osc_order_info", C.byref(ro), C.byref(cc))
         ln, sc, xw = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._call("osc_spmm_plan", C.byref(ln), C.byref(sc), C.byref(xw))
+        sb, ba = C.c_int32(0), C.c_int64(0)
+        self._call("osc_apply_info", C.byref(sb), C.byref(ba))
         return {"prefilter": int(pf.value), "fallback_rows": int(fb.value), "small_solves": int(ss.value),
                 "reordered": int(ro.value), "clustering": float(cc.value), "apply_launches": int(ln.value),
-                "apply_slab_cols": int(sc.value), "apply_xs_workgroups": int(xw.value)}
+                "apply_slab_cols": int(sc.value), "apply_xs_workgroups": int(xw.value),
+                "apply_src_blocks": int(sb.value), "blocked_applies": int(ba.value)}
 
     def halo_info(self) -> dict[str, int]:
         """Row-sharded runs (OSC_SHARD=row under a communicator): the rows of the search direction this rank receives

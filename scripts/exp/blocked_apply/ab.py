@@ -3,7 +3,7 @@ device time, agreement of the iterates.  Usage: blocked_apply.py N D k [settings
 import os, sys, time
 import ctypes as C
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from oscillink_amd import Oscillink  # noqa: E402
 
 N, D, k = [int(t) for t in sys.argv[1:4]]

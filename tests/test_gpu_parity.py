@@ -1004,3 +1004,75 @@ def test_padded_row_pitch_is_invisible(amd, name, ld, small, monkeypatch):
     if rc["chain"]:
         lat.chain_receipt(list(rc["chain"]))
     assert len(lat.bundle(k=5)) == 5
+
+
+@pytest.mark.parametrize("nb", ["2", "5", "16"])
+def test_source_blocked_apply_matches_reference(amd, nb, monkeypatch):
+    """OSC_SPMM_BLOCKED=n forces the source-blocked CG matvec (chosen automatically only when the 32-column slab is several
+    times an XCD's L2) onto a fixture, on top of the forced XCD-affine slabs it builds on; OSC_SMALL_PATH=0 keeps the
+    general multi-launch CG in play.  Same fixture, same tolerances, same iteration counts as every other path."""
+    monkeypatch.setenv("OSC_SPMM_XS", "1")
+    monkeypatch.setenv("OSC_SPMM_BLOCKED", nb)
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    case = load_case("c2_n1200_d128_k16")
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
+    lat.set_graph_csr(*_csr_from_case(case))
+    _configure(lat, case, rc, psi)
+    _check_solves(lat, case, rc, tol_u=2e-5)
+    info = lat.build_info()
+    assert info["apply_src_blocks"] == int(nb) and info["blocked_applies"] > 0 and info["small_solves"] == 0
+
+
+def test_source_blocked_apply_against_the_plain_one(amd, orc, monkeypatch):
+    """A lattice inside the automatic window (N = 40000, D = 256: slab 5 MB) with random gates: the blocked matvec and the
+    plain one give the same iteration count and the same state to fp32 summation-order noise; rows with more than
+    OSC_BLK_SLOTS edges into one block (forced by only 2 blocks at k = 24) take the epilogue path; a chain prior switches
+    the blocked matvec off; a rebuilt graph rebuilds the block-major copy."""
+    monkeypatch.delenv("OSC_SPMM_XS", raising=False)
+    monkeypatch.delenv("OSC_REORDER", raising=False)
+    rng = np.random.default_rng(77)
+    N, D, k = 40000, 256, 24
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    gates = rng.uniform(0.1, 1.0, N).astype(np.float32)
+    out = {}
+    for mode in ("0", "2", "3", "7"):
+        monkeypatch.setenv("OSC_SPMM_BLOCKED", mode)
+        lat = amd.Oscillink(Y, kneighbors=k)
+        lat.set_query(psi, gates=gates)
+        st = lat.settle(max_iters=12, tol=1e-4)
+        info = lat.build_info()
+        assert info["apply_src_blocks"] == int(mode), info
+        out[mode] = (st["iters"], st["res"], lat.U.copy())
+        if mode == "3":
+            lat.add_chain([3, 1, 4, 15, 9, 2, 6], lamP=0.25)  # chain prior: the plain apply takes over
+            st2 = lat.settle(max_iters=12, tol=1e-4)
+            assert lat.build_info()["apply_src_blocks"] == 0 and st2["iters"] >= 1
+            lat.clear_chain()
+            lat.rebuild_graph(kneighbors=8)  # new graph: the block-major copy must follow
+            lat.reset_U()
+            st3 = lat.settle(max_iters=12, tol=1e-4)
+            assert lat.build_info()["apply_src_blocks"] == 3
+            monkeypatch.setenv("OSC_SPMM_BLOCKED", "0")
+            ref = amd.Oscillink(Y, kneighbors=8)
+            ref.set_query(psi, gates=gates)
+            st4 = ref.settle(max_iters=12, tol=1e-4)
+            assert st3["iters"] == st4["iters"] and relerr(lat.U, ref.U) < 1e-6
+        lat.close()
+    for mode in ("2", "3", "7"):
+        assert out[mode][0] == out["0"][0]
+        assert out[mode][1] == pytest.approx(out["0"][1], rel=1e-3)
+        assert relerr(out[mode][2], out["0"][2]) < 1e-6, mode
+    # and against the oracle on the device-built graph
+    monkeypatch.setenv("OSC_SPMM_BLOCKED", "0")
+    lat = amd.Oscillink(Y, kneighbors=k)
+    import scipy.sparse as sp
+    from tests._fullsize import oracle_solves, stop_iteration
+
+    rp, col, a, w, sd = lat.graph_csr()
+    A = sp.csr_matrix((a, col, rp), shape=(N, N), dtype=np.float32)
+    ref = oracle_solves(orc, Y, psi, A, k=k, gates=gates, settle_iters=out["3"][0], settle_tol=1e-4, ustar_iters=8)
+    assert stop_iteration(ref["hist_settle"], 1e-4) == out["3"][0]
+    assert relerr(out["3"][2], ref["U"]) < 1e-5
