@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 // an XCD's 4 MB L2).  Measured (scripts/exp/gather_bench.hip, profiles/r02_gather_bench.txt): a CU completes a random
 // 128-byte row gather every 2.4 clk when the rows come from <= 3.6 MB per XCD, every 7.0 clk from a 12.8 MB slab -- the
 // request rate, not the bytes, is what the plain apply pays for.  Here the neighbour rows are visited block by block:
-//   * source rows are cut into nb blocks of ~1.65 MB of slab rows;
+//   * source rows are cut into nb blocks, nb such that a row has ~4 edges into each (blocked_plan in osc_api.hip);
 //   * every gathering wave owns a fixed set of row groups (8 rows each, dealt round-robin) per slice of the destination
 //     rows and runs  for block b: for my groups: gather the edges that point into b,  the per-row sums staying in
 //     registers across the blocks (no partial results through memory); the destination rows are cut into slices so that

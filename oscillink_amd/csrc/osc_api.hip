@@ -226,7 +226,8 @@ struct osc_lattice {
   DevBuf<int2> blk_slots, blk_rest, blk_over;
   int blk_nb = 0;          // blocks of the copy held (0 = none / stale)
   int spmm_blocked = -1;   // -1 by lattice size, 0 off, > 0 = that many source blocks (OSC_SPMM_BLOCKED)
-  double blk_mb = 1.65;    // size of a source block (rows x 128 B) of the blocked apply: two are L2-resident (OSC_BLK_MB)
+  double blk_mb = 10.5;    // smallest slab (N x 128 B, MiB) the blocked apply is chosen for (OSC_BLK_MB)
+  double blk_edges = 4.3;  // edges of a row per source block the block count aims at (OSC_BLK_EDGES)
   int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
   int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
   int64_t blk_applies = 0; // blocked matvecs enqueued since creation
@@ -967,17 +968,23 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   return nb;
 }
 
-// Source blocks of the blocked CG matvec: 0 = use the plain apply.  Pays once the 32-column slab an XCD gathers from
-// (N x 128 B) no longer fits its L2.  The slab is cut into resident sets of ~blk_mb MB and each set into blocks small
-// enough that a row rarely has more than 8 edges into one block (the width of the block-major copy's slot rows).
+// Source blocks of the blocked CG matvec (k_apply_blocked): 0 = use the plain apply.
 int blocked_plan(const L& h, bool with_path) {
   if (h.spmm_blocked == 0 || with_path || (int64_t)h.N * h.width >= ((int64_t)1 << 28) || h.N >= ((int64_t)1 << 24) ||
       (int64_t)h.N * h.ld * 4 >= ((int64_t)1 << 32))
     return 0;
   if (h.spmm_blocked > 0) return std::min(h.spmm_blocked, OSC_MAX_SRC_BLOCKS);
-  const double slab = (double)h.N * 128.0, blk = h.blk_mb * 1024.0 * 1024.0;
-  if (slab <= 2.2 * blk) return 0;  // the whole slab (nearly) fits the L2 anyway
-  return (int)std::min<double>(OSC_MAX_SRC_BLOCKS, std::ceil(slab / blk));
+  // as many blocks as give a row ~4.3 edges into each (6 slots per (row, block); measured at N = 100k, D = 768: k = 16 /
+  // 24 / 32 / 48 / 64 are best with 4 / 5 / 7 / 10 / 14 blocks, each 8-11 % faster than the plain apply)
+  const double mean_deg = h.N > 0 ? (double)h.nnz / (double)h.N : 0.0;
+  const int nb = (int)std::min<double>(OSC_MAX_SRC_BLOCKS, std::max(2.0, std::floor(mean_deg / h.blk_edges + 0.5)));
+  if (h.spmm_blocked == -2) return nb;  // "whenever possible" (experiments)
+  // ... and only where it pays: the slab an XCD gathers from must be well beyond its 4 MB L2.  Measured against the
+  // plain apply (D = 768 unless noted, k = 32): N = 35k +11 %, 50k x 512 +7 %, 65k x 256 +2 %, 80k +2 %, 90k -5 %,
+  // 100k -10 %, 110k -1 % (three destination slices instead of two), 130k x 256 -12 %.
+  const double slab = (double)h.N * 128.0;
+  if (slab < h.blk_mb * 1024.0 * 1024.0) return 0;
+  return nb;
 }
 
 BlockedView blocked_view(L& h, int nb) {
@@ -1783,7 +1790,8 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     }
     if (const char* e = getenv("OSC_P_BLOCKED")) h->p_blocked = atoi(e) != 0;
     if (const char* e = getenv("OSC_SPMM_BLOCKED")) h->spmm_blocked = atoi(e);
-    if (const char* e = getenv("OSC_BLK_MB")) h->blk_mb = std::max(0.25, atof(e));
+    if (const char* e = getenv("OSC_BLK_MB")) h->blk_mb = std::max(0.0, atof(e));
+    if (const char* e = getenv("OSC_BLK_EDGES")) h->blk_edges = std::max(0.5, atof(e));
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
     if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
