@@ -311,8 +311,9 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 // What was tried on top and did not pay (scripts/exp/blocked_apply/README.md): pulling the next block into the L2 with
 // dword-per-line loads, gated or not by a progress counter in the XCD's L2 (no change: 877-890 us either way), and
 // holding leaders back at that counter (stragglers fall out of the resident set and get later still: 1.8-2.3 ms).
-// Same terms per row as k_spmm, added in ascending column order except for the (rare) edges beyond OSC_BLK_SLOTS per
-// (row, block), which are added last.  No chain prior here (lattices with one use k_spmm).
+// Same terms per row as k_spmm; the order of summation differs where a row has more than OSC_BLK_SLOTS edges into one
+// block (those move to a later block's free slots, launch_blocked_fill): results agree with k_spmm's to fp32 rounding
+// of the sums (3e-8 relative on the state).  No chain prior here (lattices with one use k_spmm).
 constexpr int kBlkGroups = 17;   // row groups per gathering wave (4 registers each for the sums)
 constexpr int kBlkPair = 1;      // groups whose gathers are in flight together (2 with 12 groups: 0.96-0.99 ms vs 0.88)
 constexpr int kBlkGatherWaves = 3;
@@ -457,41 +458,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (p.b == nb - 1) {  // the rows of this slice are complete: the rest of long lists, diagonal term, output, p.Ap
       const int w8 = opaque(W8);
       const int row_first = rlo + p.slice * slice_rows + ((wgx * CW + wave) << 3) + sub;
-      constexpr int EC = 4;  // groups whose own rows / gates / rest descriptors are fetched together (these loads miss)
-#pragma unroll
-      for (int g0 = 0; g0 < GM; g0 += EC) {
-        float4 xs[EC];
-        int2 rr[EC];
-        float bv[EC];
+      // Own rows / gates / rest descriptors of EC groups at a time (these loads miss).  Loads and stores of a wave retire
+      // in issue order, so the loads of batch k + 1 are issued BEFORE the stores of batch k: otherwise every batch would
+      // also wait for the previous batch's stores to be acknowledged.
+      constexpr int EC = 2, NBATCH = (GM + EC - 1) / EC;
+      float4 xs[2][EC];
+      int2 rr[2][EC];
+      float bv[2][EC];
+      auto fetch = [&](int k, float4 (&x)[EC], int2 (&r)[EC], float (&bb)[EC]) {
 #pragma unroll
         for (int i = 0; i < EC; ++i) {
-          const int g = g0 + i, row = row_first + g * w8;
-          xs[i] = f4(0.f);
-          rr[i] = make_int2(0, 0);
-          bv[i] = 0.f;
+          const int g = k * EC + i, row = row_first + g * w8;
+          x[i] = f4(0.f);
+          r[i] = make_int2(0, 0);
+          bb[i] = 0.f;
           if (g < GM && g < ng && row < rhi && cok) {
-            xs[i] = ld4_at(xbase, (uint32_t)row * 128u + lr16);
-            rr[i] = ld2_at(a.rest, (uint32_t)row * 8u);  // edges beyond SL per block: {first, count}, ascending columns
-            bv[i] = ld1_at(a.B, (uint32_t)row * 4u);
+            x[i] = ld4_at(xbase, (uint32_t)row * 128u + lr16);
+            r[i] = ld2_at(a.rest, (uint32_t)row * 8u);  // edges beyond SL per block: {first, count}, ascending columns
+            bb[i] = ld1_at(a.B, (uint32_t)row * 4u);
           }
         }
+      };
+      fetch(0, xs[0], rr[0], bv[0]);
+#pragma unroll
+      for (int k = 0; k < NBATCH; ++k) {
+        if (k + 1 < NBATCH) fetch(k + 1, xs[(k + 1) & 1], rr[(k + 1) & 1], bv[(k + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < EC; ++i) {
-          const int g = g0 + i, row = row_first + g * w8;
+          const int g = k * EC + i, row = row_first + g * w8;
           if (g >= GM) continue;
           if (g >= ng || row >= rhi || !cok) continue;
-          for (int e = 0; e < rr[i].y; ++e) {
-            const int2 en = ld2_at(a.over, (uint32_t)(rr[i].x + e) * 8u);
+          for (int e = 0; e < rr[k & 1][i].y; ++e) {
+            const int2 en = ld2_at(a.over, (uint32_t)(rr[k & 1][i].x + e) * 8u);
             acc[g] = fma4(__int_as_float(en.y), ld4_at(xbase, (uint32_t)en.x * 128u + lr16), acc[g]);
           }
-          const float cs = fmaf(a.cs_B, bv[i], a.cs_const);
+          const float cs = fmaf(a.cs_B, bv[k & 1][i], a.cs_const);
           float4 o;
-          o.x = cs * xs[i].x - a.cW * acc[g].x;
-          o.y = cs * xs[i].y - a.cW * acc[g].y;
-          o.z = cs * xs[i].z - a.cW * acc[g].z;
-          o.w = cs * xs[i].w - a.cW * acc[g].w;
+          o.x = cs * xs[k & 1][i].x - a.cW * acc[g].x;
+          o.y = cs * xs[k & 1][i].y - a.cW * acc[g].y;
+          o.z = cs * xs[k & 1][i].z - a.cW * acc[g].z;
+          o.w = cs * xs[k & 1][i].w - a.cW * acc[g].w;
           st4_stream(a.OUT + ((size_t)(uint32_t)row * (uint32_t)ld + (uint32_t)(p.sc0 + lr * 4)), o);
-          dot[0] = mulacc4(xs[i], o, dot[0]);
+          dot[0] = mulacc4(xs[k & 1][i], o, dot[0]);
         }
       }
     }
@@ -506,24 +514,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ---- build of the block-major graph copy ----------------------------------------------------
 __device__ __forceinline__ int blk_of(int col, int rpb, int nb) { return min(nb - 1, col / rpb); }
 
-// edges beyond the 8 slots of their (row, block), in total
+// Placement of a row's edges in the block-major copy: an edge goes into the slot row of its own block while that has room
+// (slots 0 .. c - 1 for the block's c <= SL own edges, ascending columns); an edge that finds its block full moves to
+// the first later block (cyclically) whose slot row has room behind that block's own edges -- it is then gathered while
+// another block is the resident one, i.e. as a miss among hits, but inside the regular rounds; only what fits nowhere
+// (degree > SL * nb) goes to the `over` list of the epilogue.  Deterministic: everything follows the ELL row's order.
+__device__ __forceinline__ int blk_unplaced(const int (&c)[OSC_MAX_SRC_BLOCKS]) {
+  int excess = 0, room = 0;
+#pragma unroll
+  for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q) {
+    excess += max(0, c[q] - OSC_BLK_SLOTS);
+    room += max(0, OSC_BLK_SLOTS - c[q]);  // (blocks q >= nb have c = SL: see the callers)
+  }
+  return max(0, excess - room);
+}
+
+// edges that fit no slot row, in total
 __global__ void k_blk_count(const int32_t* col, const int32_t* deg, int32_t width, int32_t N, int32_t nb, int32_t rpb,
                             unsigned* over_count) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= N) return;
   int c[OSC_MAX_SRC_BLOCKS];
 #pragma unroll
-  for (int k = 0; k < OSC_MAX_SRC_BLOCKS; ++k) c[k] = 0;
+  for (int k = 0; k < OSC_MAX_SRC_BLOCKS; ++k) c[k] = k < nb ? 0 : OSC_BLK_SLOTS;
   const int d = deg[row];
   for (int e = 0; e < d; ++e) {
     const int b = blk_of(col[(size_t)row * width + e], rpb, nb);
 #pragma unroll
     for (int k = 0; k < OSC_MAX_SRC_BLOCKS; ++k) c[k] += (k == b);
   }
-  unsigned over = 0;
-#pragma unroll
-  for (int k = 0; k < OSC_MAX_SRC_BLOCKS; ++k) over += (unsigned)max(0, c[k] - OSC_BLK_SLOTS);
-  if (over) atomicAdd(over_count, over);
+  const int over = blk_unplaced(c);
+  if (over) atomicAdd(over_count, (unsigned)over);
 }
 
 // *over_count must be zero on entry (it hands out the ranges of `over`); slots must be pre-filled with {-1, x}
@@ -531,18 +552,18 @@ __global__ void k_blk_fill(const int32_t* col, const float* w, const int32_t* de
                            int32_t rpb, int2* slots, int2* rest, int2* over, unsigned* over_count) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= N) return;
-  int c[OSC_MAX_SRC_BLOCKS], k[OSC_MAX_SRC_BLOCKS];
+  int c[OSC_MAX_SRC_BLOCKS], k[OSC_MAX_SRC_BLOCKS], tail[OSC_MAX_SRC_BLOCKS];
 #pragma unroll
-  for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q) c[q] = 0, k[q] = 0;
+  for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q) c[q] = q < nb ? 0 : OSC_BLK_SLOTS, k[q] = 0;
   const int d = deg[row];
   for (int e = 0; e < d; ++e) {
     const int b = blk_of(col[(size_t)row * width + e], rpb, nb);
 #pragma unroll
     for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q) c[q] += (q == b);
   }
-  int total = 0;
 #pragma unroll
-  for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q) total += max(0, c[q] - OSC_BLK_SLOTS);
+  for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q) tail[q] = min(c[q], OSC_BLK_SLOTS);  // first slot behind the own edges
+  const int total = blk_unplaced(c);
   unsigned at = total ? atomicAdd(over_count, (unsigned)total) : 0u;
   rest[row] = make_int2((int)at, total);
   for (int e = 0; e < d; ++e) {
@@ -553,7 +574,18 @@ __global__ void k_blk_fill(const int32_t* col, const float* w, const int32_t* de
     for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q)
       if (q == b) kb = k[q]++;
     const int2 ent = make_int2(j, __float_as_int(w[(size_t)row * width + e]));
-    if (kb < OSC_BLK_SLOTS) slots[((size_t)b * N + row) * OSC_BLK_SLOTS + kb] = ent;
+    if (kb < OSC_BLK_SLOTS) {
+      slots[((size_t)b * N + row) * OSC_BLK_SLOTS + kb] = ent;
+      continue;
+    }
+    int tb = -1, ts = 0;  // first block after b (cyclically) with room
+    for (int step = 1; step < nb && tb < 0; ++step) {
+      const int q = (b + step) % nb;
+#pragma unroll
+      for (int t = 0; t < OSC_MAX_SRC_BLOCKS; ++t)
+        if (t == q && tail[t] < OSC_BLK_SLOTS) tb = q, ts = tail[t]++;
+    }
+    if (tb >= 0) slots[((size_t)tb * N + row) * OSC_BLK_SLOTS + ts] = ent;
     else over[at++] = ent;
   }
 }
