@@ -233,22 +233,24 @@ def main():
     settle_gbs = (world if replicas else 1) * bytes_settle / (ms_per_step * 1e-3) / 1e9  # all GPUs together
 
     # The same launch against the bound that applies to a gather (profiles/r02_gather_bench.txt):
-    # a CU retires one random 128-byte row per `ceiling` clocks for the footprint an XCD gathers from (its 32-column slab,
-    # N x 128 B) -- measured with scripts/exp/gather_bench.hip on this part, no index loads; 256 CUs at 2.4 GHz.
+    # a CU retires one random 128-byte row per N clocks depending on the footprint an XCD gathers from -- measured with
+    # scripts/exp/gather_bench.hip on this part, no index loads; 256 CUs at 2.4 GHz.  Two yardsticks: the whole 32-column
+    # slab (N x 128 B: what the plain apply gathers from) and an L2-resident source (what source blocking aims at).
     request_rate = None
     if spmm_kernel and world == 1 and mv_ms > 0:
         rows = float(nnz) * ((d_local + 31) // 32)                       # gathered neighbour rows per launch
         mb = N * 128.0 / 2 ** 20
         pts = [(3.6, 2.4), (6.4, 4.0), (12.8, 7.0), (32.0, 9.3), (200.0, 10.9)]  # MB per XCD -> clk per row per CU
-        ceil_clk = pts[0][1] if mb <= pts[0][0] else pts[-1][1]
+        slab_clk = pts[0][1] if mb <= pts[0][0] else pts[-1][1]
         for (m0, c0_), (m1, c1_) in zip(pts, pts[1:]):
             if m0 < mb <= m1:
-                ceil_clk = c0_ + (c1_ - c0_) * (math.log(mb / m0) / math.log(m1 / m0))
+                slab_clk = c0_ + (c1_ - c0_) * (math.log(mb / m0) / math.log(m1 / m0))
         clk = mv_ms * 1e-3 * 2.4e9 * 256 / rows
-        request_rate = {"gathered_rows_per_launch": rows, "footprint_MB_per_xcd": mb, "achieved_clk_per_row_per_cu": clk,
-                        "ceiling_clk_per_row_per_cu": ceil_clk, "frac": ceil_clk / clk,
+        request_rate = {"gathered_rows_per_launch": rows, "achieved_clk_per_row_per_cu": clk,
+                        "slab_footprint_MB_per_xcd": mb, "slab_footprint_clk_per_row_per_cu": slab_clk,
+                        "l2_resident_clk_per_row_per_cu": pts[0][1], "frac_of_l2_resident_rate": pts[0][1] / clk,
                         "source": "profiles/r02_gather_bench.txt (gathers only; the apply also issues edge-list, own-row "
-                                  "and output requests, ~14 % of its L2 requests)"}
+                                  "and output requests)"}
 
     out = {
         "metric": "settles/sec",

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 //     registers across the blocks (no partial results through memory); the destination rows are cut into slices so that
 //     the rows in flight on an XCD fit its waves' registers.  All waves of an XCD walk the same (slab, slice, block)
 //     sequence from the same start, so what they gather from at any time is a few neighbouring blocks rather than the
-//     whole slab (L2 hits 25 -> 54 M, misses 58 -> 31 M per launch at config 3);
+//     whole slab (L2 hits 25 -> 49 M, misses 58 -> 33 M per launch at config 3);
 //   * loads of one wave complete in issue order, so a miss in a gathering wave's stream holds up every L2 hit behind it.
 //     Hence two roles per workgroup: waves 0-2 gather (LDS reads and slab rows only), wave 3 reads the next block's edge
 //     lists (block-major copy of the graph, BlockedView: always misses) into registers while the others gather and
