@@ -511,6 +511,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+// chain prior for k_apply_blocked (ChainFixArgs): one wave per (64 columns, chunk of path rows), one thread per column
+__global__ __launch_bounds__(64) void k_chain_fix(const ChainFixArgs a) {
+  if (a.gate != nullptr && *a.gate <= a.gate_tol) return;
+  const int col = a.c0 + (int)blockIdx.x * 64 + (int)threadIdx.x;
+  const int chunk = (int)blockIdx.y;
+  const int per = (a.prows + a.chunks - 1) / a.chunks;
+  const int s0 = chunk * per, s1 = min(a.prows, s0 + per);
+  float dotc = 0.f;
+  if (col < a.c1) {
+    const float* xs = a.X + (size_t)(col >> 5) * (size_t)a.N * 32 + (col & 31);  // this column of the slab-major operand
+    for (int s = s0; s < s1; ++s) {
+      const int i = a.prow[s], d = a.pdeg[s];
+      float acc = 0.f;
+      for (int e = 0; e < d; ++e) acc = fmaf(a.pw[(size_t)s * a.pwidth + e], xs[(size_t)a.pcol[(size_t)s * a.pwidth + e] * 32], acc);
+      const float o = -a.cP * acc;
+      a.OUT[(size_t)i * a.ld + col] += o;
+      dotc = fmaf(xs[(size_t)i * 32], o, dotc);
+    }
+    a.part[(size_t)(a.part_row0 + chunk) * a.ld + col] = dotc;
+  }
+}
+
 // ---- build of the block-major graph copy ----------------------------------------------------
 __device__ __forceinline__ int blk_of(int col, int rpb, int nb) { return min(nb - 1, col / rpb); }
 
@@ -876,6 +898,13 @@ void launch_blocked_fill(const int32_t* col, const float* w, const int32_t* deg,
 }
 int blocked_groups_max() { return kBlkGroups; }
 int blocked_gather_waves() { return kBlkGatherWaves; }
+int chain_fix_chunks(int32_t prows) { return std::max(1, std::min(OSC_CHAIN_FIX_MAX_CHUNKS, (prows + 7) / 8)); }
+void launch_chain_fix(const ChainFixArgs& a, hipStream_t s) {
+  if (a.prows < 1 || a.prows > OSC_CHAIN_FIX_MAX_ROWS || a.chunks < 1 || a.chunks > OSC_CHAIN_FIX_MAX_CHUNKS || a.c1 <= a.c0)
+    throw std::runtime_error("chain fix-up: unsupported arguments");
+  hipLaunchKernelGGL(k_chain_fix, dim3((a.c1 - a.c0 + 63) / 64, a.chunks), dim3(64), 0, s, a);
+  HIP_CHECK(hipGetLastError());
+}
 int blocked_resident_per_cu() {
   int n = 0;
   HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_apply_blocked<kBlkGroups>, 256, 0));

@@ -191,6 +191,24 @@ void launch_blocked_fill(const int32_t* col, const float* w, const int32_t* deg,
 // row groups per wave the blocked apply holds in registers, and the workgroups per CU it needs resident
 int blocked_groups_max();
 int blocked_gather_waves();
+// Chain prior beside the blocked matvec: out_i -= cP sum_j Wp_ij x_j for the (few) rows of the chain's path graph, and
+// the matching terms of the p . Ap column sums into the rows [part_row0, part_row0 + chunks) of `part`.
+constexpr int OSC_CHAIN_FIX_MAX_ROWS = 4096;
+constexpr int OSC_CHAIN_FIX_MAX_CHUNKS = 64;
+struct ChainFixArgs {
+  const float* X;        // operand, slab-major
+  float* OUT;            // row-major, pitch ld: already holds the result without the chain term
+  float* part;
+  const int32_t* prow;   // [prows] lattice row of path row s
+  const int32_t* pcol;   // [prows][pwidth]
+  const float* pw;
+  const int32_t* pdeg;
+  const float* gate;
+  float gate_tol, cP;
+  int32_t prows, pwidth, N, ld, c0, c1, part_row0, chunks;
+};
+int chain_fix_chunks(int32_t prows);
+void launch_chain_fix(const ChainFixArgs& a, hipStream_t s);
 void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s);
 int blocked_resident_per_cu();
 void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s);

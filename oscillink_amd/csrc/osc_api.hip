@@ -203,7 +203,7 @@ struct osc_lattice {
   bool chain_present = false;
   float lamP = 0.0f;
   int32_t prows = 0, pwidth = 0;
-  DevBuf<int32_t> path_slot, pcol, pdeg;
+  DevBuf<int32_t> path_slot, pcol, pdeg, prow;  // prow: lattice row of path row s (inverse of path_slot)
   DevBuf<float> pw;
   // CG scratch
   int grid_cap = 1024;
@@ -435,7 +435,7 @@ void ensure_ctrl(L& h, size_t slots) {
 }
 
 void ensure_cg_scratch(L& h, int max_iters) {
-  const size_t pn = (size_t)h.grid_cap * h.ld;
+  const size_t pn = (size_t)(h.grid_cap + OSC_CHAIN_FIX_MAX_CHUNKS) * h.ld;  // + the chain fix-up's rows beside the blocked apply
   h.part0.alloc(pn);
   h.part1.alloc(pn);
   h.alpha.alloc(h.ld);
@@ -538,7 +538,8 @@ void install_chain(L& l) {
     auto it = dsum.find(r);
     return std::sqrt(std::max(it == dsum.end() ? 0.0f : it->second, 1e-12f));
   };
-  for (auto& kv : slot) hslot[(size_t)kv.first] = kv.second;
+  std::vector<int32_t> hprow((size_t)prows, 0);
+  for (auto& kv : slot) hslot[(size_t)kv.first] = kv.second, hprow[(size_t)kv.second] = kv.first;
   for (auto& kv : adj) {
     const int32_t r = kv.first.first, c = kv.first.second, sl = slot[r];
     const int32_t e = hdeg[(size_t)sl]++;
@@ -549,6 +550,8 @@ void install_chain(L& l) {
   l.pcol.alloc(hcol.size());
   l.pw.alloc(hw.size());
   l.pdeg.alloc(hdeg.size());
+  l.prow.alloc(hprow.size());
+  HIP_CHECK(hipMemcpyAsync(l.prow.p, hprow.data(), hprow.size() * 4, hipMemcpyHostToDevice, l.stream));
   HIP_CHECK(hipMemcpyAsync(l.path_slot.p, hslot.data(), hslot.size() * 4, hipMemcpyHostToDevice, l.stream));
   HIP_CHECK(hipMemcpyAsync(l.pcol.p, hcol.data(), hcol.size() * 4, hipMemcpyHostToDevice, l.stream));
   HIP_CHECK(hipMemcpyAsync(l.pw.p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, l.stream));
@@ -970,7 +973,7 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
 
 // Source blocks of the blocked CG matvec (k_apply_blocked): 0 = use the plain apply.
 int blocked_plan(const L& h, bool with_path) {
-  if (h.spmm_blocked == 0 || with_path || (int64_t)h.N * h.width >= ((int64_t)1 << 28) || h.N >= ((int64_t)1 << 24) ||
+  if (h.spmm_blocked == 0 || (with_path && (h.prows < 1 || h.prows > OSC_CHAIN_FIX_MAX_ROWS)) || (int64_t)h.N * h.width >= ((int64_t)1 << 28) || h.N >= ((int64_t)1 << 24) ||
       (int64_t)h.N * h.ld * 4 >= ((int64_t)1 << 32))
     return 0;
   if (h.spmm_blocked > 0) return std::min(h.spmm_blocked, OSC_MAX_SRC_BLOCKS);
@@ -1212,6 +1215,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   sa.pblk = 0;
   // source-blocked CG matvec (k_apply_blocked) where the slab an XCD gathers from is far larger than its L2
   BlkArgs ba{};
+  ChainFixArgs cf{};
   if (pblk && b.c0 == h.c0 && b.c1 == h.c1) {
     if (const int nb = blocked_plan(h, with_path)) {
       const BlockedView bv = blocked_view(h, nb);
@@ -1240,6 +1244,24 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       const int64_t nsl = (rows + per_group * gmax - 1) / (per_group * gmax);
       ba.slices = (int32_t)nsl;
       ba.groups = (int32_t)std::max<int64_t>(1, (rows + nsl * per_group - 1) / (nsl * per_group));
+      if (with_path && op.cP != 0.f) {  // the chain prior's few rows: a small launch behind every blocked apply
+        cf.X = b.P;
+        cf.OUT = b.AP;
+        cf.part = h.part0.p;
+        cf.prow = h.prow.p;
+        cf.pcol = h.pcol.p;
+        cf.pw = h.pw.p;
+        cf.pdeg = h.pdeg.p;
+        cf.cP = op.cP;
+        cf.prows = h.prows;
+        cf.pwidth = h.pwidth;
+        cf.N = (int32_t)h.N;
+        cf.ld = b.ld;
+        cf.c0 = b.c0;
+        cf.c1 = b.c1;
+        cf.part_row0 = grid;
+        cf.chunks = chain_fix_chunks(h.prows);
+      }
     }
   }
 
@@ -1259,11 +1281,16 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       ba.gate = g.p;
       ba.gate_tol = tol;
       launch_apply_blocked(ba, grid, h.stream);
+      if (cf.chunks > 0) {
+        cf.gate = g.p;
+        cf.gate_tol = tol;
+        launch_chain_fix(cf, h.stream);
+      }
       h.blk_applies += 1;
     } else {
       spmm_slabbed(h, SPMM_AP, sa, grid, it);
     }
-    launch_reduce_alpha(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
+    launch_reduce_alpha(h.part0.p, grid + (ba.nb > 0 ? cf.chunks : 0), b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
     {
       ProfScope ps(h, 1, it);
       for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });

@@ -1006,15 +1006,17 @@ def test_padded_row_pitch_is_invisible(amd, name, ld, small, monkeypatch):
     assert len(lat.bundle(k=5)) == 5
 
 
+@pytest.mark.parametrize("name", ["c2_n1200_d128_k16", "g1_n400_d64_k6_chain8"])
 @pytest.mark.parametrize("nb", ["2", "5", "16"])
-def test_source_blocked_apply_matches_reference(amd, nb, monkeypatch):
-    """OSC_SPMM_BLOCKED=n forces the source-blocked CG matvec (chosen automatically only when the 32-column slab is several
-    times an XCD's L2) onto a fixture, on top of the forced XCD-affine slabs it builds on; OSC_SMALL_PATH=0 keeps the
-    general multi-launch CG in play.  Same fixture, same tolerances, same iteration counts as every other path."""
+def test_source_blocked_apply_matches_reference(amd, name, nb, monkeypatch):
+    """OSC_SPMM_BLOCKED=n forces the source-blocked CG matvec (chosen automatically only when the 32-column slab does not
+    fit an XCD's L2) onto fixtures, on top of the forced XCD-affine slabs it builds on; OSC_SMALL_PATH=0 keeps the general
+    multi-launch CG in play.  The second fixture has a chain prior (the fix-up launch behind every blocked apply).  Same
+    fixtures, same tolerances, same iteration counts as every other path."""
     monkeypatch.setenv("OSC_SPMM_XS", "1")
     monkeypatch.setenv("OSC_SPMM_BLOCKED", nb)
     monkeypatch.setenv("OSC_SMALL_PATH", "0")
-    case = load_case("c2_n1200_d128_k16")
+    case = load_case(name)
     rc = case["recipe"]
     Y, psi = make_inputs(rc)
     lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
@@ -1028,8 +1030,8 @@ def test_source_blocked_apply_matches_reference(amd, nb, monkeypatch):
 def test_source_blocked_apply_against_the_plain_one(amd, orc, monkeypatch):
     """A lattice inside the automatic window (N = 40000, D = 256: slab 5 MB) with random gates: the blocked matvec and the
     plain one give the same iteration count and the same state to fp32 summation-order noise; rows with more than
-    OSC_BLK_SLOTS edges into one block (forced by only 2 blocks at k = 24) take the epilogue path; a chain prior switches
-    the blocked matvec off; a rebuilt graph rebuilds the block-major copy."""
+    OSC_BLK_SLOTS edges into one block move to other blocks' slots and, with only 2 blocks at k = 24, to the epilogue
+    list; a chain prior adds the fix-up launch; a rebuilt graph rebuilds the block-major copy."""
     monkeypatch.delenv("OSC_SPMM_XS", raising=False)
     monkeypatch.delenv("OSC_REORDER", raising=False)
     rng = np.random.default_rng(77)
@@ -1047,9 +1049,19 @@ def test_source_blocked_apply_against_the_plain_one(amd, orc, monkeypatch):
         assert info["apply_src_blocks"] == int(mode), info
         out[mode] = (st["iters"], st["res"], lat.U.copy())
         if mode == "3":
-            lat.add_chain([3, 1, 4, 15, 9, 2, 6], lamP=0.25)  # chain prior: the plain apply takes over
+            lat.add_chain([3, 1, 4, 15, 9, 2, 6, 39999, 20000], lamP=0.25)  # chain prior: blocked apply + fix-up launch
+            lat.reset_U()
             st2 = lat.settle(max_iters=12, tol=1e-4)
-            assert lat.build_info()["apply_src_blocks"] == 0 and st2["iters"] >= 1
+            assert lat.build_info()["apply_src_blocks"] == 3
+            monkeypatch.setenv("OSC_SPMM_BLOCKED", "0")
+            pl = amd.Oscillink(Y, kneighbors=k)
+            pl.set_query(psi, gates=gates)
+            pl.add_chain([3, 1, 4, 15, 9, 2, 6, 39999, 20000], lamP=0.25)
+            st2p = pl.settle(max_iters=12, tol=1e-4)
+            assert pl.build_info()["apply_src_blocks"] == 0
+            assert st2["iters"] == st2p["iters"] and relerr(lat.U, pl.U) < 1e-6
+            pl.close()
+            monkeypatch.setenv("OSC_SPMM_BLOCKED", "3")
             lat.clear_chain()
             lat.rebuild_graph(kneighbors=8)  # new graph: the block-major copy must follow
             lat.reset_U()
