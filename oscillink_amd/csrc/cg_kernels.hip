@@ -612,6 +612,72 @@ __global__ void k_blk_fill(const int32_t* col, const float* w, const int32_t* de
   }
 }
 
+// ---- initial residual around the blocked matvec (InitFinishArgs) ---------------------------------------------------
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void k_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, int32_t c0,
+                                                      int32_t c1) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, lr = lane % LPR;
+  for (int64_t rb = ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < N; rb += (int64_t)gridDim.x * 4 * RPW) {
+    const int row = (int)rb + sub;
+    if (row >= N) continue;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int col = c0 + (ch * LPR + lr) * 4;
+      if (col < c1) st4(dst + blk_off(N, row, col), ld4_stream(src + (size_t)row * ld + col));
+    }
+  }
+}
+
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void k_init_finish(const InitFinishArgs a) {
+  constexpr int RPW = 64 / LPR;
+  constexpr int CPW = NCH * LPR * 4;
+  __shared__ __attribute__((aligned(16))) float red[4 * CPW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, lr = lane % LPR;
+  const int32_t ld = a.ld;
+  int coff[NCH];
+  bool cok[NCH];
+  float4 psi4[NCH], rz[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    coff[ch] = a.c0 + (ch * LPR + lr) * 4;
+    cok[ch] = coff[ch] < a.c1;
+    psi4[ch] = cok[ch] ? ld4(a.psi + coff[ch]) : f4(0.f);
+    rz[ch] = f4(0.f);
+  }
+  for (int64_t rb = ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < a.N; rb += (int64_t)gridDim.x * 4 * RPW) {
+    const int row = (int)rb + sub;
+    if (row >= a.N) continue;
+    const float Bi = a.B[row];
+    float invMd = 1.f;
+    if (a.op.precond) invMd = 1.f / (fmaf(a.op.md_B, Bi, a.op.md_const) + 1e-12f);
+    const float qb = a.op.rbB * Bi;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (!cok[ch]) continue;
+      const size_t off = (size_t)row * ld + coff[ch];
+      const float4 o = ld4_stream(a.AP + off);
+      const float4 xs = ld4_stream(a.X0 + off);
+      const float4 u = (a.U == a.X0) ? xs : (a.op.rbU != 0.f ? ld4_stream(a.U + off) : f4(0.f));
+      const float4 y = (a.Y == a.X0) ? xs : ld4_stream(a.Y + off);
+      float4 r, z;
+      r.x = (a.op.rbU * u.x + a.op.rbY * y.x + qb * psi4[ch].x) - o.x;
+      r.y = (a.op.rbU * u.y + a.op.rbY * y.y + qb * psi4[ch].y) - o.y;
+      r.z = (a.op.rbU * u.z + a.op.rbY * y.z + qb * psi4[ch].z) - o.z;
+      r.w = (a.op.rbU * u.w + a.op.rbY * y.w + qb * psi4[ch].w) - o.w;
+      z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
+      if (a.X != a.X0) st4_stream(a.X + off, xs);
+      st4_stream(a.R + off, r);
+      st4(a.P + blk_off(a.pblk, row, coff[ch]), z);
+      rz[ch] = mulacc4(r, z, rz[ch]);
+    }
+  }
+  block_fold<LPR, NCH>(rz, red, a.part, ld, a.c0, a.c1);
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int LPR, int NCH>
 __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
@@ -898,6 +964,24 @@ void launch_blocked_fill(const int32_t* col, const float* w, const int32_t* deg,
 }
 int blocked_groups_max() { return kBlkGroups; }
 int blocked_gather_waves() { return kBlkGatherWaves; }
+void launch_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, int32_t c0, int32_t c1, int grid, hipStream_t s) {
+  for (int32_t s0 = c0; s0 < c1; s0 += 2048) {  // at most 2048 columns per launch, like the other elementwise kernels
+    const int32_t s1 = std::min(c1, s0 + 2048);
+    const Shape sh = pick_shape(s1 - s0);
+#define CALL(L, C) hipLaunchKernelGGL((k_rows_to_slab<L, C>), dim3(grid), dim3(256), 0, s, src, dst, N, ld, s0, s1)
+    OSC_SHAPE_SWITCH(sh, CALL);
+#undef CALL
+  }
+  HIP_CHECK(hipGetLastError());
+}
+void launch_init_finish(const InitFinishArgs& a, int grid, hipStream_t s) {
+  if (a.c1 - a.c0 > 2048) throw std::runtime_error("init_finish: column window wider than 2048");
+  const Shape sh = pick_shape(a.c1 - a.c0);
+#define CALL(L, C) hipLaunchKernelGGL((k_init_finish<L, C>), dim3(grid), dim3(256), 0, s, a)
+  OSC_SHAPE_SWITCH(sh, CALL);
+#undef CALL
+  HIP_CHECK(hipGetLastError());
+}
 int chain_fix_chunks(int32_t prows) { return std::max(1, std::min(OSC_CHAIN_FIX_MAX_CHUNKS, (prows + 7) / 8)); }
 void launch_chain_fix(const ChainFixArgs& a, hipStream_t s) {
   if (a.prows < 1 || a.prows > OSC_CHAIN_FIX_MAX_ROWS || a.chunks < 1 || a.chunks > OSC_CHAIN_FIX_MAX_CHUNKS || a.c1 <= a.c0)

@@ -207,6 +207,27 @@ struct ChainFixArgs {
   float gate_tol, cP;
   int32_t prows, pwidth, N, ld, c0, c1, part_row0, chunks;
 };
+// initial residual of a solve around the blocked matvec: rows_to_slab copies the columns [c0, c1) of a row-major array into
+// the slab-major layout the blocked matvec gathers from; init_finish turns AP = A x0 into r = b - A x0, z = r / (Md + eps),
+// p = z (slab-major), the x0 copy (when the solve is not in place) and the r . z column partials -- the tail of
+// k_spmm<.., INIT>, same expressions (solver.py:19-22)
+struct InitFinishArgs {
+  const float* AP;   // A x0, row-major
+  const float* X0;   // x0
+  float* X;          // solution array (== X0: in place, nothing to copy)
+  float* R;
+  float* P;          // slab-major, `pblk` rows per slab
+  const float* U;    // rhs terms (either may alias X0)
+  const float* Y;
+  const float* B;
+  const float* psi;
+  float* part;       // [grid][ld] r . z partials
+  OpParams op;
+  int64_t N, pblk;
+  int32_t ld, c0, c1;
+};
+void launch_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, int32_t c0, int32_t c1, int grid, hipStream_t s);
+void launch_init_finish(const InitFinishArgs& a, int grid, hipStream_t s);
 int chain_fix_chunks(int32_t prows);
 void launch_chain_fix(const ChainFixArgs& a, hipStream_t s);
 void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s);

@@ -230,6 +230,7 @@ struct osc_lattice {
   double blk_edges = 5.2;  // edges of a row per source block the block count aims at (OSC_BLK_EDGES)
   int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
   int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
+  bool blk_init = true;    // the initial residual goes through the blocked matvec as well (OSC_BLK_INIT=0: plain INIT apply)
   int64_t blk_applies = 0; // blocked matvecs enqueued since creation
   int64_t small_solves = 0;
   float* res_host = nullptr;  // pinned, host-mapped mirror of res_bits for the per-iteration read-back
@@ -1191,28 +1192,6 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   const bool pblk = h.p_blocked && xs_plan(h, b.c1 - b.c0, grid) > 0 && (b.ld & 31) == 0 && (b.c0 & 31) == 0 &&
                     b.ld == h.ld;
   sa.pblk = pblk ? h.N : 0;
-  spmm_slabbed(h, SPMM_INIT, sa, grid);
-  launch_reduce_init(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.stream);
-  UpdateArgs ua{};
-  ua.pblk = pblk ? h.N : 0;
-  ua.X = b.X;
-  ua.R = b.R;
-  ua.P = b.P;
-  ua.AP = b.AP;
-  ua.B = b.B;
-  ua.alpha = h.alpha.p;
-  ua.beta = h.beta.p;
-  ua.part_rr = h.part0.p;
-  ua.part_rz = h.part1.p;
-  ua.op = op;
-  ua.N = h.N;
-  ua.ld = b.ld;
-  ua.c0 = b.c0;
-  ua.c1 = b.c1;
-  sa.X = b.P;
-  sa.OUT = b.AP;
-  sa.xblk = pblk ? h.N : 0;
-  sa.pblk = 0;
   // source-blocked CG matvec (k_apply_blocked) where the slab an XCD gathers from is far larger than its L2
   BlkArgs ba{};
   ChainFixArgs cf{};
@@ -1265,6 +1244,60 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     }
   }
 
+  if (ba.nb > 0 && h.blk_init) {
+    // r = b - A x0 around the blocked matvec: x0 -> slab-major (into P), A x0 -> AP, then r, z, p = z, r . z
+    ProfScope ps(h, 4, 0);
+    launch_rows_to_slab(b.x0, b.P, h.N, b.ld, b.c0, b.c1, grid, h.stream);
+    ba.gate = nullptr;
+    launch_apply_blocked(ba, grid, h.stream);
+    if (cf.chunks > 0) {
+      cf.gate = nullptr;
+      launch_chain_fix(cf, h.stream);
+    }
+    InitFinishArgs fa{};
+    fa.AP = b.AP;
+    fa.X0 = b.x0;
+    fa.X = b.X;
+    fa.R = b.R;
+    fa.P = b.P;
+    fa.U = b.rhsU;
+    fa.Y = b.rhsY;
+    fa.B = b.B;
+    fa.psi = b.psi;
+    fa.part = h.part0.p;
+    fa.op = op;
+    fa.N = h.N;
+    fa.pblk = h.N;
+    fa.ld = b.ld;
+    for (int32_t s0 = b.c0; s0 < b.c1; s0 += 2048) {
+      fa.c0 = s0;
+      fa.c1 = std::min(b.c1, s0 + 2048);
+      launch_init_finish(fa, grid, h.stream);
+    }
+  } else {
+    spmm_slabbed(h, SPMM_INIT, sa, grid);
+  }
+  launch_reduce_init(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.stream);
+  UpdateArgs ua{};
+  ua.pblk = pblk ? h.N : 0;
+  ua.X = b.X;
+  ua.R = b.R;
+  ua.P = b.P;
+  ua.AP = b.AP;
+  ua.B = b.B;
+  ua.alpha = h.alpha.p;
+  ua.beta = h.beta.p;
+  ua.part_rr = h.part0.p;
+  ua.part_rz = h.part1.p;
+  ua.op = op;
+  ua.N = h.N;
+  ua.ld = b.ld;
+  ua.c0 = b.c0;
+  ua.c1 = b.c1;
+  sa.X = b.P;
+  sa.OUT = b.AP;
+  sa.xblk = pblk ? h.N : 0;
+  sa.pblk = 0;
   h.blk_last = ba.nb;
   auto enqueue_iter = [&](int it) {  // everything of iteration `it` up to its residual, gated on iteration it-1
     const Gate g{it > 1 ? res_dev + (it - 1) : nullptr, tol};
@@ -1821,6 +1854,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_SPMM_BLOCKED")) h->spmm_blocked = atoi(e);
     if (const char* e = getenv("OSC_BLK_MB")) h->blk_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_BLK_EDGES")) h->blk_edges = std::max(0.5, atof(e));
+    if (const char* e = getenv("OSC_BLK_INIT")) h->blk_init = atoi(e) != 0;
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
     if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
