@@ -218,7 +218,7 @@ def main():
     # row; per launch = per apply / launches.
     plan = lat.build_info()
     slabs = max(1, plan["apply_launches"])
-    spmm_kernel = ("k_apply_blocked<17>" if plan.get("apply_src_blocks") else
+    spmm_kernel = ("k_apply_blocked<" if plan.get("apply_src_blocks") else  # (template arguments: matched by prefix)
                    "k_spmm<8, 1, 0>" if plan["apply_xs_workgroups"] else None)
     bytes_apply = 8.0 * n_local * d_local + (8.0 * nnz + 12.0 * N) * (n_local / N)
     apply_ms = total_ms.value / max(1, launches.value)
@@ -275,7 +275,7 @@ def main():
         "lattice_create_ms": lattice_create_ms,  # first call in the process: HIP context + code objects + upload + build
         "graph_build_device_ms": dev_build_ms,
         "roofline": {"bound": "hbm",
-                     "kernel": (f"k_apply_blocked<17> (operator apply / CG matvec; one launch, XCD-affine 32-column slabs, "
+                     "kernel": (f"k_apply_blocked (operator apply / CG matvec; one launch, XCD-affine 32-column slabs, "
                                 f"source rows walked in {plan['apply_src_blocks']} blocks)" if plan.get("apply_src_blocks") else
                                 "k_spmm<8,1,AP> (operator apply / CG matvec; one launch, XCD-affine 32-column slabs)"
                                 if spmm_kernel else "k_spmm (operator apply / CG matvec; one column-slab launch)"),
@@ -368,7 +368,7 @@ def pmc_traffic(N, D, k, world, kernel):
             continue
         if prof.get("_meta", {}).get("lib_hash") != h:
             continue
-        e = prof.get(kernel)
+        e = prof.get(kernel) or next((v for k_, v in prof.items() if kernel.endswith("<") and k_.startswith(kernel)), None)
         if e and "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
             return e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, None

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 //     sequence from the same start, so what they gather from at any time is a few neighbouring blocks rather than the
 //     whole slab (L2 hits 25 -> 49 M, misses 58 -> 33 M per launch at config 3);
 //   * loads of one wave complete in issue order, so a miss in a gathering wave's stream holds up every L2 hit behind it.
-//     Hence two roles per workgroup: waves 0-2 gather (LDS reads and slab rows only), wave 3 reads the next block's edge
+//     Hence two roles per workgroup: waves 0-6 gather (LDS reads and slab rows only), wave 7 reads the next block's edge
 //     lists (block-major copy of the graph, BlockedView: always misses) into registers while the others gather and
 //     writes them to the other half of an LDS staging area; one workgroup barrier per block.
 // What was tried on top and did not pay (scripts/exp/blocked_apply/README.md): pulling the next block into the L2 with
@@ -314,9 +314,9 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 // Same terms per row as k_spmm; the order of summation differs where a row has more than OSC_BLK_SLOTS edges into one
 // block (those move to a later block's free slots, launch_blocked_fill): results agree with k_spmm's to fp32 rounding
 // of the sums (3e-8 relative on the state).  No chain prior here (lattices with one use k_spmm).
-constexpr int kBlkGroups = 17;   // row groups per gathering wave (4 registers each for the sums)
+constexpr int kBlkGroups = 14;   // row groups per gathering wave (4 registers each for the sums)
 constexpr int kBlkPair = 1;      // groups whose gathers are in flight together (2 with 12 groups: 0.96-0.99 ms vs 0.88)
-constexpr int kBlkGatherWaves = 3;
+constexpr int kBlkGatherWaves = 7;  // + the list wave: workgroups of 512 (3 + 1 with 17 groups: 0.71 instead of 0.66 ms at config 3)
 
 __device__ __forceinline__ float4 ld4_at(const float* base, uint32_t byte_off) {
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -336,17 +336,40 @@ struct BlkPhase {  // sub-phase ph = (slab, slice, block): every wave of the XCD
   int sc0, slice, b;
 };
 
-template <int GM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_apply_blocked(const BlkArgs a) {
-  constexpr int CW = kBlkGatherWaves, SL = OSC_BLK_SLOTS;
-  __shared__ __attribute__((aligned(16))) float red[4 * 32];
+// the slab's column sums of one workgroup: every wave (the list wave with zeros) folds its 8 row lanes, then the waves'
+// rows of 32 columns are added in wave order
+template <int NW>
+__device__ __forceinline__ void blk_fold(float4 dot, float (&red)[NW][32], float* part, int32_t ld, int32_t c0, int32_t c1,
+                                         int wave, int lane) {
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    dot.x += __shfl_xor(dot.x, o, 64);
+    dot.y += __shfl_xor(dot.y, o, 64);
+    dot.z += __shfl_xor(dot.z, o, 64);
+    dot.w += __shfl_xor(dot.w, o, 64);
+  }
+  __syncthreads();  // red may still be read by a previous fold
+  if (lane < 8) st4(&red[wave][lane * 4], dot);
+  __syncthreads();
+  if (threadIdx.x < 32 && c0 + (int)threadIdx.x < c1) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sacc += red[w][threadIdx.x];
+    part[(size_t)blockIdx.x * ld + c0 + threadIdx.x] = sacc;
+  }
+}
+
+template <int GM, int CW>
+__global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_apply_blocked(const BlkArgs a) {
+  constexpr int SL = OSC_BLK_SLOTS, NT = (CW + 1) * 64;
+  __shared__ __attribute__((aligned(16))) float red[CW + 1][32];
   // per gathering wave: the slots of each of its rows in the current block, and (other half) in the next one
   __shared__ int2 stage[2][CW][GM][8 * SL];
   if (a.gate != nullptr && *a.gate <= a.gate_tol) return;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane >> 3, lr = lane & 7;
   const int32_t ld = a.ld;
-  for (int c = a.c0 + threadIdx.x; c < a.c1; c += 256) a.part[(size_t)blockIdx.x * ld + c] = 0.f;
+  for (int c = a.c0 + threadIdx.x; c < a.c1; c += NT) a.part[(size_t)blockIdx.x * ld + c] = 0.f;
   if ((int)(blockIdx.x >> 3) >= a.xs) return;
   const int xcd = (int)(blockIdx.x & 7), wgx = (int)(blockIdx.x >> 3);
   const int xgroups = a.xs_groups, xgrp = xcd % xgroups, xpart = xcd / xgroups, parts = 8 / xgroups;
@@ -367,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   auto slab_base = [&](int sc0) { return a.X + (size_t)(sc0 >> 5) * (size_t)a.N * 32; };
 
   if (wave == CW) {
-    // ---- wave 3: the edge lists ---------------------------------------------------------------------------------------
+    // ---- the last wave: the edge lists --------------------------------------------------------------------------------
     const uint32_t lslot = (uint32_t)min(lr, SL - 1) * 8u;
     // slots of gathering wave cw's rows in sub-phase p: lane (sub, lr) gets slot lr of row `sub` of each group
     auto load_slots = [&](const BlkPhase& p, int cw, int2 (&en)[GM]) {
@@ -390,18 +413,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         r += w8;
       }
     };
-    static_assert(kBlkGatherWaves == 3, "the hand-over below is written for three gathering waves");
-    auto fetch_slots = [&](int ph) {  // all three waves' slots of sub-phase ph: global -> registers -> stage[ph & 1]
+    // all gathering waves' slots of sub-phase ph: global -> registers -> stage[ph & 1], two waves' worth in flight
+    auto fetch_slots = [&](int ph) {
       const BlkPhase p = phase(ph);
       int2 ea[GM], eb[GM];
       load_slots(p, 0, ea);
-      load_slots(p, 1, eb);
-      stage_slots(ph & 1, p, 0, ea);
-      load_slots(p, 2, ea);
-      stage_slots(ph & 1, p, 1, eb);
-      stage_slots(ph & 1, p, 2, ea);
+#pragma unroll
+      for (int cw = 0; cw < CW; cw += 2) {
+        if (cw + 1 < CW) load_slots(p, cw + 1, eb);
+        stage_slots(ph & 1, p, cw, ea);
+        if (cw + 2 < CW) load_slots(p, cw + 2, ea);
+        if (cw + 1 < CW) stage_slots(ph & 1, p, cw + 1, eb);
+      }
     };
-    float4 zero[1] = {f4(0.f)};
     if (nphase > 0) fetch_slots(0);
     __syncthreads();
     for (int ph = 0; ph < nphase; ++ph) {
@@ -409,13 +433,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       __syncthreads();
       if ((ph + 1) % per_slab == 0) {
         const int sc0 = phase(ph).sc0;
-        block_fold<8, 1>(zero, red, a.part, ld, sc0, min(a.c1, sc0 + 32));
+        blk_fold<CW + 1>(f4(0.f), red, a.part, ld, sc0, min(a.c1, sc0 + 32), wave, lane);
       }
     }
     return;
   }
 
-  // ---- waves 0-2: gather (L2 hits and LDS reads) ------------------------------------------------------------------------
+  // ---- the other waves: gather (L2 hits and LDS reads) ---------------------------------------------------------------
   const uint32_t lr16 = (uint32_t)lr * 16u;
   float4 acc[GM];
   float4 dot[1] = {f4(0.f)};
@@ -505,7 +529,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     __syncthreads();
     if ((ph + 1) % per_slab == 0) {  // the slab's column sums
-      block_fold<8, 1>(dot, red, a.part, ld, p.sc0, min(a.c1, p.sc0 + 32));
+      blk_fold<CW + 1>(dot[0], red, a.part, ld, p.sc0, min(a.c1, p.sc0 + 32), wave, lane);
       dot[0] = f4(0.f);
     }
   }
@@ -991,7 +1015,7 @@ void launch_chain_fix(const ChainFixArgs& a, hipStream_t s) {
 }
 int blocked_resident_per_cu() {
   int n = 0;
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_apply_blocked<kBlkGroups>, 256, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_apply_blocked<kBlkGroups, kBlkGatherWaves>, (kBlkGatherWaves + 1) * 64, 0));
   return n;
 }
 
@@ -1000,7 +1024,7 @@ void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s) {
       a.groups > kBlkGroups || a.slices < 1 || a.nb < 1 || a.nb > OSC_MAX_SRC_BLOCKS || !a.slots || !a.rest ||
       (int64_t)a.N * a.ld * 4 >= ((int64_t)1 << 32) || (a.c0 & 31) != 0)
     throw std::runtime_error("blocked apply: unsupported arguments");
-  hipLaunchKernelGGL((k_apply_blocked<kBlkGroups>), dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((k_apply_blocked<kBlkGroups, kBlkGatherWaves>), dim3(grid), dim3((kBlkGatherWaves + 1) * 64), 0, s, a);
   HIP_CHECK(hipGetLastError());
 }
 
