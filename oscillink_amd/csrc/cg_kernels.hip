@@ -315,7 +315,6 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 // block (those move to a later block's free slots, launch_blocked_fill): results agree with k_spmm's to fp32 rounding
 // of the sums (3e-8 relative on the state).  No chain prior here (lattices with one use k_spmm).
 constexpr int kBlkGroups = 14;   // row groups per gathering wave (4 registers each for the sums)
-constexpr int kBlkPair = 1;      // groups whose gathers are in flight together (2 with 12 groups: 0.96-0.99 ms vs 0.88)
 constexpr int kBlkGatherWaves = 7;  // + the list wave: workgroups of 512 (3 + 1 with 17 groups: 0.71 instead of 0.66 ms at config 3)
 
 __device__ __forceinline__ float4 ld4_at(const float* base, uint32_t byte_off) {
@@ -377,6 +376,7 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
   const int nb = a.nb, ng = a.groups;
   const int W8 = a.xs * CW * 8;  // rows one "deal" of groups covers (8 per gathering wave of the XCD)
   const int slice_rows = W8 * ng;
+  const int rpb = (a.N + nb - 1) / nb;  // rows per source block (launch_blocked_fill)
   const int nslab = a.c1 - a.c0 > xgrp * 32 ? ((a.c1 - a.c0 - xgrp * 32 + xgroups * 32 - 1) / (xgroups * 32)) : 0;
   const int per_slab = a.slices * nb, nphase = nslab * per_slab;
   auto phase = [&](int ph) {
@@ -408,22 +408,23 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
       int r = rlo + p.slice * slice_rows + ((wgx * CW + cw) << 3) + sub;
 #pragma unroll
       for (int g = 0; g < GM; ++g) {
-        if (g >= ng || r >= rhi) en[g].x = -1;  // groups / rows the wave does not have in this slice: no edges
+        if (g >= ng || r >= rhi) en[g] = make_int2(min(a.N - 1, p.b * rpb), 0);  // not this wave's: "unused" (see the gathers)
         if (lr < SL) stage[half][cw][g][sub * SL + lr] = en[g];
         r += w8;
       }
     };
-    // all gathering waves' slots of sub-phase ph: global -> registers -> stage[ph & 1], two waves' worth in flight
+    // all gathering waves' slots of sub-phase ph: global -> registers -> stage[ph & 1], NBUF waves' worth in flight (these
+    // loads always miss: the more of them are outstanding, the sooner the gathering waves can go on)
+    constexpr int NBUF = 3;
     auto fetch_slots = [&](int ph) {
       const BlkPhase p = phase(ph);
-      int2 ea[GM], eb[GM];
-      load_slots(p, 0, ea);
+      int2 e[NBUF][GM];
 #pragma unroll
-      for (int cw = 0; cw < CW; cw += 2) {
-        if (cw + 1 < CW) load_slots(p, cw + 1, eb);
-        stage_slots(ph & 1, p, cw, ea);
-        if (cw + 2 < CW) load_slots(p, cw + 2, ea);
-        if (cw + 1 < CW) stage_slots(ph & 1, p, cw + 1, eb);
+      for (int cw = 0; cw < NBUF && cw < CW; ++cw) load_slots(p, cw, e[cw]);
+#pragma unroll
+      for (int cw = 0; cw < CW; ++cw) {
+        stage_slots(ph & 1, p, cw, e[cw % NBUF]);
+        if (cw + NBUF < CW) load_slots(p, cw + NBUF, e[cw % NBUF]);
       }
     };
     if (nphase > 0) fetch_slots(0);
@@ -453,31 +454,21 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
       for (int g = 0; g < GM; ++g) acc[g] = f4(0.f);
     }
     const int2(*st)[8 * SL] = stage[ph & 1][wave];
+    // One group per round: all slots of its 8 rows in flight together.  No tests in here: an unused slot holds {first row of
+    // the block, 0.0f} (k_blk_fill, stage_slots), i.e. a gather of a line everybody has and a product with zero -- the
+    // round is bound by instruction issue (four waves share a SIMD), and a compare + exec-mask + branch per slot cost
+    // more than the fifth of the gathers they saved.
 #pragma unroll
-    for (int g0 = 0; g0 < GM; g0 += kBlkPair) {  // kBlkPair groups at a time: all slots of their rows in flight together
-      if (g0 >= ng) continue;
-      float4 v[kBlkPair][SL];
-      float wv[kBlkPair][SL];
+    for (int g = 0; g < GM; ++g) {
+      if (g >= ng) continue;
+      int2 e[SL];
+      float4 v[SL];
 #pragma unroll
-      for (int i = 0; i < kBlkPair; ++i) {
+      for (int u = 0; u < SL; ++u) e[u] = st[g][sub * SL + u];
 #pragma unroll
-        for (int u = 0; u < SL; ++u) {
-          v[i][u] = f4(0.f);
-          wv[i][u] = 0.f;
-          if (g0 + i < GM) {
-            const int2 e = st[g0 + i][sub * SL + u];
-            if (e.x >= 0) {
-              wv[i][u] = __int_as_float(e.y);
-              if (cok) v[i][u] = ld4_at(xbase, (uint32_t)e.x * 128u + lr16);
-            }
-          }
-        }
-      }
+      for (int u = 0; u < SL; ++u) v[u] = ld4_at(xbase, (uint32_t)e[u].x * 128u + lr16);
 #pragma unroll
-      for (int i = 0; i < kBlkPair; ++i)
-#pragma unroll
-        for (int u = 0; u < SL; ++u)
-          if (g0 + i < GM) acc[g0 + i] = fma4(wv[i][u], v[i][u], acc[g0 + i]);
+      for (int u = 0; u < SL; ++u) acc[g] = fma4(__int_as_float(e[u].y), v[u], acc[g]);
     }
     if (p.b == nb - 1) {  // the rows of this slice are complete: the rest of long lists, diagonal term, output, p.Ap
       const int w8 = opaque(W8);
@@ -593,7 +584,7 @@ __global__ void k_blk_count(const int32_t* col, const int32_t* deg, int32_t widt
   if (over) atomicAdd(over_count, (unsigned)over);
 }
 
-// *over_count must be zero on entry (it hands out the ranges of `over`); slots must be pre-filled with {-1, x}
+// *over_count must be zero on entry (it hands out the ranges of `over`); every slot is written
 __global__ void k_blk_fill(const int32_t* col, const float* w, const int32_t* deg, int32_t width, int32_t N, int32_t nb,
                            int32_t rpb, int2* slots, int2* rest, int2* over, unsigned* over_count) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
@@ -634,6 +625,12 @@ __global__ void k_blk_fill(const int32_t* col, const float* w, const int32_t* de
     if (tb >= 0) slots[((size_t)tb * N + row) * OSC_BLK_SLOTS + ts] = ent;
     else over[at++] = ent;
   }
+  // unused slots: a row every wave gathering from block q has in its caches anyway, weight zero
+#pragma unroll
+  for (int q = 0; q < OSC_MAX_SRC_BLOCKS; ++q)
+    if (q < nb)
+      for (int t = tail[q]; t < OSC_BLK_SLOTS; ++t)
+        slots[((size_t)q * N + row) * OSC_BLK_SLOTS + t] = make_int2(min(N - 1, q * rpb), 0);
 }
 
 // ---- initial residual around the blocked matvec (InitFinishArgs) ---------------------------------------------------

@@ -91,7 +91,8 @@ struct GraphView {
 
 // The lattice graph a second time, split by SOURCE-row block (k_spmm_blocked): block b holds the edges whose neighbour row
 // lies in [b * rows_per_block, (b + 1) * rows_per_block), rows_per_block = ceil(N / nb).  Fixed-width: every (block, row)
-// owns OSC_BLK_SLOTS slots {neighbour row, bits of W_ij}, filled in the order of the ELL row, unused slots {-1, x}; an
+// owns OSC_BLK_SLOTS slots {neighbour row, bits of W_ij}, filled in the order of the ELL row, unused slots {first row of
+// the block, 0.0f} (gathered and multiplied by zero: no tests in the gather loop); an
 // edge that finds the slot row of its block full sits in a later block's free slots instead (k_blk_fill), and what fits
 // nowhere is in over[rest[row].x .. + rest[row].y), added after the blocks (so such rows' sums are formed in a different
 // order than k_spmm's: same terms, last-bit differences).

@@ -1005,7 +1005,6 @@ BlockedView blocked_view(L& h, int nb) {
     h.blk_slots.alloc((size_t)nb * h.N * OSC_BLK_SLOTS);
     h.blk_over.alloc((size_t)over + 1);
     h.blk_rest.alloc((size_t)h.N);
-    HIP_CHECK(hipMemsetAsync(h.blk_slots.p, 0xFF, h.blk_slots.n * sizeof(int2), h.stream));  // {-1, NaN bits}: unused
     HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4, h.stream));
     launch_blocked_fill(h.ell_col.p, h.ell_w.p, h.deg.p, h.width, (int32_t)h.N, nb, h.blk_slots.p, h.blk_rest.p, h.blk_over.p, cnt.p,
                         h.stream);
