@@ -305,9 +305,9 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 //     sequence from the same start, so what they gather from at any time is a few neighbouring blocks rather than the
 //     whole slab (L2 hits 25 -> 49 M, misses 58 -> 33 M per launch at config 3);
 //   * loads of one wave complete in issue order, so a miss in a gathering wave's stream holds up every L2 hit behind it.
-//     Hence two roles per workgroup: waves 0-6 gather (LDS reads and slab rows only), wave 7 reads the next block's edge
-//     lists (block-major copy of the graph, BlockedView: always misses) into registers while the others gather and
-//     writes them to the other half of an LDS staging area; one workgroup barrier per block.
+//     Hence two roles per workgroup: waves 0-6 gather (LDS reads and slab rows only), wave 7 copies the next block's edge
+//     lists (block-major copy of the graph, BlockedView: always misses) into the other half of an LDS staging area by
+//     LDS-DMA while the others gather; one workgroup barrier per block.
 // What was tried on top and did not pay (scripts/exp/blocked_apply/README.md): pulling the next block into the L2 with
 // dword-per-line loads, gated or not by a progress counter in the XCD's L2 (no change: 877-890 us either way), and
 // holding leaders back at that counter (stragglers fall out of the resident set and get later still: 1.8-2.3 ms).
@@ -363,7 +363,7 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
   constexpr int SL = OSC_BLK_SLOTS, NT = (CW + 1) * 64;
   __shared__ __attribute__((aligned(16))) float red[CW + 1][32];
   // per gathering wave: the slots of each of its rows in the current block, and (other half) in the next one
-  __shared__ int2 stage[2][CW][GM][8 * SL];
+  __shared__ __attribute__((aligned(16))) int2 stage[2][GM][CW][8 * SL];
   if (a.gate != nullptr && *a.gate <= a.gate_tol) return;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane >> 3, lr = lane & 7;
@@ -391,41 +391,38 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
 
   if (wave == CW) {
     // ---- the last wave: the edge lists --------------------------------------------------------------------------------
-    const uint32_t lslot = (uint32_t)min(lr, SL - 1) * 8u;
-    // slots of gathering wave cw's rows in sub-phase p: lane (sub, lr) gets slot lr of row `sub` of each group
-    auto load_slots = [&](const BlkPhase& p, int cw, int2 (&en)[GM]) {
-      const int2* sb = a.slots + (size_t)p.b * (size_t)a.N * SL;
-      const int w8 = opaque(W8);
-      int r = rlo + p.slice * slice_rows + ((wgx * CW + cw) << 3) + sub;
-#pragma unroll
-      for (int g = 0; g < GM; ++g) {
-        en[g] = ld2_at(sb, (uint32_t)min(r, rhi - 1) * (8u * SL) + lslot);
-        r += w8;
-      }
-    };
-    auto stage_slots = [&](int half, const BlkPhase& p, int cw, int2 (&en)[GM]) {
-      const int w8 = opaque(W8);
-      int r = rlo + p.slice * slice_rows + ((wgx * CW + cw) << 3) + sub;
-#pragma unroll
-      for (int g = 0; g < GM; ++g) {
-        if (g >= ng || r >= rhi) en[g] = make_int2(min(a.N - 1, p.b * rpb), 0);  // not this wave's: "unused" (see the gathers)
-        if (lr < SL) stage[half][cw][g][sub * SL + lr] = en[g];
-        r += w8;
-      }
-    };
-    // all gathering waves' slots of sub-phase ph: global -> registers -> stage[ph & 1], NBUF waves' worth in flight (these
-    // loads always miss: the more of them are outstanding, the sooner the gathering waves can go on)
-    constexpr int NBUF = 3;
+    // For a fixed group index g the slot rows of the workgroup's CW gathering waves are 8 * CW consecutive lattice rows, i.e.
+    // one contiguous piece of the block-major copy (and of the staging area, laid out [g][wave][row][slot]): it is copied
+    // global -> LDS by LDS-DMA loads of 1 KB per instruction, no registers in between, ALL pieces of a sub-phase in flight
+    // together (the loads always miss; under the gathers' traffic every dependent round trip costs several microseconds).
+    // Rows past the slice / lattice end copy whatever follows in the array (other rows' valid slots, or the zeroed
+    // padding behind the last block: blocked_view): their sums are never stored.
+    constexpr int GROUP_BYTES = CW * 8 * SL * 8, PIECES = (GROUP_BYTES + 1023) / 1024;
+    static_assert(GM * PIECES <= 60, "outstanding vector-memory operations of one wave");
+    const unsigned stage_lds = (unsigned)(size_t)&stage[0][0][0][0];
     auto fetch_slots = [&](int ph) {
       const BlkPhase p = phase(ph);
-      int2 e[NBUF][GM];
+      const char* sb = reinterpret_cast<const char*>(a.slots + (size_t)p.b * (size_t)a.N * SL);
+      const int row0 = rlo + p.slice * slice_rows + ((wgx * CW) << 3);
+      const int w8 = opaque(W8);
 #pragma unroll
-      for (int cw = 0; cw < NBUF && cw < CW; ++cw) load_slots(p, cw, e[cw]);
+      for (int g = 0; g < GM; ++g) {
+        if (g >= ng) continue;
+        const char* src = sb + (size_t)(uint32_t)(row0 + g * w8) * (8u * SL);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(stage_lds + (unsigned)(((ph & 1) * GM + g) * GROUP_BYTES));
 #pragma unroll
-      for (int cw = 0; cw < CW; ++cw) {
-        stage_slots(ph & 1, p, cw, e[cw % NBUF]);
-        if (cw + NBUF < CW) load_slots(p, cw + NBUF, e[cw % NBUF]);
+        for (int q = 0; q < PIECES; ++q) {
+          if (q * 1024 + lane * 16 < GROUP_BYTES) {
+            const char* lsrc = src + lane * 16;  // (the instruction's offset advances the global AND the LDS address)
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(lsrc), "s"(dst), "n"(q * 1024)
+                         : "memory");
+          }
+        }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     if (nphase > 0) fetch_slots(0);
     __syncthreads();
@@ -453,7 +450,7 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
       for (int g = 0; g < GM; ++g) acc[g] = f4(0.f);
     }
-    const int2(*st)[8 * SL] = stage[ph & 1][wave];
+    const int2(*st)[CW][8 * SL] = stage[ph & 1];
     // One group per round: all slots of its 8 rows in flight together.  No tests in here: an unused slot holds {first row of
     // the block, 0.0f} (k_blk_fill, stage_slots), i.e. a gather of a line everybody has and a product with zero -- the
     // round is bound by instruction issue (four waves share a SIMD), and a compare + exec-mask + branch per slot cost
@@ -464,7 +461,7 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
       int2 e[SL];
       float4 v[SL];
 #pragma unroll
-      for (int u = 0; u < SL; ++u) e[u] = st[g][sub * SL + u];
+      for (int u = 0; u < SL; ++u) e[u] = st[g][wave][sub * SL + u];
 #pragma unroll
       for (int u = 0; u < SL; ++u) v[u] = ld4_at(xbase, (uint32_t)e[u].x * 128u + lr16);
 #pragma unroll

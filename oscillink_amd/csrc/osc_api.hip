@@ -1002,7 +1002,9 @@ BlockedView blocked_view(L& h, int nb) {
     unsigned over = 0;
     HIP_CHECK(hipMemcpyAsync(&over, cnt.p, 4, hipMemcpyDeviceToHost, h.stream));
     sync(h);
-    h.blk_slots.alloc((size_t)nb * h.N * OSC_BLK_SLOTS);
+    const size_t nslots = (size_t)nb * h.N * OSC_BLK_SLOTS, npad = (size_t)8192 * OSC_BLK_SLOTS;  // the apply's list copies run up to a deal of rows past the end
+    h.blk_slots.alloc(nslots + npad);
+    HIP_CHECK(hipMemsetAsync(h.blk_slots.p + nslots, 0, npad * sizeof(int2), h.stream));  // {row 0, 0.0f}
     h.blk_over.alloc((size_t)over + 1);
     h.blk_rest.alloc((size_t)h.N);
     HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4, h.stream));
