@@ -339,3 +339,62 @@ def test_sharded_panel_prefilter_build_on_loopback_ranks(amd, world, monkeypatch
     for route, (rp, col, a, w, sd) in _ranks(world, rank_fn):
         assert route == 2
         assert np.array_equal(rp, want[0]) and np.array_equal(col, want[1]) and np.array_equal(a, want[2])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_column_sharded_solves_with_the_blocked_matvec(amd, world, monkeypatch):
+    """The source-blocked CG matvec inside a column-sharded solve: forced onto a fixture (per-rank windows of 64 / 32
+    columns at an offset, chain-free and with the chain fix-up launch), every rank still reproduces the fixture and all
+    ranks leave with the same state bit for bit."""
+    monkeypatch.delenv("OSC_SHARD", raising=False)
+    monkeypatch.setenv("OSC_SPMM_XS", "1")
+    monkeypatch.setenv("OSC_SPMM_BLOCKED", "3")
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    for name in ("c2_n1200_d128_k16", "g1_n400_d64_k6_chain8"):
+        case = load_case(name)
+        rc = case["recipe"]
+        if rc["D"] // world % 32 != 0:
+            continue  # the slab-major search direction needs 32-column-aligned windows (else the plain path runs)
+        Y, psi = make_inputs(rc)
+        csr = (case["indptr"].astype(np.int64), case["indices"].astype(np.int32), case["A_data"].astype(np.float32))
+
+        def rank_fn(rank, comm):
+            lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], comm=comm, _build_graph=False)
+            lat.set_graph_csr(*csr)
+            _configure(lat, case, rc, psi)
+            out = _solve_and_collect(lat, rc)
+            out["blocks"] = lat.build_info()["apply_src_blocks"]
+            return out
+
+        out = _ranks(world, rank_fn)
+        assert all(o["blocks"] == 3 for o in out), [o["blocks"] for o in out]
+        _assert_matches_fixture(out, case, rc, world, 0)
+
+
+def test_column_sharded_config_sized_lattice_takes_the_blocked_matvec(amd, monkeypatch):
+    """N = 40000, D = 256 on two loopback ranks (128 columns each): the automatic choice (slab 4.9 MiB) runs the blocked
+    matvec on both ranks; state and iteration count equal the single-rank plain solve."""
+    monkeypatch.delenv("OSC_SHARD", raising=False)
+    monkeypatch.delenv("OSC_SPMM_XS", raising=False)
+    monkeypatch.delenv("OSC_SPMM_BLOCKED", raising=False)
+    rng = np.random.default_rng(3)
+    N, D, k = 40000, 256, 16
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    gates = rng.uniform(0.2, 1.0, size=N).astype(np.float32)
+
+    def rank_fn(rank, comm):
+        lat = amd.Oscillink(Y, kneighbors=k, comm=comm)
+        lat.set_query(psi, gates=gates)
+        st = dict(lat.settle(max_iters=12, tol=1e-4))
+        return st, lat.U.copy(), lat.build_info()["apply_src_blocks"]
+
+    out = _ranks(2, rank_fn)
+    monkeypatch.setenv("OSC_SPMM_BLOCKED", "0")
+    one = amd.Oscillink(Y, kneighbors=k)
+    one.set_query(psi, gates=gates)
+    s1 = one.settle(max_iters=12, tol=1e-4)
+    assert one.build_info()["apply_src_blocks"] == 0
+    for st, U, blocks in out:
+        assert blocks >= 2 and st["iters"] == s1["iters"] and relerr(U, one.U) < 2e-6
+    assert np.array_equal(out[0][1], out[1][1])
