@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 // Same terms per row as k_spmm; the order of summation differs where a row has more than OSC_BLK_SLOTS edges into one
 // block (those move to a later block's free slots, launch_blocked_fill): results agree with k_spmm's to fp32 rounding
 // of the sums (3e-8 relative on the state).  No chain prior here (lattices with one use k_spmm).
-constexpr int kBlkGroups = 14;   // row groups per gathering wave (4 registers each for the sums)
+constexpr int kBlkGroups = 16;   // row groups per gathering wave (4 registers each for the sums)
 constexpr int kBlkGatherWaves = 7;  // + the list wave: workgroups of 512 (3 + 1 with 17 groups: 0.71 instead of 0.66 ms at config 3)
 
 __device__ __forceinline__ float4 ld4_at(const float* base, uint32_t byte_off) {
@@ -395,8 +395,9 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
     // one contiguous piece of the block-major copy (and of the staging area, laid out [g][wave][row][slot]): it is copied
     // global -> LDS by LDS-DMA loads of 1 KB per instruction, no registers in between, ALL pieces of a sub-phase in flight
     // together (the loads always miss; under the gathers' traffic every dependent round trip costs several microseconds).
-    // Rows past the slice / lattice end copy whatever follows in the array (other rows' valid slots, or the zeroed
-    // padding behind the last block: blocked_view): their sums are never stored.
+    // A group that starts inside the lattice but runs past its end (or past the slice) copies whatever follows in the
+    // array -- other rows' valid slots, or the zeroed padding behind the last block (blocked_view: >= 8 * CW rows) -- and
+    // the sums of such rows are never stored; a group that starts past the end is skipped here AND by the gathering waves.
     constexpr int GROUP_BYTES = CW * 8 * SL * 8, PIECES = (GROUP_BYTES + 1023) / 1024;
     static_assert(GM * PIECES <= 60, "outstanding vector-memory operations of one wave");
     const unsigned stage_lds = (unsigned)(size_t)&stage[0][0][0][0];
@@ -407,7 +408,7 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
       const int w8 = opaque(W8);
 #pragma unroll
       for (int g = 0; g < GM; ++g) {
-        if (g >= ng) continue;
+        if (g >= ng || row0 + g * w8 >= a.N) continue;  // (a group that starts past the lattice: nobody reads its area)
         const char* src = sb + (size_t)(uint32_t)(row0 + g * w8) * (8u * SL);
         const unsigned dst = __builtin_amdgcn_readfirstlane(stage_lds + (unsigned)(((ph & 1) * GM + g) * GROUP_BYTES));
 #pragma unroll
@@ -455,9 +456,10 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
     // the block, 0.0f} (k_blk_fill, stage_slots), i.e. a gather of a line everybody has and a product with zero -- the
     // round is bound by instruction issue (four waves share a SIMD), and a compare + exec-mask + branch per slot cost
     // more than the fifth of the gathers they saved.
+    const int wg_row0 = rlo + p.slice * slice_rows + ((wgx * CW) << 3);  // first row of this workgroup's group 0
 #pragma unroll
     for (int g = 0; g < GM; ++g) {
-      if (g >= ng) continue;
+      if (g >= ng || wg_row0 + g * W8 >= a.N) continue;  // (same test as the list wave's: that area was not staged)
       int2 e[SL];
       float4 v[SL];
 #pragma unroll

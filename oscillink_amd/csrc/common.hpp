@@ -97,7 +97,7 @@ struct GraphView {
 // nowhere is in over[rest[row].x .. + rest[row].y), added after the blocks (so such rows' sums are formed in a different
 // order than k_spmm's: same terms, last-bit differences).
 constexpr int OSC_MAX_SRC_BLOCKS = 16;
-constexpr int OSC_BLK_SLOTS = 6;
+constexpr int OSC_BLK_SLOTS = 4;
 struct BlockedView {
   const int2* slots;    // [nb][N][OSC_BLK_SLOTS]
   const int2* rest;     // [N] {first, count} into over

@@ -227,7 +227,7 @@ struct osc_lattice {
   int blk_nb = 0;          // blocks of the copy held (0 = none / stale)
   int spmm_blocked = -1;   // -1 by lattice size, 0 off, > 0 = that many source blocks (OSC_SPMM_BLOCKED)
   double blk_mb = 4.0;     // smallest slab (N x 128 B, MiB) the blocked apply is chosen for (OSC_BLK_MB)
-  double blk_edges = 5.2;  // edges of a row per source block the block count aims at (OSC_BLK_EDGES)
+  double blk_edges = 3.3;  // edges of a row per source block the block count aims at (OSC_BLK_EDGES)
   int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
   int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
   bool blk_init = true;    // the initial residual goes through the blocked matvec as well (OSC_BLK_INIT=0: plain INIT apply)

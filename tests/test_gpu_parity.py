@@ -1088,3 +1088,26 @@ def test_source_blocked_apply_against_the_plain_one(amd, orc, monkeypatch):
     ref = oracle_solves(orc, Y, psi, A, k=k, gates=gates, settle_iters=out["3"][0], settle_tol=1e-4, ustar_iters=8)
     assert stop_iteration(ref["hist_settle"], 1e-4) == out["3"][0]
     assert relerr(out["3"][2], ref["U"]) < 1e-5
+
+
+def test_source_blocked_apply_when_the_last_slice_runs_far_past_the_lattice(amd, monkeypatch):
+    """N = 130000 takes three destination slices whose capacity exceeds N by several thousand rows: row groups that start
+    past the lattice must be skipped by the list copy and by the gathers alike (an earlier version read the block-major
+    copy out of bounds there).  Also N just below / above multiples of the per-slice capacity."""
+    monkeypatch.delenv("OSC_SPMM_XS", raising=False)
+    monkeypatch.delenv("OSC_REORDER", raising=False)
+    rng = np.random.default_rng(99)
+    for N in (130000, 57345, 114700):
+        D, k = 128, 8
+        Y = rng.standard_normal((N, D)).astype(np.float32)
+        psi = rng.standard_normal(D).astype(np.float32)
+        res = {}
+        for mode in ("0", "-1"):
+            monkeypatch.setenv("OSC_SPMM_BLOCKED", mode)
+            lat = amd.Oscillink(Y, kneighbors=k)
+            lat.set_query(psi)
+            st = lat.settle(max_iters=12, tol=1e-4)
+            res[mode] = (st["iters"], lat.U.copy(), lat.build_info()["apply_src_blocks"])
+            lat.close()
+        assert res["0"][2] == 0 and res["-1"][2] >= 2
+        assert res["0"][0] == res["-1"][0] and relerr(res["-1"][1], res["0"][1]) < 1e-6
