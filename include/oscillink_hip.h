@@ -89,8 +89,8 @@ int osc_order_info(osc_handle h, int32_t* reordered, double* clustering);
 int osc_spmm_plan(osc_handle h, int32_t* launches, int32_t* slab_cols, int32_t* xs_workgroups);
 
 /* the CG matvec of the last general-path solve: src_blocks = 0 for the plain apply, else the number of source-row blocks
- * the blocked apply walked (chosen when the 32-column slab an XCD gathers from, N x 128 B, is at least OSC_BLK_MB = 4
- * MiB, i.e. does not fit its L2, and the lattice has no chain prior; the block count follows the mean degree;
+ * the blocked apply walked (chosen when the 32-column slab an XCD gathers from, N x 128 B, is at least OSC_BLK_MB = 2
+ * MiB; a chain prior of up to 4096 path rows is applied by a small launch behind it; the block count follows the mean degree;
  * OSC_SPMM_BLOCKED = 0 off / n forces n blocks); blocked_applies = such matvecs enqueued since creation (measurement
  * aid) */
 int osc_apply_info(osc_handle h, int32_t* src_blocks, int64_t* blocked_applies);

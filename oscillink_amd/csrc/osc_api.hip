@@ -226,7 +226,7 @@ struct osc_lattice {
   DevBuf<int2> blk_slots, blk_rest, blk_over;
   int blk_nb = 0;          // blocks of the copy held (0 = none / stale)
   int spmm_blocked = -1;   // -1 by lattice size, 0 off, > 0 = that many source blocks (OSC_SPMM_BLOCKED)
-  double blk_mb = 4.0;     // smallest slab (N x 128 B, MiB) the blocked apply is chosen for (OSC_BLK_MB)
+  double blk_mb = 2.0;     // smallest slab (N x 128 B, MiB) the blocked apply is chosen for (OSC_BLK_MB)
   double blk_edges = 3.3;  // edges of a row per source block the block count aims at (OSC_BLK_EDGES)
   int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
   int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
@@ -978,16 +978,16 @@ int blocked_plan(const L& h, bool with_path) {
       (int64_t)h.N * h.ld * 4 >= ((int64_t)1 << 32))
     return 0;
   if (h.spmm_blocked > 0) return std::min(h.spmm_blocked, OSC_MAX_SRC_BLOCKS);
-  // as many blocks as give a row ~5.2 edges into each (6 slots per (row, block); an edge that finds its block's slot row
-  // full moves to a later block's, so the rows should be nearly but not quite full; measured at N = 100k, D = 768:
-  // k = 16 / 32 / 48 are best with 3 / 6 / 8 blocks: 0.21 / 0.71 / 0.95 ms against 0.28 / 0.98 / 1.50 for the plain apply)
+  // as many blocks as give a row ~3.3 edges into each (4 slots per (row, block); an edge that finds its block's slot row
+  // full moves to a later block's, so the rows should be nearly but not quite full; measured at N = 100k, D = 768, k = 32:
+  // 4 slots x 9 blocks 0.59 ms, 5 x 7 0.60, 6 x 6 0.61)
   const double mean_deg = h.N > 0 ? (double)h.nnz / (double)h.N : 0.0;
   const int nb = (int)std::min<double>(OSC_MAX_SRC_BLOCKS, std::max(2.0, std::floor(mean_deg / h.blk_edges + 0.5)));
   if (h.spmm_blocked == -2) return nb;  // "whenever possible" (experiments)
-  // ... and only where it pays: when the slab an XCD gathers from (N x 128 B) does not fit its 4 MB L2.  Measured against
-  // the plain apply (k = 32 unless noted): N = 20k x 768 +10 %; 35k x 768 -13 %, 40k x 256 (k 8) -8 %, 50k x 512 -16 %,
-  // 65k x 256 (k 16) -18 %, 80k x 768 -22 %, 100k x 768 -28 % (k 16: -24 %, k 48: -37 %, k 64: -33 %), 110k x 768 -15 %
-  // (three destination slices instead of two), 130k x 256 -30 %.
+  // ... and wherever the XCD-affine slab mode itself runs from a 2 MiB slab (N = 16384) on.  Measured against the plain
+  // apply (k = 32 unless noted): N = 20k x 768 -7 %, 35k x 768 -26 %, 40k x 256 (k 8) -25 %, 50k x 512 -30 %, 65k x 256
+  // (k 16) -30 %, 60k x 1024 (k 24) -29 %, 80k x 768 -39 %, 100k x 768 -39 % (k 16, D 384: -33 %; k 48: -47 %; k 64:
+  // -45 %), 100k x 128 (k 16) -35 %, 110k x 768 -40 %, 130k x 256 -43 %.
   const double slab = (double)h.N * 128.0;
   if (slab < h.blk_mb * 1024.0 * 1024.0) return 0;
   return nb;
