@@ -1111,3 +1111,54 @@ def test_source_blocked_apply_when_the_last_slice_runs_far_past_the_lattice(amd,
             lat.close()
         assert res["0"][2] == 0 and res["-1"][2] >= 2
         assert res["0"][0] == res["-1"][0] and relerr(res["-1"][1], res["0"][1]) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["hub", "powerlaw", "banded", "empty_rows"])
+def test_source_blocked_apply_on_injected_degenerate_graphs(amd, kind, monkeypatch):
+    """Graphs the kNN build never produces, injected as CSR and pushed through the blocked matvec with 2, 7 and 16 source
+    blocks: a hub row that neighbours 120 others (far more edges into one block than a slot row holds: the overflow
+    lists), power-law degrees, a banded graph (every edge inside the row's own block), and a graph where most rows
+    have no edge at all.  State and iteration count must equal the plain apply's."""
+    import scipy.sparse as sp
+
+    monkeypatch.setenv("OSC_SPMM_XS", "1")
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    rng = np.random.default_rng(1234)
+    N, D = 6000, 64
+    if kind == "hub":
+        rows = np.concatenate([np.full(120, 17), rng.integers(0, N, 4000)])
+        cols = np.concatenate([rng.choice(np.setdiff1d(np.arange(N), [17]), 120, replace=False), rng.integers(0, N, 4000)])
+    elif kind == "powerlaw":
+        deg = np.minimum(100, (rng.pareto(1.2, N) + 1).astype(int))
+        rows = np.repeat(np.arange(N), deg)
+        cols = rng.integers(0, N, rows.size)
+    elif kind == "banded":
+        rows = np.repeat(np.arange(N), 6)
+        cols = np.clip(rows + np.tile([-3, -2, -1, 1, 2, 3], N), 0, N - 1)
+    else:
+        rows = rng.integers(0, 300, 2000)
+        cols = rng.integers(0, N, 2000)
+    keep = rows != cols
+    A = sp.coo_matrix((rng.uniform(0.05, 1.0, keep.sum()).astype(np.float32), (rows[keep], cols[keep])), shape=(N, N)).tocsr()
+    A = A.maximum(A.T).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    if A.getnnz(axis=1).max() > 128:
+        pytest.skip("row wider than the ELL limit of the injection path")
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    gates = rng.uniform(0.1, 1.0, N).astype(np.float32)
+    out = {}
+    for mode in ("0", "2", "7", "16"):
+        monkeypatch.setenv("OSC_SPMM_BLOCKED", mode)
+        lat = amd.Oscillink(Y, kneighbors=6, _build_graph=False)
+        lat.set_graph_csr(A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float32))
+        lat.set_query(psi, gates=gates)
+        st = lat.settle(max_iters=16, tol=1e-5)
+        Us = lat.solve_Ustar()
+        assert lat.build_info()["apply_src_blocks"] == int(mode)
+        out[mode] = (st["iters"], lat.U.copy(), Us.copy())
+        lat.close()
+    for mode in ("2", "7", "16"):
+        assert out[mode][0] == out["0"][0], (kind, mode)
+        assert relerr(out[mode][1], out["0"][1]) < 1e-6 and relerr(out[mode][2], out["0"][2]) < 1e-6, (kind, mode)
