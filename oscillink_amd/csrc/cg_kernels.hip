@@ -293,17 +293,16 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Operator apply, source-blocked (CG matvec on unstructured lattices whose 32-column slab, N x 128 B, is several times
-// an XCD's 4 MB L2).  Measured (scripts/exp/gather_bench.hip, profiles/r02_gather_bench.txt): a CU completes a random
+// Operator apply, source-blocked (the CG matvec wherever the XCD-affine slab mode runs: blocked_plan in osc_api.hip).  Measured (scripts/exp/gather_bench.hip, profiles/r02_gather_bench.txt): a CU completes a random
 // 128-byte row gather every 2.4 clk when the rows come from <= 3.6 MB per XCD, every 7.0 clk from a 12.8 MB slab -- the
 // request rate, not the bytes, is what the plain apply pays for.  Here the neighbour rows are visited block by block:
-//   * source rows are cut into nb blocks, nb such that a row has ~4 edges into each (blocked_plan in osc_api.hip);
+//   * source rows are cut into nb blocks, nb such that a row has ~3.3 edges into each (4 slots per row and block);
 //   * every gathering wave owns a fixed set of row groups (8 rows each, dealt round-robin) per slice of the destination
 //     rows and runs  for block b: for my groups: gather the edges that point into b,  the per-row sums staying in
 //     registers across the blocks (no partial results through memory); the destination rows are cut into slices so that
 //     the rows in flight on an XCD fit its waves' registers.  All waves of an XCD walk the same (slab, slice, block)
 //     sequence from the same start, so what they gather from at any time is a few neighbouring blocks rather than the
-//     whole slab (L2 hits 25 -> 49 M, misses 58 -> 33 M per launch at config 3);
+//     whole slab (L2 hits 25 -> 56 M, misses 58 -> 26 M per launch at config 3);
 //   * loads of one wave complete in issue order, so a miss in a gathering wave's stream holds up every L2 hit behind it.
 //     Hence two roles per workgroup: waves 0-6 gather (LDS reads and slab rows only), wave 7 copies the next block's edge
 //     lists (block-major copy of the graph, BlockedView: always misses) into the other half of an LDS staging area by
@@ -313,7 +312,7 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
 // holding leaders back at that counter (stragglers fall out of the resident set and get later still: 1.8-2.3 ms).
 // Same terms per row as k_spmm; the order of summation differs where a row has more than OSC_BLK_SLOTS edges into one
 // block (those move to a later block's free slots, launch_blocked_fill): results agree with k_spmm's to fp32 rounding
-// of the sums (3e-8 relative on the state).  No chain prior here (lattices with one use k_spmm).
+// of the sums (3e-8 relative on the state).  The chain prior's few rows are applied by k_chain_fix behind this kernel.
 constexpr int kBlkGroups = 16;   // row groups per gathering wave (4 registers each for the sums)
 constexpr int kBlkGatherWaves = 7;  // + the list wave: workgroups of 512 (3 + 1 with 17 groups: 0.71 instead of 0.66 ms at config 3)
 
