@@ -2,7 +2,7 @@
 """Differential soak of the source-blocked CG matvec (csrc/cg_kernels.hip: k_apply_blocked) against the plain apply on
 shapes the test suite does not cover: N 17k-130k (ragged), D 96-1024 in steps of 4 (partial last slab, 1 / 2 / 4 / 8 slab
 groups), k 4-48, i.i.d. and clustered anchors (many edges into one block: the epilogue list), random gates, 1-16 source
-blocks forced, the automatic choice, and a settle + U* solve per case.  Iteration counts must agree; states to 2e-6."""
+blocks forced, the automatic choice, every third case with a chain prior, and a settle + U* solve per case.  Iteration counts must agree; states to 2e-6."""
 import os
 import sys
 
@@ -45,6 +45,8 @@ for t in range(count):
         os.environ["OSC_SPMM_XS"] = "1"  # the slab apply both build on, whatever the size
         lat = amd.Oscillink(Y, kneighbors=k)
         lat.set_query(psi, gates=gates)
+        if t % 3 == 2:  # a chain prior: the fix-up launch behind every blocked apply
+            lat.add_chain([int(v) for v in np.random.default_rng(t).integers(0, N, 12)], lamP=0.3)
         st = lat.settle(max_iters=12, tol=1e-4)
         U = lat.U.copy()
         Us = lat.solve_Ustar()
