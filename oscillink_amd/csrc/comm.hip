@@ -79,7 +79,7 @@ struct LoopGroup {
   uint64_t generation = 0;
   bool broken = false;
   int joined = 0;
-  double timeout_s = 60.0;
+  double timeout_s = 300.0;  // a rank may build a large lattice (N ~ 1M: seconds) before its first collective
   struct Slot {
     void* ptr = nullptr;
     const std::vector<CommXfer>* list = nullptr;
@@ -134,12 +134,16 @@ class LoopbackComm final : public Comm {
       if (const char* e = getenv("OSC_LOOPBACK_TIMEOUT_S")) g_->timeout_s = std::max(1.0, atof(e));
       g_loop_groups[key] = g_;
     }
+    // (a constructor that throws never runs the destructor: check before counting this rank in)
     if (g_->world != world) throw CommError("loopback: ranks of one group disagree on the world size");
-    if (++g_->joined > world) throw CommError("loopback: more ranks joined than the world size");
+    if (g_->joined >= world) throw CommError("loopback: more ranks joined than the world size");
+    ++g_->joined;
   }
   ~LoopbackComm() override {
     std::lock_guard<std::mutex> lk(g_loop_mu);
     --g_->joined;
+    for (auto it = g_loop_groups.begin(); it != g_loop_groups.end();)  // groups whose last rank has gone
+      it = (it->second.expired() || (it->second.lock() == g_ && g_->joined == 0)) ? g_loop_groups.erase(it) : std::next(it);
   }
   const char* kind() const override { return "loopback"; }
 

@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // items of one split are consecutive: the workgroups that start together sweep the same column tiles together
     const int split = item / a.rb_count, rb = a.rb_begin + (item - split * a.rb_count);
     const int t0 = split * a.tiles_per_split, t1 = min(a.ntileB, t0 + a.tiles_per_split);
-    if (t0 >= t1) continue;
+    if (t0 >= t1) {  // an empty column split (the planner never makes one; OSC_KNN_MODE=panel can): no hits, but say so
+      if (MODE == 1 && lane == 0) a.hit_cnt[item * 4 + wave] = 0;
+      continue;
+    }
     const int row = rb * 128 + 32 * wave + l31;
     half8 areg[NK16];
 #pragma unroll

@@ -225,10 +225,13 @@ class OscillinkLattice:
         self._call("osc_spmm_plan", C.byref(ln), C.byref(sc), C.byref(xw))
         sb, ba = C.c_int32(0), C.c_int64(0)
         self._call("osc_apply_info", C.byref(sb), C.byref(ba))
+        fo, lp = C.c_int32(0), C.c_int32(0)
+        self._call("osc_solver_info", C.byref(fo), C.byref(lp))
         return {"prefilter": int(pf.value), "fallback_rows": int(fb.value), "small_solves": int(ss.value),
                 "reordered": int(ro.value), "clustering": float(cc.value), "apply_launches": int(ln.value),
                 "apply_slab_cols": int(sc.value), "apply_xs_workgroups": int(xw.value),
-                "apply_src_blocks": int(sb.value), "blocked_applies": int(ba.value)}
+                "apply_src_blocks": int(sb.value), "blocked_applies": int(ba.value),
+                "cg_fold": int(fo.value), "cg_launches_per_iter": int(lp.value)}
 
     def halo_info(self) -> dict[str, int]:
         """Row-sharded runs (OSC_SHARD=row under a communicator): the rows of the search direction this rank receives
@@ -264,6 +267,16 @@ class OscillinkLattice:
         A = np.asarray(A, dtype=np.float32)
         if A.shape != (self.N, self.N):
             raise ValueError("A shape mismatch")
+        # The reference takes whatever adjacency a state carries (lattice.py:709-713) and only promises approximate
+        # symmetry after its row cap (graph.py:69-83); the device graph is an SPD operator with unit Laplacian
+        # diagonal, so a dense adjacency is brought to that contract here instead of being refused by osc_set_csr:
+        # the diagonal is dropped and float drift between A_ij and A_ji is averaged over the mutual support
+        # ("Injected graphs").
+        if np.any(np.diagonal(A) != 0) or not np.array_equal(A, A.T):
+            A = A.copy()
+            np.fill_diagonal(A, 0.0)
+            both = (A > 0) & (A.T > 0)
+            A = np.where(both, 0.5 * (A + A.T), 0.0).astype(np.float32)
         r, c = np.nonzero(A > 0)
         rowptr = np.zeros(self.N + 1, dtype=np.int64)
         np.add.at(rowptr, r + 1, 1)

@@ -369,6 +369,25 @@ def test_diverged_column_reports_nan_like_the_reference(amd, small, monkeypatch)
     assert np.isnan(out[:, 3]).any() and np.isfinite(np.delete(out, 3, axis=1)).all()
 
 
+@pytest.mark.parametrize("row", [0, 67, 199])
+def test_diverged_column_on_the_blocked_apply(amd, row, monkeypatch):
+    """The same on the source-blocked matvec: its unused slots gather the first row of their block with weight 0.0f, so a
+    non-finite value in such a row (row 0 and row 67 = first rows of blocks at 3 blocks over 200 rows) reaches every row of
+    ITS column as 0 * NaN -- exactly what the reference's dense `L_sym @ X` does -- and must never leave the column."""
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    monkeypatch.setenv("OSC_SPMM_XS", "1")
+    monkeypatch.setenv("OSC_SPMM_BLOCKED", "3")
+    lat = _lattice(amd, N=200, D=64, k=6)
+    U = lat.U.copy()
+    U[row, 35] = np.nan
+    lat.U = U
+    st = lat.settle(max_iters=6, tol=1e-3)
+    assert lat.build_info()["apply_src_blocks"] == 3
+    assert st["iters"] == 6 and np.isnan(st["res"])
+    out = lat.U
+    assert np.isnan(out[:, 35]).any() and np.isfinite(np.delete(out, 35, axis=1)).all()
+
+
 def test_failed_rebuild_keeps_the_python_state(amd):
     lat = _lattice(amd, N=40, D=12, k=5)
     before = (lat._kneighbors, lat._row_cap_val, lat._deterministic_k, lat._signature())
