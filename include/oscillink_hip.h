@@ -95,13 +95,6 @@ int osc_spmm_plan(osc_handle h, int32_t* launches, int32_t* slab_cols, int32_t* 
  * aid) */
 int osc_apply_info(osc_handle h, int32_t* src_blocks, int64_t* blocked_applies);
 
-/* the column sums of the last general-path solve (solver.py:21,25,29,33: r.z, p.Ap, r.r): fold = 0 when separate reduce
- * launches finished them (5 launches per CG iteration), 1 when the initial residual and the x, r updates finished theirs
- * in-kernel (4 per iteration: a chain prior beside the blocked matvec keeps the apply's reduce launch), 2 when the operator
- * apply did too (3 per iteration); launches_per_iter = kernel launches of one CG iteration of that solve.  OSC_CG_FOLD = 0
- * never / 1 wherever one update launch covers the column window (measurement aid) */
-int osc_solver_info(osc_handle h, int32_t* fold, int32_t* launches_per_iter);
-
 /* CSR view of the graph for `.A`, `.L_sym`, `_signature()` (lattice.py:729-744) and export_state
  * (:582-624).  rowptr has N+1 entries; col/a/w have nnz entries, columns ascending within a row;
  * a = capped adjacency A_ij (> 0), w = A_ij / (sqrt_deg_i sqrt_deg_j); sqrt_deg has N entries.

@@ -71,128 +71,10 @@ __device__ __forceinline__ float bcast_f(float v, int sub, int t) {
   return __int_as_float(bcast_i<LPR>(__float_as_int(v), sub, t));
 }
 
-// write-through accesses (global_load / global_store ... sc1): what another CU's -- another XCD's -- workgroup reads inside
-// the same launch is stored this way, and read this way (MI355X_MICROARCH.md, inter-workgroup visibility)
-__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_wt(const float* p) {
-  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_wt(const double* p) {
-  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// FoldArgs: the tail of a kernel whose workgroups have each written one row of part0 (and part1: NIN == 2) write-through.
-// Called by all NT threads of every workgroup of the launch (uniformly).  extra_rows: rows of part0 beyond gridDim.x that
-// an earlier launch completed (none today).
-template <int NIN, int NT>
-__device__ __forceinline__ void fold_finish(const FoldArgs& f, const float* part0, const float* part1, int32_t ld, int32_t c0,
-                                            int32_t c1) {
-  __shared__ int s_last;
-  __shared__ float s_res[NT / 64];
-  const int G = (int)gridDim.x, ng = f.ngroups, grp = (int)blockIdx.x % ng;
-  // every storing wave's stores have left before its workgroup signals (the counter add below is behind the barrier)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int members = (G - grp + ng - 1) / ng;
-    const unsigned t = __hip_atomic_fetch_add(f.ctr + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = t == (unsigned)members - 1u;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // level 1: the rows grp, grp + ng, ... of this group, 8 loads in flight per input
-  for (int col = c0 + (int)threadIdx.x; col < c1; col += NT) {
-    double s0 = 0.0, s1 = 0.0;
-    int b = grp;
-    for (; b + 7 * ng < G; b += 8 * ng) {
-      float v0[8], v1[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        v0[u] = ld_wt(part0 + (size_t)(b + u * ng) * ld + col);
-        if (NIN > 1) v1[u] = ld_wt(part1 + (size_t)(b + u * ng) * ld + col);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        s0 += (double)v0[u];
-        if (NIN > 1) s1 += (double)v1[u];
-      }
-    }
-    for (; b < G; b += ng) {
-      s0 += (double)ld_wt(part0 + (size_t)b * ld + col);
-      if (NIN > 1) s1 += (double)ld_wt(part1 + (size_t)b * ld + col);
-    }
-    st_wt(f.gsum + (size_t)(grp * 2) * ld + col, s0);
-    if (NIN > 1) st_wt(f.gsum + (size_t)(grp * 2 + 1) * ld + col, s1);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(f.ctr + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-    const unsigned t = __hip_atomic_fetch_add(f.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = t == (unsigned)min(ng, G) - 1u;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // level 2: the group sums, in group order; then the step the k_reduce_* kernels would have taken
-  const int nga = min(ng, G);
-  float resc = 0.f;
-  for (int col = c0 + (int)threadIdx.x; col < c1; col += NT) {
-    double t0 = 0.0, t1 = 0.0;
-    int g = 0;
-    for (; g + 7 < nga; g += 8) {
-      double v0[8], v1[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        v0[u] = ld_wt(f.gsum + (size_t)((g + u) * 2) * ld + col);
-        if (NIN > 1) v1[u] = ld_wt(f.gsum + (size_t)((g + u) * 2 + 1) * ld + col);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        t0 += v0[u];
-        if (NIN > 1) t1 += v1[u];
-      }
-    }
-    for (; g < nga; ++g) {
-      t0 += ld_wt(f.gsum + (size_t)(g * 2) * ld + col);
-      if (NIN > 1) t1 += ld_wt(f.gsum + (size_t)(g * 2 + 1) * ld + col);
-    }
-    if (f.op == FOLD_INIT) {
-      f.rz[col] = t0;                                            // solver.py:22
-    } else if (f.op == FOLD_ALPHA) {
-      f.coef[col] = (float)(f.rz[col] / (t0 + 1e-18));           // solver.py:25-26
-    } else {
-      resc = nanmax(resc, (float)sqrt(t0));                      // ||r_c||_2        (solver.py:29)
-      f.coef[col] = (float)(t1 / (f.rz[col] + 1e-18));           // solver.py:33-34
-      f.rz[col] = t1;
-    }
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(f.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (NIN > 1 && f.op == FOLD_BETA) {  // max over the window's columns -> the iteration's residual
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) resc = nanmax(resc, __shfl_xor(resc, o, 64));
-    if ((threadIdx.x & 63) == 0) s_res[threadIdx.x >> 6] = resc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int w = 1; w < NT / 64; ++w) resc = nanmax(resc, s_res[w]);
-      const uint32_t bits = __float_as_uint(resc);
-      atomicMax(f.res_bits, bits);  // (the slot is zero before the iteration: non-negative floats order as uints)
-      if (f.host_slot != nullptr) {
-        *reinterpret_cast<volatile uint32_t*>(f.host_slot) = bits;
-        __threadfence_system();
-      }
-    }
-  }
-}
-
-// fold per-lane column partials of the 4 waves of a block and write one row of part[grid][ld] (wt: write-through, for
-// fold_finish)
+// fold per-lane column partials of the 4 waves of a block and write one row of part[grid][ld]
 template <int LPR, int NCH>
 __device__ __forceinline__ void block_fold(float4 (&dot)[NCH], float* red /*[4][CPW]*/, float* part, int32_t ld,
-                                           int32_t c0, int32_t c1, bool wt = false) {
+                                           int32_t c0, int32_t c1) {
   constexpr int CPW = NCH * LPR * 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, lr = lane % LPR;
@@ -216,11 +98,7 @@ __device__ __forceinline__ void block_fold(float4 (&dot)[NCH], float* red /*[4][
   __syncthreads();
   for (int idx = threadIdx.x; idx < CPW; idx += 256) {
     const int col = c0 + idx;
-    if (col < c1) {
-      const float v = (red[idx] + red[CPW + idx]) + (red[2 * CPW + idx] + red[3 * CPW + idx]);
-      if (wt) st_wt(part + (size_t)blockIdx.x * ld + col, v);
-      else part[(size_t)blockIdx.x * ld + col] = v;
-    }
+    if (col < c1) part[(size_t)blockIdx.x * ld + col] = (red[idx] + red[CPW + idx]) + (red[2 * CPW + idx] + red[3 * CPW + idx]);
   }
 }
 
@@ -243,21 +121,14 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
   const int sub = lane / LPR, lr = lane % LPR;
   const int32_t ld = a.ld;
   const bool xs = a.xs != 0;  // workgroup-uniform
-  const bool wt = MODE != SPMM_DOT && a.fold.op != FOLD_NONE;  // the column sums are finished inside this launch
-  bool active = true;
-  if (xs) {  // this workgroup's row of part[][] is summed over every column by the reduce step: clear the columns
+  if (xs) {  // this workgroup's row of part[][] is summed over every column by the reduce kernels: clear the columns
              // of the slabs other XCDs own (block_fold's leading barrier orders this against the folds below)
-    for (int c = a.c0 + threadIdx.x; c < a.c1; c += 256) {
-      if (wt) st_wt(a.part + (size_t)blockIdx.x * ld + c, 0.f);
-      else a.part[(size_t)blockIdx.x * ld + c] = 0.f;
-    }
-    if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and keeps the write-through zeros ahead of the sums
-    active = (int)(blockIdx.x >> 3) < a.xs;  // a.xs workgroups per XCD do the work
-    if (!active && !wt) return;
+    for (int c = a.c0 + threadIdx.x; c < a.c1; c += 256) a.part[(size_t)blockIdx.x * ld + c] = 0.f;
+    if ((int)(blockIdx.x >> 3) >= a.xs) return;  // a.xs workgroups per XCD do the work
   }
   // slab loop: one pass over [c0, c1) normally; in xs mode the slabs x, x+8, ... of this workgroup's XCD
   const int xgroups = xs ? a.xs_groups : 1, xgrp = (int)(blockIdx.x & 7) % xgroups, xpart = (int)(blockIdx.x & 7) / xgroups;
-  for (int32_t sc0 = !active ? a.c1 : (xs ? a.c0 + xgrp * CPW : a.c0); sc0 < a.c1; sc0 += xs ? xgroups * CPW : (1 << 30)) {
+  for (int32_t sc0 = xs ? a.c0 + xgrp * CPW : a.c0; sc0 < a.c1; sc0 += xs ? xgroups * CPW : (1 << 30)) {
   const int32_t sc1 = xs ? min(a.c1, sc0 + CPW) : a.c1;
   int coff[NCH];
   bool cok[NCH];
@@ -417,11 +288,8 @@ __global__ __launch_bounds__(256) void k_spmm(const SpmmArgs a) {
       }
     }
   }
-  block_fold<LPR, NCH>(dot, red, a.part, ld, sc0, sc1, wt);
+  block_fold<LPR, NCH>(dot, red, a.part, ld, sc0, sc1);
   }  // slab loop
-  if constexpr (MODE != SPMM_DOT) {
-    if (wt) fold_finish<1, 256>(a.fold, a.part, nullptr, ld, a.c0, a.c1);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -470,7 +338,7 @@ struct BlkPhase {  // sub-phase ph = (slab, slice, block): every wave of the XCD
 // rows of 32 columns are added in wave order
 template <int NW>
 __device__ __forceinline__ void blk_fold(float4 dot, float (&red)[NW][32], float* part, int32_t ld, int32_t c0, int32_t c1,
-                                         int wave, int lane, bool wt) {
+                                         int wave, int lane) {
 #pragma unroll
   for (int o = 8; o < 64; o <<= 1) {
     dot.x += __shfl_xor(dot.x, o, 64);
@@ -485,8 +353,7 @@ __device__ __forceinline__ void blk_fold(float4 dot, float (&red)[NW][32], float
     float sacc = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) sacc += red[w][threadIdx.x];
-    if (wt) st_wt(part + (size_t)blockIdx.x * ld + c0 + threadIdx.x, sacc);
-    else part[(size_t)blockIdx.x * ld + c0 + threadIdx.x] = sacc;
+    part[(size_t)blockIdx.x * ld + c0 + threadIdx.x] = sacc;
   }
 }
 
@@ -500,14 +367,8 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane >> 3, lr = lane & 7;
   const int32_t ld = a.ld;
-  const bool wt = a.fold.op != FOLD_NONE;  // the column sums (-> alpha) are finished inside this launch: fold_finish
-  for (int c = a.c0 + threadIdx.x; c < a.c1; c += NT) {
-    if (wt) st_wt(a.part + (size_t)blockIdx.x * ld + c, 0.f);
-    else a.part[(size_t)blockIdx.x * ld + c] = 0.f;
-  }
-  if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through zeros stay ahead of the slabs' sums
-  const bool active = (int)(blockIdx.x >> 3) < a.xs;
-  if (!active && !wt) return;
+  for (int c = a.c0 + threadIdx.x; c < a.c1; c += NT) a.part[(size_t)blockIdx.x * ld + c] = 0.f;
+  if ((int)(blockIdx.x >> 3) >= a.xs) return;
   const int xcd = (int)(blockIdx.x & 7), wgx = (int)(blockIdx.x >> 3);
   const int xgroups = a.xs_groups, xgrp = xcd % xgroups, xpart = xcd / xgroups, parts = 8 / xgroups;
   const int rlo = (int)((int64_t)a.N * xpart / parts), rhi = (int)((int64_t)a.N * (xpart + 1) / parts);
@@ -516,7 +377,7 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
   const int slice_rows = W8 * ng;
   const int rpb = (a.N + nb - 1) / nb;  // rows per source block (launch_blocked_fill)
   const int nslab = a.c1 - a.c0 > xgrp * 32 ? ((a.c1 - a.c0 - xgrp * 32 + xgroups * 32 - 1) / (xgroups * 32)) : 0;
-  const int per_slab = a.slices * nb, nphase = active ? nslab * per_slab : 0;  // (a workgroup beyond a.xs only joins the fold)
+  const int per_slab = a.slices * nb, nphase = nslab * per_slab;
   auto phase = [&](int ph) {
     BlkPhase p;
     const int q = ph / per_slab, r = ph - q * per_slab;
@@ -570,10 +431,12 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
       __syncthreads();
       if ((ph + 1) % per_slab == 0) {
         const int sc0 = phase(ph).sc0;
-        blk_fold<CW + 1>(f4(0.f), red, a.part, ld, sc0, min(a.c1, sc0 + 32), wave, lane, wt);
+        blk_fold<CW + 1>(f4(0.f), red, a.part, ld, sc0, min(a.c1, sc0 + 32), wave, lane);
       }
     }
-  } else {
+    return;
+  }
+
   // ---- the other waves: gather (L2 hits and LDS reads) ---------------------------------------------------------------
   const uint32_t lr16 = (uint32_t)lr * 16u;
   float4 acc[GM];
@@ -655,12 +518,10 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
     }
     __syncthreads();
     if ((ph + 1) % per_slab == 0) {  // the slab's column sums
-      blk_fold<CW + 1>(dot[0], red, a.part, ld, p.sc0, min(a.c1, p.sc0 + 32), wave, lane, wt);
+      blk_fold<CW + 1>(dot[0], red, a.part, ld, p.sc0, min(a.c1, p.sc0 + 32), wave, lane);
       dot[0] = f4(0.f);
     }
   }
-  }  // roles
-  if (wt) fold_finish<1, NT>(a.fold, a.part, nullptr, ld, a.c0, a.c1);
 }
 
 // chain prior for k_apply_blocked (ChainFixArgs): one wave per (64 columns, chunk of path rows), one thread per column
@@ -833,9 +694,7 @@ __global__ __launch_bounds__(256) void k_init_finish(const InitFinishArgs a) {
       rz[ch] = mulacc4(r, z, rz[ch]);
     }
   }
-  const bool wt = a.fold.op != FOLD_NONE;
-  block_fold<LPR, NCH>(rz, red, a.part, ld, a.c0, a.c1, wt);
-  if (wt) fold_finish<1, 256>(a.fold, a.part, nullptr, ld, a.c0, a.c1);
+  block_fold<LPR, NCH>(rz, red, a.part, ld, a.c0, a.c1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -882,10 +741,8 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
       rz[ch] = mulacc4(r, z, rz[ch]);
     }
   }
-  const bool wt = a.fold.op != FOLD_NONE;
-  block_fold<LPR, NCH>(rr, red, a.part_rr, ld, a.c0, a.c1, wt);
-  block_fold<LPR, NCH>(rz, red, a.part_rz, ld, a.c0, a.c1, wt);
-  if (wt) fold_finish<2, 256>(a.fold, a.part_rr, a.part_rz, ld, a.c0, a.c1);
+  block_fold<LPR, NCH>(rr, red, a.part_rr, ld, a.c0, a.c1);
+  block_fold<LPR, NCH>(rz, red, a.part_rz, ld, a.c0, a.c1);
 }
 
 template <int LPR, int NCH>

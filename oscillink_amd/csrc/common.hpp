@@ -105,25 +105,6 @@ struct BlockedView {
   int32_t nb;           // source blocks; 0 = no blocked copy
 };
 
-// In-kernel completion of the CG's column sums (solver.py:21,25,29,33): where one launch covers a solve's column window the
-// k_reduce_* launches behind the operator apply / the x, r update / the initial residual are folded into those kernels.
-// Every workgroup writes its row of part[][] write-through and takes a ticket in its group's counter (group =
-// blockIdx % ngroups); the group's last arriver sums the group's rows in fp64, in fixed order, into gsum[group][][] and
-// takes a ticket in the top counter; the last group finisher sums the group sums, again in fixed order, and applies the
-// finish step (rz of the initial residual; alpha; beta + residual).  Same sums whatever the arrival order: deterministic.
-enum FoldOp { FOLD_NONE = 0, FOLD_INIT = 1, FOLD_ALPHA = 2, FOLD_BETA = 3 };
-constexpr int OSC_FOLD_MAX_GROUPS = 64;
-struct FoldArgs {
-  int32_t op;          // FoldOp; FOLD_NONE: the k_reduce_* kernels finish the sums
-  int32_t ngroups;     // <= min(grid, OSC_FOLD_MAX_GROUPS)
-  uint32_t* ctr;       // [1 + OSC_FOLD_MAX_GROUPS] arrival counters: zero on entry, zero again on exit
-  double* gsum;        // [OSC_FOLD_MAX_GROUPS][2][ld] group sums
-  double* rz;          // [ld] r.z of the previous step (INIT writes it, ALPHA reads it, BETA reads and replaces it)
-  float* coef;         // [ld] ALPHA: alpha, BETA: beta
-  uint32_t* res_bits;  // BETA: this iteration's residual slot (atomicMax, like k_reduce_beta)
-  float* host_slot;    // BETA: host-mapped mirror of that slot, or nullptr
-};
-
 // arguments of the source-blocked CG matvec (k_apply_blocked): out = (cs_const + cs_B B_i) x_i - cW sum_j W_ij x_j
 struct BlkArgs {
   const float* X;   // operand, slab-major [ld / 32][N][32]
@@ -139,7 +120,6 @@ struct BlkArgs {
   int32_t N, ld, c0, c1;
   int32_t xs, xs_groups;  // workgroups per XCD that take part, slab groups (as in SpmmArgs)
   int32_t nb, groups, slices;  // source blocks; row groups (of 8 rows) per gathering wave and slice; dest-row slices
-  FoldArgs fold;               // FOLD_ALPHA (CG loop) / FOLD_NONE
 };
 
 enum SpmmMode { SPMM_AP = 0, SPMM_INIT = 1, SPMM_DOT = 2 };
@@ -176,7 +156,6 @@ struct SpmmArgs {
   // contiguous N x 128 B range (even spread over the L2 channels; no 3 KB row stride).  xblk != 0: the operand X is
   // stored that way (value = rows per slab = N); pblk != 0: INIT writes its P output that way.
   int64_t xblk, pblk;
-  FoldArgs fold;  // AP: FOLD_ALPHA, INIT: FOLD_INIT, or FOLD_NONE
 };
 
 struct UpdateArgs {
@@ -196,7 +175,6 @@ struct UpdateArgs {
   const float* gate;  // see SpmmArgs
   float gate_tol;
   int64_t pblk;  // != 0: P is stored slab-major with this many rows per slab (see SpmmArgs)
-  FoldArgs fold;  // k_update_xr: FOLD_BETA or FOLD_NONE
 };
 
 struct Gate {
@@ -248,7 +226,6 @@ struct InitFinishArgs {
   OpParams op;
   int64_t N, pblk;
   int32_t ld, c0, c1;
-  FoldArgs fold;  // FOLD_INIT or FOLD_NONE
 };
 void launch_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, int32_t c0, int32_t c1, int grid, hipStream_t s);
 void launch_init_finish(const InitFinishArgs& a, int grid, hipStream_t s);

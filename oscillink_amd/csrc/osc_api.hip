@@ -216,9 +216,6 @@ struct osc_lattice {
   int xs_groups_cap = 8;   // upper bound on the slab groups (= slabs in flight) of that mode (OSC_XS_GROUPS)
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
-  DevBuf<uint32_t> fold_ctr;  // FoldArgs: arrival counters and group sums of the in-kernel column reductions
-  DevBuf<double> fold_gsum;
-  int cg_fold = -1;           // -1 automatic, 0 never (the k_reduce_* launches), 1 wherever one launch covers the window (OSC_CG_FOLD)
   DevBuf<uint32_t> res_bits, arrive;  // arrive: per-iteration barrier counters (+1 status word) of the one-launch path
   bool small_path = true;             // OSC_SMALL_PATH=0 disables the one-launch CG for small lattices
   int predicted_iters = 0;            // iterations the last general-path solve of this handle took (0 = unknown)
@@ -233,8 +230,6 @@ struct osc_lattice {
   double blk_edges = 3.3;  // edges of a row per source block the block count aims at (OSC_BLK_EDGES)
   int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
   int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
-  int fold_last = 0;       // in-kernel column reductions of that solve: 0 none, 1 initial residual + updates, 2 + the operator apply
-  int launches_last = 0;   // kernel launches per CG iteration of that solve
   bool blk_init = true;    // the initial residual goes through the blocked matvec as well (OSC_BLK_INIT=0: plain INIT apply)
   int64_t blk_applies = 0; // blocked matvecs enqueued since creation
   int64_t small_solves = 0;
@@ -448,11 +443,6 @@ void ensure_cg_scratch(L& h, int max_iters) {
   h.beta.alloc(h.ld);
   h.rz.alloc(h.ld);
   h.colsum.alloc(h.ld);
-  if (h.fold_ctr.n != 1 + OSC_FOLD_MAX_GROUPS) {
-    h.fold_ctr.alloc(1 + OSC_FOLD_MAX_GROUPS);
-    HIP_CHECK(hipMemsetAsync(h.fold_ctr.p, 0, h.fold_ctr.n * 4, h.stream));
-  }
-  h.fold_gsum.alloc((size_t)OSC_FOLD_MAX_GROUPS * 2 * h.ld);
   // sized for solve_Ustar's default 64 iterations from the start: a settle(12) followed by a U* solve must not pay
   // for re-allocating the residual slots, their pinned mirror and the per-iteration events
   ensure_ctrl(h, (size_t)std::max(max_iters, 64) + 2);
@@ -1255,33 +1245,6 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     }
   }
 
-  // In-kernel completion of the column sums (FoldArgs): the k_reduce_* launch behind the initial residual, every operator
-  // apply and every x, r update disappears -- 3 launches per iteration instead of 5, which is what a short solve is made
-  // of (a per-rank window of a sharded settle, a mid-size lattice).  Needs one update launch per iteration (<= 2048
-  // columns); the operator apply keeps its reduce launch when the chain fix-up adds rows to its partial sums behind it.
-  FoldArgs fold{};
-  fold.ngroups = 1;
-  while (fold.ngroups * fold.ngroups < grid && fold.ngroups < OSC_FOLD_MAX_GROUPS) fold.ngroups <<= 1;  // ~ sqrt(grid)
-  fold.ngroups = std::min(fold.ngroups, grid);
-  fold.ctr = h.fold_ctr.p;
-  fold.gsum = h.fold_gsum.p;
-  fold.rz = h.rz.p;
-  bool fold_on = h.cg_fold != 0 && b.c1 - b.c0 <= 2048 && (size_t)OSC_FOLD_MAX_GROUPS * 2 * b.ld <= h.fold_gsum.n;
-  if (fold_on && h.cg_fold < 0) {
-    // the last arriver of a group reads (grid / ngroups) rows x the window x 2 sums with 256 threads: beyond ~256 loads
-    // per thread the tail costs more than the launch it replaces
-    const int64_t per_thread = (int64_t)((grid + fold.ngroups - 1) / fold.ngroups) * (b.c1 - b.c0) * 2 / 256;
-    fold_on = per_thread <= 256;
-  }
-  const bool fold_ap = fold_on && cf.chunks == 0;
-  if (fold_on) HIP_CHECK(hipMemsetAsync(h.fold_ctr.p, 0, h.fold_ctr.n * 4, h.stream));  // (a faulted launch may have left tickets)
-  auto fold_for = [&](int op, bool on) {
-    FoldArgs f = fold;
-    f.op = on ? op : FOLD_NONE;
-    return f;
-  };
-  sa.fold = fold_for(FOLD_INIT, fold_on);
-
   // (an inertia start hands over x0 IN the AP array, which the blocked matvec would overwrite with A x0 before
   // init_finish has read x0: such a solve keeps the gathering INIT kernel, which reads x0 completely first)
   if (ba.nb > 0 && h.blk_init && b.x0 != b.AP) {
@@ -1309,7 +1272,6 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     fa.N = h.N;
     fa.pblk = h.N;
     fa.ld = b.ld;
-    fa.fold = fold_for(FOLD_INIT, fold_on);
     for (int32_t s0 = b.c0; s0 < b.c1; s0 += 2048) {
       fa.c0 = s0;
       fa.c1 = std::min(b.c1, s0 + 2048);
@@ -1318,7 +1280,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   } else {
     spmm_slabbed(h, SPMM_INIT, sa, grid);
   }
-  if (!fold_on) launch_reduce_init(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.stream);
+  launch_reduce_init(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.stream);
   UpdateArgs ua{};
   ua.pblk = pblk ? h.N : 0;
   ua.X = b.X;
@@ -1339,21 +1301,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   sa.OUT = b.AP;
   sa.xblk = pblk ? h.N : 0;
   sa.pblk = 0;
-  sa.fold = fold_for(FOLD_ALPHA, fold_ap);
-  sa.fold.coef = h.alpha.p;
-  ba.fold = sa.fold;
-  ua.fold = fold_for(FOLD_BETA, fold_on);
-  ua.fold.coef = h.beta.p;
   h.blk_last = ba.nb;
-  h.fold_last = fold_on ? (fold_ap ? 2 : 1) : 0;
-  {  // kernel launches of one CG iteration: p update, operator apply (+ chain fix-up), [alpha], x/r update, [beta]
-    const int32_t ncols = b.c1 - b.c0;
-    int apply_launches = 1;
-    if (ba.nb > 0) apply_launches = 1 + (cf.chunks > 0 ? 1 : 0);
-    else if (xs_plan(h, ncols, grid) == 0) apply_launches = (ncols + auto_slab(h, ncols) - 1) / auto_slab(h, ncols);
-    const int windows = (ncols + 2047) / 2048;
-    h.launches_last = windows + apply_launches + (fold_ap ? 0 : 1) + windows + (fold_on ? 0 : 1);
-  }
   auto enqueue_iter = [&](int it) {  // everything of iteration `it` up to its residual, gated on iteration it-1
     const Gate g{it > 1 ? res_dev + (it - 1) : nullptr, tol};
     sa.gate = g.p;
@@ -1378,20 +1326,10 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     } else {
       spmm_slabbed(h, SPMM_AP, sa, grid, it);
     }
-    if (!fold_ap)
-      launch_reduce_alpha(h.part0.p, grid + (ba.nb > 0 ? cf.chunks : 0), b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
-    ua.fold.res_bits = h.res_bits.p + it;
-    ua.fold.host_slot = mapped ? h.res_host_dev + it : nullptr;
+    launch_reduce_alpha(h.part0.p, grid + (ba.nb > 0 ? cf.chunks : 0), b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
     {
       ProfScope ps(h, 1, it);
       for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });
-    }
-    if (fold_on) {  // beta, r.z and the residual came out of the update launch itself
-      if (mapped) return;
-      if (h.comm) h.comm->allreduce(h.res_bits.p + it, 1, COMM_F32, COMM_MAX, h.stream);
-      HIP_CHECK(hipMemcpyAsync(h.res_host + it, h.res_bits.p + it, 4, hipMemcpyDeviceToHost, h.stream));
-      HIP_CHECK(hipEventRecord(h.iter_events[(size_t)it], h.stream));
-      return;
     }
     if (mapped) {
       launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream,
@@ -1920,7 +1858,6 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_BLK_MB")) h->blk_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_BLK_EDGES")) h->blk_edges = std::max(0.5, atof(e));
     if (const char* e = getenv("OSC_BLK_INIT")) h->blk_init = atoi(e) != 0;
-    if (const char* e = getenv("OSC_CG_FOLD")) h->cg_fold = atoi(e);
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
     if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
@@ -2000,13 +1937,6 @@ int osc_apply_info(osc_handle h, int32_t* src_blocks, int64_t* blocked_applies) 
   return guarded(h, [&](L& l) {
     if (src_blocks) *src_blocks = l.blk_last;
     if (blocked_applies) *blocked_applies = l.blk_applies;
-  });
-}
-
-int osc_solver_info(osc_handle h, int32_t* fold, int32_t* launches_per_iter) {
-  return guarded(h, [&](L& l) {
-    if (fold) *fold = l.fold_last;
-    if (launches_per_iter) *launches_per_iter = l.launches_last;
   });
 }
 

@@ -225,13 +225,10 @@ class OscillinkLattice:
         self._call("osc_spmm_plan", C.byref(ln), C.byref(sc), C.byref(xw))
         sb, ba = C.c_int32(0), C.c_int64(0)
         self._call("osc_apply_info", C.byref(sb), C.byref(ba))
-        fo, lp = C.c_int32(0), C.c_int32(0)
-        self._call("osc_solver_info", C.byref(fo), C.byref(lp))
         return {"prefilter": int(pf.value), "fallback_rows": int(fb.value), "small_solves": int(ss.value),
                 "reordered": int(ro.value), "clustering": float(cc.value), "apply_launches": int(ln.value),
                 "apply_slab_cols": int(sc.value), "apply_xs_workgroups": int(xw.value),
-                "apply_src_blocks": int(sb.value), "blocked_applies": int(ba.value),
-                "cg_fold": int(fo.value), "cg_launches_per_iter": int(lp.value)}
+                "apply_src_blocks": int(sb.value), "blocked_applies": int(ba.value)}
 
     def halo_info(self) -> dict[str, int]:
         """Row-sharded runs (OSC_SHARD=row under a communicator): the rows of the search direction this rank receives

@@ -108,64 +108,6 @@ def test_general_multi_kernel_cg_on_small_fixtures(amd, name, monkeypatch):
     _check_solves(lat, case, rc, tol_u=2e-5)
 
 
-@pytest.mark.parametrize("name", ["c2_n1200_d128_k16", "g1_n400_d64_k6_chain8", "gates_chain_n333_d50_k7"])
-@pytest.mark.parametrize("mode", ["plain", "xs", "blocked"])
-@pytest.mark.parametrize("fold", ["0", "1"])
-def test_in_kernel_column_reductions_match_reference(amd, name, mode, fold, monkeypatch):
-    """OSC_CG_FOLD=1: the column sums of solver.py:21,25,29,33 are finished inside the kernels that form them (last-arriver
-    groups, fixed summation order) instead of by reduce launches; OSC_CG_FOLD=0 keeps the launches.  Both through the same
-    fixtures on the plain apply, the XCD-affine slab apply and the source-blocked apply (where a chain prior keeps the
-    apply's own reduce launch: fold level 1)."""
-    monkeypatch.setenv("OSC_SMALL_PATH", "0")
-    monkeypatch.setenv("OSC_CG_FOLD", fold)
-    if mode != "plain":
-        monkeypatch.setenv("OSC_SPMM_XS", "1")
-    if mode == "blocked":
-        monkeypatch.setenv("OSC_SPMM_BLOCKED", "3")
-    case = load_case(name)
-    rc = case["recipe"]
-    Y, psi = make_inputs(rc)
-    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
-    lat.set_graph_csr(*_csr_from_case(case))
-    _configure(lat, case, rc, psi)
-    _check_solves(lat, case, rc, tol_u=2e-5)
-    info = lat.build_info()
-    assert info["small_solves"] == 0
-    fixup = bool(info["apply_src_blocks"] > 0 and rc["chain"])  # (a pitch that is no multiple of 32 keeps the plain apply)
-    want = 0 if fold == "0" else (1 if fixup else 2)
-    assert info["cg_fold"] == want, info
-    assert info["cg_launches_per_iter"] == {0: 5, 1: 4, 2: 3}[want] + (1 if fixup else 0), info
-
-
-def test_in_kernel_column_reductions_are_deterministic_and_equal_the_launched_ones(amd, monkeypatch):
-    """Mid-size lattice on the automatic path (N = 20000, D = 128: the default there), ragged window (D = 100), and a wide one
-    (D = 1000 on 8 groups of workgroups): residual histories and states of the folded and the launched reductions agree to
-    fp32 rounding of the fp64 column sums, and repeated folded solves are bit-identical (the sums never depend on the
-    arrival order)."""
-    monkeypatch.delenv("OSC_SPMM_XS", raising=False)
-    rng = np.random.default_rng(11)
-    for N, D, k in ((20000, 128, 16), (9000, 100, 8), (7000, 1000, 12)):
-        Y = rng.standard_normal((N, D)).astype(np.float32)
-        psi = rng.standard_normal(D).astype(np.float32)
-        gates = rng.uniform(0.2, 1.0, N).astype(np.float32)
-        runs = {}
-        for fold in ("0", "1", "1b"):
-            monkeypatch.setenv("OSC_CG_FOLD", fold[0])
-            lat = amd.Oscillink(Y, kneighbors=k)
-            lat.set_query(psi, gates=gates)
-            st = lat.settle(max_iters=12, tol=1e-5)
-            hist = np.array(lat.residual_history())
-            Us = lat.solve_Ustar(tol=1e-6)
-            runs[fold] = (st["iters"], hist, lat.U.copy(), Us.copy(), lat.last_ustar["iters"])
-            assert lat.build_info()["cg_fold"] == (0 if fold == "0" else 2)
-            lat.close()
-        assert runs["0"][0] == runs["1"][0] and runs["0"][4] == runs["1"][4]
-        assert np.allclose(runs["0"][1], runs["1"][1], rtol=1e-5)
-        assert relerr(runs["1"][2], runs["0"][2]) < 1e-6 and relerr(runs["1"][3], runs["0"][3]) < 1e-6
-        assert np.array_equal(runs["1"][1], runs["1b"][1])
-        assert np.array_equal(runs["1"][2], runs["1b"][2]) and np.array_equal(runs["1"][3], runs["1b"][3])
-
-
 @pytest.mark.parametrize("name", ALL_CASES)
 def test_device_knn_graph_matches_reference(amd, name):
     """Device mutual-kNN + cap + Laplacian weights against the reference's adjacency (same edge set, same weights)."""
