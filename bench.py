@@ -16,7 +16,9 @@ N > 1: strong scaling of the same settle -- the CG is column-sharded (per-column
 D/N column slab and the only per-iteration exchange is one RCCL all-reduce(max) of the residual.  This script uses no
 PyTorch: the launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; the ncclUniqueId travels through a
 rendezvous directory on the node, the timing barrier and the max over ranks go through the library's own communicator
-(osc_comm_allreduce_f64).
+(osc_comm_allreduce_f64).  If the communicator cannot be set up on every rank the run FAILS (exit code 3, no JSON line):
+N independent replicas are not a measurement of this job.  The JSON line carries `comm` = what the library's communicator
+reports (kind "rccl", world N) so that a reader can see RCCL really spanned N ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with these extra objects:
   roofline        : the operator apply (SpMM, the CG matvec): algorithmic bytes per launch / mean launch time (HIP
@@ -51,8 +53,8 @@ MFMA_F32_TFLOPS = 157.3  # fp32 matrix peak (the exact route's GEMM)
 # ---- rendezvous without a distributed runtime: a directory on the node -------------------------------------------
 class FileRendezvous:
     """Single-node exchange of small blobs between the ranks one launcher started (same parent process, same
-    MASTER_PORT): rank 0 publishes, everyone polls.  Used for the 128-byte communicator id and for the fallback
-    barrier when no communicator could be set up."""
+    MASTER_PORT): rank 0 publishes, everyone polls.  Used for the 128-byte communicator id and for agreeing on whether
+    every rank joined the communicator."""
 
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
@@ -115,7 +117,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("OSC_BENCH_ONE_DEVICE"):  # rehearsal on a one-GPU box: every rank on device 0 (RCCL then refuses
-        local_rank = 0                          # the communicator and the ranks fall back to independent replicas)
+        local_rank = 0                          # the communicator and the run must fail, see below)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -147,45 +149,47 @@ def main():
     if comm is not None:
         try:
             lat = Oscillink(Y, kneighbors=k, deterministic_k=False, device=local_rank, comm=comm)
-        except Exception as e:  # noqa: BLE001 -- a communicator that cannot be set up must not cost the whole measurement
+        except Exception as e:  # noqa: BLE001 -- reported by every rank below
             comm_error = f"{type(e).__name__}: {e}"
             lat = None
-    if launched:  # every rank takes the same branch: one failed rank sends all of them to independent replicas
+    if launched:  # every rank learns whether ALL ranks joined; if not, the job fails as a whole
         flags = rdzv.gather("comm_ok", (comm_error or "").encode())
         bad = [f.decode() for f in flags if f]
         if bad:
-            comm_error = comm_error or f"communicator setup failed on another rank: {bad[0]}"
             if lat is not None:
                 lat.close()
-                lat = None
+            rdzv.close()
+            print(f"bench.py: rank {rank}: the {world}-rank communicator could not be set up ({comm_error or bad[0]}); "
+                  "refusing to report independent replicas as a sharded run", file=sys.stderr, flush=True)
+            raise SystemExit(3)
     if lat is None:
         lat = Oscillink(Y, kneighbors=k, deterministic_k=False, device=local_rank)
-    replicas = launched and comm_error is not None
+    # what the library's communicator itself says (kind "rccl" / "loopback" / "none", ranks it spans)
+    c_rank, c_world, c_mode, c_kind = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.create_string_buffer(32)
+    lat._call("osc_comm_info", C.byref(c_rank), C.byref(c_world), C.byref(c_mode), c_kind, 32)
+    comm_info = {"kind": c_kind.value.decode(), "world": int(c_world.value), "rank": int(c_rank.value),
+                 "shard": "row" if c_mode.value == 1 else "column"}
+    if launched and (comm_info["kind"] != "rccl" or comm_info["world"] != world):
+        print(f"bench.py: rank {rank}: communicator reports {comm_info}, expected rccl over {world} ranks", file=sys.stderr,
+              flush=True)
+        raise SystemExit(3)
     lattice_create_ms = 1000.0 * (time.time() - t0)
     nnz, max_deg, dev_build_ms = lat.graph_stats()
     lat.set_query(psi)
 
-    barrier_round = [0]
-
     def sync_all():
         """barrier + device drain on every rank"""
         nat.lib().osc_device_synchronize(local_rank)
-        if launched and not replicas:
+        if launched:
             lat._call("osc_comm_allreduce_f64", None, 0, 0)  # drains the stream, then a barrier over the communicator
-        elif launched:
-            barrier_round[0] += 1
-            rdzv.gather(f"barrier{barrier_round[0]}", b"1")
         nat.lib().osc_device_synchronize(local_rank)
 
     def max_over_ranks(x: float) -> float:
         if not launched:
             return x
-        if not replicas:
-            v = (C.c_double * 1)(x)
-            lat._call("osc_comm_allreduce_f64", v, 1, 1)
-            return float(v[0])
-        barrier_round[0] += 1
-        return max(float(b.decode()) for b in rdzv.gather(f"max{barrier_round[0]}", repr(x).encode()))
+        v = (C.c_double * 1)(x)
+        lat._call("osc_comm_allreduce_f64", v, 1, 1)
+        return float(v[0])
 
     def step():
         lat.reset_U()
@@ -210,7 +214,7 @@ def main():
     c0, c1 = C.c_int32(0), C.c_int32(0)
     lat._call("osc_comm_shard", C.byref(c0), C.byref(c1))
     d_local = int(c1.value - c0.value)
-    n_local = N // world if (args.shard == "row" and launched and not replicas) else N  # rows this rank's operator covers
+    n_local = N // world if (args.shard == "row" and launched) else N  # rows this rank's operator covers
     # The dominant kernel is the operator apply inside the CG loop (the CG matvec).  The library times each apply (all
     # its launches: one at config 3, column slabs elsewhere) with one HIP-event pair on its own stream; the
     # initial-residual apply of a settle (extra rhs / r / p streams) is kept in a separate slot.  Algorithmic bytes of
@@ -230,7 +234,7 @@ def main():
     iters_mean = iters_total / args.steps
     # whole settle, algorithmic: (20 + 44 I) N D + 8 nnz (I + 1) bytes, all ranks together
     bytes_settle = (20.0 + 44.0 * iters_mean) * N * D + 8.0 * nnz * (iters_mean + 1.0)
-    settle_gbs = (world if replicas else 1) * bytes_settle / (ms_per_step * 1e-3) / 1e9  # all GPUs together
+    settle_gbs = bytes_settle / (ms_per_step * 1e-3) / 1e9  # all GPUs together (they settle ONE lattice)
 
     # The same launch against the bound that applies to a gather (profiles/r02_gather_bench.txt):
     # a CU retires one random 128-byte row per N clocks depending on the footprint an XCD gathers from -- measured with
@@ -254,24 +258,22 @@ def main():
 
     out = {
         "metric": "settles/sec",
-        # sharded: all ranks settle ONE lattice together; replicas (fallback only): every rank settles its own copy
-        "value": (world if replicas else 1) * args.steps / elapsed,
+        "value": args.steps / elapsed,  # all ranks settle ONE lattice together
         "unit": "settles/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak" if replicas else "strong",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"config3: N={N} D={D} k={k} fp32 settle(dt=1,max_iters={args.max_iters},tol={args.tol})",
                    "N": N, "D": D, "k": k, "nnz": nnz, "max_degree": max_deg,
-                   "parallelism": ("single" if not launched else
-                                   f"independent replicas x{world} (no communicator: {comm_error})" if replicas else
-                                   f"{args.shard}-sharded CG x{world}"),
+                   "parallelism": "single" if not launched else f"{args.shard}-sharded CG x{world}",
                    "cg_iters_per_settle": iters_mean, "residual": last["res"]},
+        "comm": comm_info,
         "lattice_create_ms": lattice_create_ms,  # first call in the process: HIP context + code objects + upload + build
         "graph_build_device_ms": dev_build_ms,
         "roofline": {"bound": "hbm",
@@ -292,7 +294,7 @@ def main():
     }
 
     if not args.no_extras:
-        out.update(extras(lat, N, D, args, launched and not replicas))
+        out.update(extras(lat, N, D, args, launched))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lat, Y, psi, args)
     if rank == 0:

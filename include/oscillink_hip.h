@@ -95,6 +95,14 @@ int osc_spmm_plan(osc_handle h, int32_t* launches, int32_t* slab_cols, int32_t* 
  * aid) */
 int osc_apply_info(osc_handle h, int32_t* src_blocks, int64_t* blocked_applies);
 
+/* the block-major copy of the graph the blocked matvec walks, built for `nb` source blocks (test / diagnostic aid; no
+ * reference counterpart): slot_col / slot_w [nb][N][4] = {neighbour row, W_ij} per (source block, row, slot), unused slots
+ * {first row of the block, 0}; rows whose edges exceed 4 nb slots list the rest in over_col / over_w[over_first[i] ..
+ * + over_count[i]) (at most over_cap entries in all).  Any output may be NULL.  OSC_E_UNSUPPORTED on a lattice stored in
+ * an internal row order. */
+int osc_get_blocked_copy(osc_handle h, int32_t nb, int32_t* slot_col, float* slot_w, int32_t* over_first,
+                         int32_t* over_count, int32_t* over_col, float* over_w, int32_t over_cap);
+
 /* CSR view of the graph for `.A`, `.L_sym`, `_signature()` (lattice.py:729-744) and export_state
  * (:582-624).  rowptr has N+1 entries; col/a/w have nnz entries, columns ascending within a row;
  * a = capped adjacency A_ij (> 0), w = A_ij / (sqrt_deg_i sqrt_deg_j); sqrt_deg has N entries.

@@ -114,6 +114,12 @@ def mutual_knn_graph(Y, k, *, deterministic=False, seed=None, dense=True, block=
         A[rows, idx] = val  # graph.py:60-62
         M = ((A > 0) & (A.T > 0)).astype(F32)  # graph.py:64
         return np.maximum(A * M, (A * M).T)  # graph.py:65
+    return mutual_graph_from_lists(N, idx, val)
+
+
+def mutual_graph_from_lists(N: int, idx: np.ndarray, val: np.ndarray):
+    """Sparse form of graph.py:60-65 from per-row top-k lists (idx (N,k), val (N,k) clipped at 0): the mutual mask and
+    the max-symmetrisation; CSR with sorted columns."""
     A = _csr_from_lists(N, idx, val)
     At = A.T.tocsr()
     mask = A.multiply(At > 0)  # entries of A where the transpose is also > 0

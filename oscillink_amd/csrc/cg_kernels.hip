@@ -41,6 +41,12 @@ __device__ __forceinline__ float4 ld4_stream(const float* p) {
   const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
   return make_float4(t.x, t.y, t.z, t.w);
 }
+// ... or an ordinary one, by a kernel-uniform flag (UpdateArgs::temporal)
+__device__ __forceinline__ float4 ld4_sel(const float* p, bool temporal) { return temporal ? ld4(p) : ld4_stream(p); }
+__device__ __forceinline__ void st4_sel(float* p, float4 v, bool temporal) {
+  if (temporal) st4(p, v);
+  else st4_stream(p, v);
+}
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 __device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
   return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
@@ -375,7 +381,6 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
   const int nb = a.nb, ng = a.groups;
   const int W8 = a.xs * CW * 8;  // rows one "deal" of groups covers (8 per gathering wave of the XCD)
   const int slice_rows = W8 * ng;
-  const int rpb = (a.N + nb - 1) / nb;  // rows per source block (launch_blocked_fill)
   const int nslab = a.c1 - a.c0 > xgrp * 32 ? ((a.c1 - a.c0 - xgrp * 32 + xgroups * 32 - 1) / (xgroups * 32)) : 0;
   const int per_slab = a.slices * nb, nphase = nslab * per_slab;
   auto phase = [&](int ph) {
@@ -707,6 +712,7 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, lr = lane % LPR;
   const int32_t ld = a.ld;
+  const bool tmp = a.temporal != 0;
   int coff[NCH];
   bool cok[NCH];
   float4 al[NCH], rr[NCH], rz[NCH];
@@ -728,14 +734,14 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
     for (int ch = 0; ch < NCH; ++ch) {
       if (!cok[ch]) continue;
       const size_t off = (size_t)row * ld + coff[ch];
-      float4 x = ld4_stream(a.X + off), p = ld4_stream(a.P + p_off(a, row, coff[ch])), r = ld4_stream(a.R + off);
-      const float4 ap = ld4_stream(a.AP + off);
+      float4 x = ld4_sel(a.X + off, tmp), p = ld4_sel(a.P + p_off(a, row, coff[ch]), tmp), r = ld4_sel(a.R + off, tmp);
+      const float4 ap = ld4_sel(a.AP + off, tmp);
       x.x = fmaf(p.x, al[ch].x, x.x); x.y = fmaf(p.y, al[ch].y, x.y);
       x.z = fmaf(p.z, al[ch].z, x.z); x.w = fmaf(p.w, al[ch].w, x.w);
       r.x = fmaf(-ap.x, al[ch].x, r.x); r.y = fmaf(-ap.y, al[ch].y, r.y);
       r.z = fmaf(-ap.z, al[ch].z, r.z); r.w = fmaf(-ap.w, al[ch].w, r.w);
-      st4_stream(a.X + off, x);
-      st4_stream(a.R + off, r);
+      st4_sel(a.X + off, x, tmp);
+      st4_sel(a.R + off, r, tmp);
       rr[ch] = mulacc4(r, r, rr[ch]);
       const float4 z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
       rz[ch] = mulacc4(r, z, rz[ch]);
@@ -752,6 +758,7 @@ __global__ __launch_bounds__(256) void k_update_p(const UpdateArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, lr = lane % LPR;
   const int32_t ld = a.ld;
+  const bool tmp = a.temporal != 0;
   int coff[NCH];
   bool cok[NCH];
   float4 be[NCH];
@@ -772,8 +779,8 @@ __global__ __launch_bounds__(256) void k_update_p(const UpdateArgs a) {
       if (!cok[ch]) continue;
       const size_t off = (size_t)row * ld + coff[ch];
       const size_t poff = p_off(a, row, coff[ch]);
-      const float4 r = ld4_stream(a.R + off);
-      float4 p = ld4_stream(a.P + poff);
+      const float4 r = ld4_sel(a.R + off, tmp);
+      float4 p = ld4_sel(a.P + poff, tmp);
       p.x = fmaf(p.x, be[ch].x, r.x * invMd); p.y = fmaf(p.y, be[ch].y, r.y * invMd);
       p.z = fmaf(p.z, be[ch].z, r.z * invMd); p.w = fmaf(p.w, be[ch].w, r.w * invMd);
       st4(a.P + poff, p);

@@ -71,48 +71,6 @@ __global__ void k_loop_reduce(T* __restrict__ acc, const T* __restrict__ src, si
   }
 }
 
-struct LoopGroup {
-  int world = 0;
-  std::mutex mu;
-  std::condition_variable cv;
-  int arrived = 0;
-  uint64_t generation = 0;
-  bool broken = false;
-  int joined = 0;
-  double timeout_s = 300.0;  // a rank may build a large lattice (N ~ 1M: seconds) before its first collective
-  struct Slot {
-    void* ptr = nullptr;
-    const std::vector<CommXfer>* list = nullptr;
-  };
-  std::vector<Slot> slots;
-
-  // every rank of the group passes, or every rank throws
-  void barrier() {
-    std::unique_lock<std::mutex> lk(mu);
-    if (broken) throw CommError("loopback communicator is broken (a rank failed or timed out earlier)");
-    const uint64_t gen = generation;
-    if (++arrived == world) {
-      arrived = 0;
-      ++generation;
-      cv.notify_all();
-      return;
-    }
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
-    while (generation == gen && !broken) {
-      if (cv.wait_until(lk, deadline) == std::cv_status::timeout && generation == gen) {
-        broken = true;  // a rank never reached this collective: mismatched call sequences
-        cv.notify_all();
-      }
-    }
-    if (generation == gen) throw CommError("loopback barrier timed out: the ranks' collective sequences differ");
-  }
-  void fail() {
-    std::lock_guard<std::mutex> lk(mu);
-    broken = true;
-    cv.notify_all();
-  }
-};
-
 std::mutex g_loop_mu;
 std::map<uint64_t, std::weak_ptr<LoopGroup>> g_loop_groups;
 std::atomic<uint64_t> g_loop_next{1};

@@ -14,22 +14,12 @@
 #include <vector>
 
 #include "common.hpp"
+#include "loop_group.hpp"  // CommError, CommXfer, the loopback backend's host barrier
 
 namespace osc {
 
-struct CommError : std::runtime_error {
-  using std::runtime_error::runtime_error;
-};
-
 enum CommDType { COMM_F32 = 0, COMM_F64 = 1, COMM_I32 = 2 };
 enum CommOp { COMM_SUM = 0, COMM_MAX = 1 };
-
-// one piece of a grouped transfer: `bytes` at `ptr`; peer = destination (send), source (recv) or root (broadcast)
-struct CommXfer {
-  void* ptr;
-  size_t bytes;
-  int peer;
-};
 
 class Comm {
  public:

@@ -96,7 +96,7 @@ struct GraphView {
 // edge that finds the slot row of its block full sits in a later block's free slots instead (k_blk_fill), and what fits
 // nowhere is in over[rest[row].x .. + rest[row].y), added after the blocks (so such rows' sums are formed in a different
 // order than k_spmm's: same terms, last-bit differences).
-constexpr int OSC_MAX_SRC_BLOCKS = 16;
+constexpr int OSC_MAX_SRC_BLOCKS = 32;  // (register arrays of this size in k_blk_count / k_blk_fill)
 constexpr int OSC_BLK_SLOTS = 4;
 struct BlockedView {
   const int2* slots;    // [nb][N][OSC_BLK_SLOTS]
@@ -175,6 +175,10 @@ struct UpdateArgs {
   const float* gate;  // see SpmmArgs
   float gate_tol;
   int64_t pblk;  // != 0: P is stored slab-major with this many rows per slab (see SpmmArgs)
+  // != 0: the solve's five N x window arrays fit the Infinity Cache together (a per-rank window of a sharded solve, a
+  // mid-size lattice): X, R, AP are then read and written with ordinary loads / stores so that the next kernel finds them
+  // there; 0: streamed nontemporally (they would only push the gathered operand out).
+  int32_t temporal;
 };
 
 struct Gate {

@@ -11,6 +11,7 @@
 
 #include "../../include/oscillink_hip.h"
 #include "common.hpp"
+#include "host_logic.hpp"
 #include "comm.hpp"
 #include "knn.hpp"
 #include "knn_gemm.hpp"
@@ -227,9 +228,10 @@ struct osc_lattice {
   int blk_nb = 0;          // blocks of the copy held (0 = none / stale)
   int spmm_blocked = -1;   // -1 by lattice size, 0 off, > 0 = that many source blocks (OSC_SPMM_BLOCKED)
   double blk_mb = 2.0;     // smallest slab (N x 128 B, MiB) the blocked apply is chosen for (OSC_BLK_MB)
-  double blk_edges = 3.3;  // edges of a row per source block the block count aims at (OSC_BLK_EDGES)
+  double blk_edges = 0.0;  // edges of a row per source block the block count aims at; 0 = by lattice size: 3.3 / 2.4 (OSC_BLK_EDGES)
   int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
   int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
+  double temporal_mb = 200.0;  // largest solve (5 arrays x N x window) whose update kernels use ordinary instead of nontemporal accesses (OSC_TEMPORAL_MB)
   bool blk_init = true;    // the initial residual goes through the blocked matvec as well (OSC_BLK_INIT=0: plain INIT apply)
   int64_t blk_applies = 0; // blocked matvecs enqueued since creation
   int64_t small_solves = 0;
@@ -942,24 +944,9 @@ int32_t auto_slab(const L& h, int32_t ncols) {
 // groups, the XCDs of a group split the rows.  Needs 128-byte-aligned rows and the slabs in flight (groups x N x 128 B)
 // inside the Infinity Cache: measured 1.11 vs 1.26 ms per apply at N = 100k, D = 768; no gain at N = 200k, D = 1536 with
 // 8 slabs (205 MB) in flight, 4 % with 4 (xs_groups_for); 36 % slower at N = 1M, D = 384.
-int xs_groups(int32_t ncols, int cap = 8) {
-  const int nsl = (ncols + 31) / 32;
-  const int g = (nsl % 8 == 0) ? 8 : (nsl % 4 == 0) ? 4 : (nsl % 2 == 0) ? 2 : 1;
-  return std::min(g, cap);
-}
-// slab groups (= slabs in flight) of the XCD-affine apply: the natural count gcd(8, slabs), halved until the slabs in
-// flight fit 128 MiB of the Infinity Cache; 0 = the mode does not pay (measured: shrinking below 4 groups loses to the
-// general path -- config 5's shape 56.4 ms general, 54.2 at 4 groups, 57.1 at 2, 60.7 at 1; config 4's shape loses at
-// every count).
-int xs_groups_for(const L& h, int32_t ncols) {
-  const int natural = xs_groups(ncols, h.xs_groups_cap);
-  int g = natural;
-  const double cap_bytes = 128.0 * 1024 * 1024;
-  while (g > 1 && (double)g * (double)h.N * 128.0 > cap_bytes) g >>= 1;
-  if ((double)g * (double)h.N * 128.0 > cap_bytes) return 0;
-  if (g != natural && g < 4) return 0;
-  return g;
-}
+// (the counts themselves: host_logic.hpp)
+int xs_groups(int32_t ncols, int cap = 8) { return host::xs_groups(ncols, cap); }
+int xs_groups_for(const L& h, int32_t ncols) { return host::xs_groups_for(h.N, ncols, h.xs_groups_cap); }
 int xs_plan(const L& h, int32_t ncols, int grid) {
   if (grid < 8 || (grid & 7) != 0) return 0;
   const int nb = std::max(1, std::min(grid / 8, h.xs_nb > 0 ? h.xs_nb : 96));
@@ -978,16 +965,17 @@ int blocked_plan(const L& h, bool with_path) {
       (int64_t)h.N * h.ld * 4 >= ((int64_t)1 << 32))
     return 0;
   if (h.spmm_blocked > 0) return std::min(h.spmm_blocked, OSC_MAX_SRC_BLOCKS);
-  // as many blocks as give a row ~3.3 edges into each (4 slots per (row, block); an edge that finds its block's slot row
-  // full moves to a later block's, so the rows should be nearly but not quite full; measured at N = 100k, D = 768, k = 32:
-  // 4 slots x 9 blocks 0.59 ms, 5 x 7 0.60, 6 x 6 0.61)
+  // block count from the mean degree and the lattice size (host_logic.hpp: blocked_edges_per_block); OSC_BLK_EDGES
+  // overrides the edges a row should have per block
   const double mean_deg = h.N > 0 ? (double)h.nnz / (double)h.N : 0.0;
-  const int nb = (int)std::min<double>(OSC_MAX_SRC_BLOCKS, std::max(2.0, std::floor(mean_deg / h.blk_edges + 0.5)));
+  const double e = h.blk_edges > 0.0 ? h.blk_edges : host::blocked_edges_per_block(h.N);
+  const int nb = host::blocked_block_count(mean_deg, e, OSC_MAX_SRC_BLOCKS);
   if (h.spmm_blocked == -2) return nb;  // "whenever possible" (experiments)
   // ... and wherever the XCD-affine slab mode itself runs from a 2 MiB slab (N = 16384) on.  Measured against the plain
   // apply (k = 32 unless noted): N = 20k x 768 -7 %, 35k x 768 -26 %, 40k x 256 (k 8) -25 %, 50k x 512 -30 %, 65k x 256
   // (k 16) -30 %, 60k x 1024 (k 24) -29 %, 80k x 768 -39 %, 100k x 768 -39 % (k 16, D 384: -33 %; k 48: -47 %; k 64:
-  // -45 %), 100k x 128 (k 16) -35 %, 110k x 768 -40 %, 130k x 256 -43 %.
+  // -45 %), 100k x 128 (k 16) -35 %, 110k x 768 -40 %, 130k x 256 -43 %; round 3: 160k x 768 -31 %, 200k x 768 -37 %
+  // (k 64: -46 %), 260k x 768 -22 % (k 64: -37 %).
   const double slab = (double)h.N * 128.0;
   if (slab < h.blk_mb * 1024.0 * 1024.0) return 0;
   return nb;
@@ -1002,7 +990,11 @@ BlockedView blocked_view(L& h, int nb) {
     unsigned over = 0;
     HIP_CHECK(hipMemcpyAsync(&over, cnt.p, 4, hipMemcpyDeviceToHost, h.stream));
     sync(h);
-    const size_t nslots = (size_t)nb * h.N * OSC_BLK_SLOTS, npad = (size_t)8192 * OSC_BLK_SLOTS;  // the apply's list copies run up to a deal of rows past the end
+    // the apply's list wave copies whole row groups: up to 8 x gather-waves slot rows past the lattice's end
+    // (host_logic.hpp: blocked_list_extent <= N - 1 + 8 x gather waves, swept in tests/host_logic)
+    constexpr size_t kPadRows = 8192;
+    if ((size_t)blocked_gather_waves() * 8 > kPadRows) throw std::runtime_error("blocked graph copy: padding too small");
+    const size_t nslots = (size_t)nb * h.N * OSC_BLK_SLOTS, npad = kPadRows * OSC_BLK_SLOTS;
     h.blk_slots.alloc(nslots + npad);
     HIP_CHECK(hipMemsetAsync(h.blk_slots.p + nslots, 0, npad * sizeof(int2), h.stream));  // {row 0, 0.0f}
     h.blk_over.alloc((size_t)over + 1);
@@ -1160,8 +1152,8 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   const size_t nslots = (size_t)max_iters + 2;
   ensure_ctrl(h, nslots);
   uint32_t* done_ctr = h.res_bits.p + h.res_bits.n / 2;  // second half of the control array
-  HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, nslots * 4, h.stream));
-  HIP_CHECK(hipMemsetAsync(done_ctr, 0, nslots * 4, h.stream));
+  // (one fill for both halves: each fill is a launch of its own, ~5 us in front of a solve that may take 100)
+  HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, (h.res_bits.n / 2 + nslots) * 4, h.stream));
   // Single GPU: the last workgroup of each iteration's beta reduction writes the residual into host-mapped memory and
   // the host polls that word (no 4-byte copy, event record and event wait per iteration).  Under a communicator the
   // residual first goes through the all-reduce, so the copy + event path stays.
@@ -1214,16 +1206,14 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       ba.c0 = b.c0;
       ba.c1 = b.c1;
       ba.nb = nb;
-      // workgroups per XCD: what is resident at once
-      ba.xs = std::min(std::min(grid / 8, 128), std::max(1, h.blk_resident));
+      // workgroups per XCD (what is resident at once), slab groups, row groups per wave, destination slices
       const int xg = xs_groups_for(h, b.c1 - b.c0);
-      ba.xs_groups = xg > 0 ? xg : xs_groups(b.c1 - b.c0, h.xs_groups_cap);
-      // slices of the destination rows: as few as the row groups a wave can hold allow, evenly filled
-      const int64_t gmax = blocked_groups_max();
-      const int64_t rows = (h.N + 8 / ba.xs_groups - 1) / (8 / ba.xs_groups), per_group = (int64_t)ba.xs * blocked_gather_waves() * 8;
-      const int64_t nsl = (rows + per_group * gmax - 1) / (per_group * gmax);
-      ba.slices = (int32_t)nsl;
-      ba.groups = (int32_t)std::max<int64_t>(1, (rows + nsl * per_group - 1) / (nsl * per_group));
+      const host::BlockedGeom geom = host::blocked_geometry(h.N, xg > 0 ? xg : xs_groups(b.c1 - b.c0, h.xs_groups_cap), grid,
+                                                           h.blk_resident, blocked_groups_max(), blocked_gather_waves());
+      ba.xs = geom.xs;
+      ba.xs_groups = geom.xs_groups;
+      ba.slices = geom.slices;
+      ba.groups = geom.groups;
       if (with_path && op.cP != 0.f) {  // the chain prior's few rows: a small launch behind every blocked apply
         cf.X = b.P;
         cf.OUT = b.AP;
@@ -1283,6 +1273,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   launch_reduce_init(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.stream);
   UpdateArgs ua{};
   ua.pblk = pblk ? h.N : 0;
+  ua.temporal = 5.0 * (double)h.N * (double)(b.c1 - b.c0) * 4.0 <= h.temporal_mb * 1048576.0;
   ua.X = b.X;
   ua.R = b.R;
   ua.P = b.P;
@@ -1467,13 +1458,7 @@ void allreduce_sums(L& h, double* buf, size_t n) {
 void build_halo_plan(L& h) {
   L::HaloPlan& hp = h.halo;
   const int G = h.world, me = h.rank;
-  auto lo = [&](int r) { return h.N * r / G; };
-  auto owner = [&](int64_t row) {  // rank whose block [N r / G, N (r+1) / G) holds `row`
-    int r = (int)std::min<int64_t>(G - 1, (row * G + G - 1) / std::max<int64_t>(1, h.N));
-    while (r > 0 && row < lo(r)) --r;
-    while (r + 1 < G && row >= lo(r + 1)) ++r;
-    return r;
-  };
+  auto lo = [&](int r) { return host::row_lo(h.N, G, r); };
   const int64_t r0 = lo(me), r1 = lo(me + 1), nloc = r1 - r0;
   std::vector<int32_t> col((size_t)nloc * h.width), deg((size_t)nloc);
   if (nloc > 0) {
@@ -1481,59 +1466,15 @@ void build_halo_plan(L& h) {
     HIP_CHECK(hipMemcpyAsync(deg.data(), h.deg.p + r0, (size_t)nloc * 4, hipMemcpyDeviceToHost, h.stream));
   }
   sync(h);
-  std::vector<std::vector<int32_t>> need((size_t)G), give((size_t)G);
-  std::vector<char> need_mark((size_t)h.N, 0);
-  std::vector<int> give_last((size_t)G);
-  auto edge = [&](int64_t i, int64_t j) {  // my row i references row j
-    if (j >= r0 && j < r1) return;
-    if (!need_mark[(size_t)j]) {
-      need_mark[(size_t)j] = 1;
-      need[(size_t)owner(j)].push_back((int32_t)j);
-    }
-  };
-  for (int64_t i = r0; i < r1; ++i) {
-    std::fill(give_last.begin(), give_last.end(), 0);
-    auto touch = [&](int64_t j) {
-      edge(i, j);
-      if (j >= r0 && j < r1) return;
-      const int q = owner(j);
-      if (!give_last[(size_t)q]) {
-        give_last[(size_t)q] = 1;
-        give[(size_t)q].push_back((int32_t)i);
-      }
-    };
-    const int32_t* ci = col.data() + (size_t)(i - r0) * h.width;
-    for (int e = 0; e < deg[(size_t)(i - r0)]; ++e) touch(ci[e]);
-  }
-  if (h.chain_present && h.lamP > 0.0f) {  // path graph: consecutive chain nodes (graph.py:96-111), device row ids
+  std::vector<std::pair<int64_t, int64_t>> chain_edges;  // path graph: consecutive chain nodes (graph.py:96-111), device row ids
+  if (h.chain_present && h.lamP > 0.0f) {
     auto id = [&](int32_t v) { return permuted(h) ? h.inv_h[(size_t)v] : v; };
-    std::vector<std::vector<int32_t>> extra_give((size_t)G);
-    for (size_t t = 0; t + 1 < h.chain_nodes.size(); ++t) {
-      const int64_t a = id(h.chain_nodes[t]), b = id(h.chain_nodes[t + 1]);
-      for (int dir = 0; dir < 2; ++dir) {
-        const int64_t i = dir ? b : a, j = dir ? a : b;
-        if (i < r0 || i >= r1 || (j >= r0 && j < r1)) continue;
-        edge(i, j);
-        extra_give[(size_t)owner(j)].push_back((int32_t)i);
-      }
-    }
-    for (int q = 0; q < G; ++q)
-      for (int32_t i : extra_give[(size_t)q]) give[(size_t)q].push_back(i);
+    for (size_t t = 0; t + 1 < h.chain_nodes.size(); ++t) chain_edges.emplace_back(id(h.chain_nodes[t]), id(h.chain_nodes[t + 1]));
   }
-  hp.give_off.assign((size_t)G + 1, 0);
-  hp.need_off.assign((size_t)G + 1, 0);
-  std::vector<int32_t> gi, ni;
-  for (int q = 0; q < G; ++q) {
-    auto& g = give[(size_t)q];
-    std::sort(g.begin(), g.end());
-    g.erase(std::unique(g.begin(), g.end()), g.end());
-    auto& n = need[(size_t)q];
-    std::sort(n.begin(), n.end());
-    gi.insert(gi.end(), g.begin(), g.end());
-    ni.insert(ni.end(), n.begin(), n.end());
-    hp.give_off[(size_t)q + 1] = (int64_t)gi.size();
-    hp.need_off[(size_t)q + 1] = (int64_t)ni.size();
-  }
+  host::HaloLists hl = host::build_halo_lists(h.N, G, me, h.width, col.data(), deg.data(), chain_edges);
+  hp.give_off = hl.give_off;
+  hp.need_off = hl.need_off;
+  const std::vector<int32_t>&gi = hl.give_idx, &ni = hl.need_idx;
   hp.give_rows = (int64_t)gi.size();
   hp.need_rows = (int64_t)ni.size();
   // counts of every (rank, peer) pair, all-gathered: row r = [need from 0..G-1 | give to 0..G-1] of rank r
@@ -1548,19 +1489,10 @@ void build_halo_plan(L& h) {
   h.comm->allgather(cnt_d.p, (size_t)2 * G * 4, h.stream);
   HIP_CHECK(hipMemcpyAsync(all.data(), cnt_d.p, all.size() * 4, hipMemcpyDeviceToHost, h.stream));
   sync(h);
-  hp.need_rows_max = 0;
-  bool full = false;
-  for (int r = 0; r < G; ++r) {
-    int64_t tot = 0;
-    for (int q = 0; q < G; ++q) {
-      tot += all[(size_t)r * 2 * G + q];
-      if (all[(size_t)r * 2 * G + q] != all[(size_t)q * 2 * G + G + r])  // r needs from q == q gives to r
-        throw CommError("halo plan: need / give counts of a rank pair differ (asymmetric lattice graph?)");
-    }
-    hp.need_rows_max = std::max(hp.need_rows_max, tot);
-    const int64_t remote = h.N - (lo(r + 1) - lo(r));
-    if (remote > 0 && (double)tot > 0.7 * (double)remote) full = true;  // packing would move ~everything anyway
-  }
+  const host::HaloDecision dec = host::halo_decide(h.N, G, all);
+  if (!dec.consistent) throw CommError("halo plan: need / give counts of a rank pair differ (asymmetric lattice graph?)");
+  hp.need_rows_max = dec.need_rows_max;
+  bool full = dec.full;
   const char* fe = getenv("OSC_HALO");  // "full" | "lists": force one exchange form (tests, A/B); same on every rank
   const int force = fe ? (!strcmp(fe, "full") ? 1 : !strcmp(fe, "lists") ? 2 : 0) : 0;
   if (force == 1) full = true;
@@ -1858,6 +1790,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_BLK_MB")) h->blk_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_BLK_EDGES")) h->blk_edges = std::max(0.5, atof(e));
     if (const char* e = getenv("OSC_BLK_INIT")) h->blk_init = atoi(e) != 0;
+    if (const char* e = getenv("OSC_TEMPORAL_MB")) h->temporal_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
     if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
@@ -1866,9 +1799,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_FAKE_COL_SHARD")) {  // "r/w": work on rank r's column slab of w, no communicator
       int r = 0, w = 1;                                   // (measurement hook: one rank's share of a column-sharded solve)
       if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) {
-        const int32_t q = h->dcols / 4;
-        h->c0 = (int32_t)((int64_t)q * r / w) * 4;
-        h->c1 = (int32_t)((int64_t)q * (r + 1) / w) * 4;
+        std::tie(h->c0, h->c1) = host::column_shard(h->dcols, r, w);
         if (h->c1 <= h->c0) throw Invalid("OSC_FAKE_COL_SHARD: more ranks than 4-column groups");
       }
     }
@@ -1937,6 +1868,41 @@ int osc_apply_info(osc_handle h, int32_t* src_blocks, int64_t* blocked_applies) 
   return guarded(h, [&](L& l) {
     if (src_blocks) *src_blocks = l.blk_last;
     if (blocked_applies) *blocked_applies = l.blk_applies;
+  });
+}
+
+int osc_get_blocked_copy(osc_handle h, int32_t nb, int32_t* slot_col, float* slot_w, int32_t* over_first, int32_t* over_count,
+                         int32_t* over_col, float* over_w, int32_t over_cap) {
+  return guarded(h, [&](L& l) {
+    require_graph(l);
+    if (nb < 1 || nb > OSC_MAX_SRC_BLOCKS) throw Invalid("osc_get_blocked_copy: 1 <= nb <= 32");
+    if (permuted(l)) throw Unsupported("osc_get_blocked_copy: the lattice is stored in an internal row order");
+    const BlockedView bv = blocked_view(l, nb);
+    const size_t ns = (size_t)nb * l.N * OSC_BLK_SLOTS;
+    std::vector<int2> hs(ns), hr((size_t)l.N);
+    HIP_CHECK(hipMemcpyAsync(hs.data(), bv.slots, ns * sizeof(int2), hipMemcpyDeviceToHost, l.stream));
+    HIP_CHECK(hipMemcpyAsync(hr.data(), bv.rest, (size_t)l.N * sizeof(int2), hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+    int64_t total = 0;
+    for (int64_t i = 0; i < l.N; ++i) total = std::max<int64_t>(total, (int64_t)hr[(size_t)i].x + hr[(size_t)i].y);
+    std::vector<int2> ho((size_t)total);
+    if (total > 0) {
+      HIP_CHECK(hipMemcpyAsync(ho.data(), bv.over, (size_t)total * sizeof(int2), hipMemcpyDeviceToHost, l.stream));
+      sync(l);
+    }
+    for (size_t t = 0; t < ns; ++t) {
+      if (slot_col) slot_col[t] = hs[t].x;
+      if (slot_w) std::memcpy(slot_w + t, &hs[t].y, 4);
+    }
+    for (int64_t i = 0; i < l.N; ++i) {
+      if (over_first) over_first[i] = hr[(size_t)i].x;
+      if (over_count) over_count[i] = hr[(size_t)i].y;
+    }
+    if (total > over_cap && (over_col || over_w)) throw Invalid("osc_get_blocked_copy: over_cap too small");
+    for (int64_t t = 0; t < total; ++t) {
+      if (over_col) over_col[t] = ho[(size_t)t].x;
+      if (over_w) std::memcpy(over_w + t, &ho[(size_t)t].y, 4);
+    }
   });
 }
 
@@ -2035,50 +2001,16 @@ int osc_edge_prefix(osc_handle h, int32_t cap, int64_t* pairs, int32_t* n_out) {
 
 int osc_set_csr(osc_handle h, const int64_t* rowptr, const int32_t* col, const float* a) {
   return guarded(h, [&](L& l) {
-    if (!rowptr || rowptr[0] != 0) throw Invalid("osc_set_csr: rowptr[0] must be 0");
-    int64_t width = 1;
-    for (int64_t i = 0; i < l.N; ++i) {
-      if (rowptr[i + 1] < rowptr[i]) throw Invalid("osc_set_csr: rowptr must be non-decreasing");
-      width = std::max(width, rowptr[i + 1] - rowptr[i]);
+    // validated and packed on the host (host_logic.hpp: sorted columns, no diagonal, no duplicates, symmetric)
+    host::PackedEll pk;
+    try {
+      pk = host::pack_csr(l.N, rowptr, col, a);
+    } catch (const host::InvalidArg& e) {
+      throw Invalid(e.what());
     }
-    const int64_t nnz = rowptr[l.N];
-    if (nnz > 0 && (!col || !a)) throw Invalid("osc_set_csr: col / a missing");
-    const size_t W = (size_t)std::max<int64_t>(1, width);  // validated on the host before the handle is touched
-    const size_t n = (size_t)l.N * W;
-    std::vector<int32_t> hc(n, 0), hd((size_t)l.N, 0);
-    std::vector<float> ha(n, 0.f);
-    // The graph contract of every consumer (GraphView): columns ascending within a row (the reference's argwhere order
-    // for _signature, the first-max tie-break of the null points), no diagonal, no duplicates, symmetric (SPD operator).
-    std::vector<std::pair<int32_t, float>> ent;
-    for (int64_t i = 0; i < l.N; ++i) {
-      ent.clear();
-      for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
-        if (col[p] < 0 || col[p] >= l.N) throw Invalid("osc_set_csr: column index out of range");
-        if (!(a[p] > 0.f)) continue;  // only strictly positive weights are edges (graph.py:64)
-        if (col[p] == i) throw Invalid("osc_set_csr: diagonal entry (the lattice adjacency has a zero diagonal)");
-        ent.emplace_back(col[p], a[p]);
-      }
-      std::sort(ent.begin(), ent.end());
-      for (size_t e = 1; e < ent.size(); ++e)
-        if (ent[e].first == ent[e - 1].first) throw Invalid("osc_set_csr: duplicate column within a row");
-      for (size_t e = 0; e < ent.size(); ++e) {
-        hc[(size_t)i * W + e] = ent[e].first;
-        ha[(size_t)i * W + e] = ent[e].second;
-      }
-      hd[(size_t)i] = (int32_t)ent.size();
-    }
-    for (int64_t i = 0; i < l.N; ++i) {  // symmetry: (j, i) exists with the same weight
-      const int32_t* ci = hc.data() + (size_t)i * W;
-      for (int e = 0; e < hd[(size_t)i]; ++e) {
-        const int32_t j = ci[e];
-        const int32_t* cj = hc.data() + (size_t)j * W;
-        const int32_t* hit = std::lower_bound(cj, cj + hd[(size_t)j], (int32_t)i);
-        if (hit == cj + hd[(size_t)j] || *hit != i) throw Invalid("osc_set_csr: adjacency is not symmetric (missing transposed edge)");
-        const float x = ha[(size_t)i * W + e], y = ha[(size_t)j * W + (hit - cj)];
-        if (std::fabs(x - y) > 1e-6f * std::max(std::fabs(x), std::fabs(y)))
-          throw Invalid("osc_set_csr: adjacency is not symmetric (A_ij != A_ji)");
-      }
-    }
+    const size_t W = (size_t)pk.width, n = (size_t)l.N * W;
+    const std::vector<int32_t>&hc = pk.col, &hd = pk.deg;
+    const std::vector<float>& ha = pk.a;
     // everything above ran on the host: a refused graph leaves the handle untouched
     if (l.have_graph) drop_order(l);  // the injected ids are API ids
     else {
@@ -2867,11 +2799,7 @@ int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world)
     l.comm.reset();
     l.rank = rank;
     l.world = world;
-    // column slabs in units of 4 floats, as even as possible
-    const int32_t q = l.dcols / 4;
-    const int32_t lo = (int32_t)((int64_t)q * rank / world), hi = (int32_t)((int64_t)q * (rank + 1) / world);
-    l.c0 = lo * 4;
-    l.c1 = hi * 4;
+    std::tie(l.c0, l.c1) = host::column_shard(l.dcols, rank, world);  // slabs in units of 4 floats, as even as possible
     if (l.shard_mode == 1) {  // row-sharded CG: every rank works on all columns of its row block
       l.c0 = 0;
       l.c1 = l.dcols;

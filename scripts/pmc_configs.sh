@@ -1,13 +1,14 @@
 #!/bin/bash
 # PMC passes (separate runs, kernel trace only beside them) of one settle loop at config 4's and config 5's shapes on one
-# GPU: HBM/fabric bytes and L2 hit rate of the operator apply there.  Usage (on the GPU box): bash scripts/pmc_configs.sh
+# GPU: HBM/fabric bytes and L2 hit rate of the operator apply there.  Usage (on the GPU box): bash scripts/pmc_configs.sh [tag]
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r02_cfg
+TAG0=${1:-r03}
+OUT=$ROOT/gpurun_out/${TAG0}_cfg
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for CFG in "1000000 384 16" "200000 1536 64"; do
-  TAG=$(echo $CFG | tr ' ' 'x')
+for CFG in "1000000 384 16" "200000 1536 64 chain"; do
+  TAG=$(echo $CFG | cut -d' ' -f1-3 | tr ' ' 'x')
   for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
     N=$(echo $C | tr ' ' '_')
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${TAG}_$N -- python3 $ROOT/scripts/exp/settle_loop.py $CFG > $OUT/${TAG}_$N.log 2>&1
