@@ -156,6 +156,8 @@ struct SpmmArgs {
   // contiguous N x 128 B range (even spread over the L2 channels; no 3 KB row stride).  xblk != 0: the operand X is
   // stored that way (value = rows per slab = N); pblk != 0: INIT writes its P output that way.
   int64_t xblk, pblk;
+  // != 0: the rows are stored in a local order (maybe_reorder): launch the variant with more gathers in flight per row
+  int32_t deep;
 };
 
 struct UpdateArgs {

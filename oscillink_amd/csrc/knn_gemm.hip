@@ -25,6 +25,13 @@
 //            exact fp32 and proves (unchanged contract: every left-out column has fp16 score <= the list's last).
 //            A row with an overflowed split or fewer than keep candidates goes to the exact kernel's row list.
 // The neighbour lists that come out are therefore those of the exact fp32 scoring, as with the other routes.
+//
+// D <= 384 (K depth 6): a wave's panel is only 96 registers, so it carries TWO row groups -- its 32 rows of two
+// consecutive 128-row blocks (NRG = 2: 192 panel registers, eight 32 x 32 accumulators).  Every B fragment read from LDS
+// then feeds two MFMAs instead of one: with one row group the LDS reads and the MFMAs of a K step take the same number
+// of cycles (4 waves x 16 KB / 128 B per clk = 512 clk = 16 MFMAs x 32 clk), which caps that shape near 50-60 % of the
+// matrix pipe whatever else is hidden.  Hit lists, thresholds and the select stay per (128-row block, wave): nothing
+// outside k_panel knows about the pairing.
 #include "knn_gemm.hpp"
 
 #include <algorithm>
@@ -62,8 +69,9 @@ struct PanelArgs {
   int32_t group_tiles, ngroups;  // MODE 0: tile maxima are folded over groups of consecutive sample tiles
   float* tmax;         // MODE 0: [npad][ngroups]
   const float* tau;    // MODE 1: [npad]
-  uint2* hit_list;     // MODE 1: [(item * 4 + wave) * HB_CAP + e] = {local row << 27 | column, score bits}
-  int32_t* hit_cnt;    // MODE 1: [item * 4 + wave] hits of that wave in that item (may exceed HB_CAP: overflow)
+  uint2* hit_list;     // MODE 1: [(list * 4 + wave) * hit_cap + e] = {local row << 27 | column, score bits}; list = split * rb_count + (row block - rb_begin)
+  int32_t* hit_cnt;    // MODE 1: [list * 4 + wave] hits of that wave in that list (may exceed hit_cap: overflow)
+  int32_t hit_cap;     // entries per list: HB_CAP / row groups per wave
   unsigned* queue;
 };
 
@@ -78,12 +86,15 @@ struct PanelArgs {
                  : "memory");                                                                                        \
   } while (0)
 
-template <int NKT, int MODE>
+template <int NKT, int MODE, int NRG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_panel(const PanelArgs a) {
   static_assert(NKT % RING == 0, "a tile's K steps must be whole laps of the ring (compile-time stage indices)");
+  static_assert(NRG == 1 || NRG == 2, "row groups per wave");
   constexpr int NK16 = NKT * 4;
+  constexpr int HCAP = HB_CAP / NRG;  // entries of one (row group, wave) hit list
   extern __shared__ __attribute__((aligned(1024))) float lds[];  // RING stages x [128 rows][32 float slots] (+2 KB lead)
   __shared__ int s_item;
+  __shared__ __attribute__((aligned(16))) float s_tau[4][NRG][2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int frow = lane >> 3;
@@ -94,7 +105,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int s = 0; s < 4; ++s) rd[s] = (unsigned)(l31 * 128 + (((2 * s + h) ^ swz) * 16));
   const char* ldsc = reinterpret_cast<const char*>(lds) + 2048;
-  const int nitems = a.rb_count * a.S;
+  const int nsets = (a.rb_count + NRG - 1) / NRG;  // work item = (column split, set of NRG consecutive row blocks)
+  const int nitems = nsets * a.S;
   const size_t ldh = (size_t)a.ldh;
   const size_t tile_stride = (size_t)128 * ldh;  // halfs between column tiles
   for (;;) {
@@ -104,28 +116,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     if (item >= nitems) break;
     // items of one split are consecutive: the workgroups that start together sweep the same column tiles together
-    const int split = item / a.rb_count, rb = a.rb_begin + (item - split * a.rb_count);
+    const int split = item / nsets, rbi0 = (item - split * nsets) * NRG;  // first row block of the set, relative to rb_begin
     const int t0 = split * a.tiles_per_split, t1 = min(a.ntileB, t0 + a.tiles_per_split);
+    int rbv[NRG];     // row block of row group r (the last set of an odd count repeats its first block: computed, not kept)
+    bool rok[NRG];
+#pragma unroll
+    for (int r = 0; r < NRG; ++r) {
+      rok[r] = rbi0 + r < a.rb_count;
+      rbv[r] = a.rb_begin + (rok[r] ? rbi0 + r : rbi0);
+    }
     if (t0 >= t1) {  // an empty column split (the planner never makes one; OSC_KNN_MODE=panel can): no hits, but say so
-      if (MODE == 1 && lane == 0) a.hit_cnt[item * 4 + wave] = 0;
+      if (MODE == 1 && lane == 0) {
+#pragma unroll
+        for (int r = 0; r < NRG; ++r)
+          if (rok[r]) a.hit_cnt[((size_t)split * a.rb_count + rbi0 + r) * 4 + wave] = 0;
+      }
       continue;
     }
-    const int row = rb * 128 + 32 * wave + l31;
-    half8 areg[NK16];
+    half8 areg[NRG][NK16];
 #pragma unroll
-    for (int i = 0; i < NK16; ++i) areg[i] = *(const half8*)(a.A + (size_t)row * ldh + i * 16 + h * 8);
-    // per query-row register g of this half-wave: local row (g & 3) + 8 (g >> 2) + 4 h of the wave's 32
-    float taug[16];  // MODE 1: thresholds; MODE 0: running maxima of the current tile group
-    int wcnt = 0;    // MODE 1: hits this wave has appended in this item (wave-uniform)
-    uint2* hitbuf = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds) + PANEL_LDS) + wave * HB_CAP;
-    const int grow0 = rb * 128 + 32 * wave + 4 * h;
-    if constexpr (MODE == 0) {
+    for (int r = 0; r < NRG; ++r) {
+      const int row = rbv[r] * 128 + 32 * wave + l31;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) taug[g] = -3.0e38f;
+      for (int i = 0; i < NK16; ++i) areg[r][i] = *(const half8*)(a.A + (size_t)row * ldh + i * 16 + h * 8);
     }
-    if constexpr (MODE == 1) {
+    // per query-row register g of this half-wave: local row (g & 3) + 8 (g >> 2) + 4 h of the wave's 32
+    float taug[MODE == 0 ? NRG : 1][16];  // MODE 0: running maxima of the current tile group
+    // MODE 1: the rows' thresholds wait in LDS, in the order the hit test reads them ([wave][row group][half][16]), and are
+    // fetched into registers per tile behind the K loop: held in registers (16 per row group) next to two row groups'
+    // accumulators and the 192-register panel they made hipcc spill 43 registers
+    int wcnt[NRG];        // MODE 1: hits this wave has appended to its list of row group r in this item (wave-uniform)
+    uint2* hitbuf[NRG];
 #pragma unroll
-      for (int g = 0; g < 16; ++g) taug[g] = a.tau[grow0 + (g & 3) + 8 * (g >> 2)];
+    for (int r = 0; r < NRG; ++r) {
+      wcnt[r] = 0;
+      hitbuf[r] = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds) + PANEL_LDS) + (wave * NRG + r) * HCAP;
+      const int grow0 = rbv[r] * 128 + 32 * wave + 4 * h;
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) taug[r][g] = -3.0e38f;
+      }
+      if constexpr (MODE == 1) {
+        if (l31 < 16) s_tau[wave][r][h][l31] = a.tau[grow0 + (l31 & 3) + 8 * (l31 >> 2)];
+      }
     }
     // source of piece q of this wave's share of a column tile: row 32 wave + 8 q + frow of the tile, swizzled chunk
     const _Float16* bsrc[4];
@@ -145,12 +178,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // groups it runs, correctly, no faster (17.6 vs 17.0 ms) -- the K loop of a lone wave per SIMD is bound by its own
     // instruction issue (32 MFMAs, 32 fragment reads, 8 DMA pieces of ~5 instructions per pair), not by the matrix pipe,
     // so VALU work placed there is not hidden.
-    f32x16 acc[4];
-    auto row_mask = [&](auto GC, const f32x16(&pa)[4]) -> unsigned long long {
+    f32x16 acc[NRG][4];
+    auto row_mask = [&](auto GC, const f32x16(&pa)[4], const float(&tg)[16]) -> unsigned long long {
       constexpr int g = decltype(GC)::value;
-      return __ballot(fmaxf(fmaxf(pa[0][g], pa[1][g]), fmaxf(pa[2][g], pa[3][g])) > taug[g]);
+      return __ballot(fmaxf(fmaxf(pa[0][g], pa[1][g]), fmaxf(pa[2][g], pa[3][g])) > tg[g]);
     };
-    auto hit_rows = [&](auto GC, const f32x16(&pa)[4], int pct) {  // query-row register g of the tile pct has a hit
+    auto hit_rows = [&](auto GC, const f32x16(&pa)[4], const float(&tg)[16], int pct, int rb, uint2* hb, int& wc) {  // query-row register g of the tile pct has a hit
       constexpr int g = decltype(GC)::value;
       const int rl = (g & 3) + 8 * (g >> 2) + 4 * h;  // local row of the wave's 32
       const int grow = rb * 128 + 32 * wave + rl;
@@ -159,7 +192,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       unsigned long long mk[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        bool pred = pa[t][g] > taug[g];
+        bool pred = pa[t][g] > tg[g];
         if (special) pred = pred && (cbase + 32 * t) != grow && (cbase + 32 * t) < a.N;  // graph.py:37: no self-similarity
         mk[t] = __ballot(pred);
       }
@@ -167,17 +200,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int t = 0; t < 4; ++t) {
         if (mk[t] == 0ull) continue;
         const bool pred = (mk[t] >> lane) & 1ull;
-        const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[t] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[t], 0u));
-        if (pred && pos < HB_CAP)
-          hitbuf[pos] = make_uint2(((unsigned)rl << 27) | (unsigned)(cbase + 32 * t), __float_as_uint(pa[t][g]));
-        wcnt += __popcll(mk[t]);
+        const int pos = wc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[t] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[t], 0u));
+        if (pred && pos < HCAP)
+          hb[pos] = make_uint2(((unsigned)rl << 27) | (unsigned)(cbase + 32 * t), __float_as_uint(pa[t][g]));
+        wc += __popcll(mk[t]);
       }
     };
-    auto hit_test_tile = [&](const f32x16(&pa)[4], int pct) {  // all 16 registers, compares batched ahead of the branches
+    auto hit_test_tile = [&](const f32x16(&pa)[4], const float(&tg)[16], int pct, int rb, uint2* hb, int& wc) {  // all 16 registers, compares batched ahead of the branches
       unsigned long long fm[16];
-      static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, pa); });
+      static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, pa, tg); });
       static_for<0, 16>([&](auto GC) {
-        if (fm[decltype(GC)::value] != 0ull) hit_rows(GC, pa, pct);
+        if (fm[decltype(GC)::value] != 0ull) hit_rows(GC, pa, tg, pct, rb, hb, wc);
       });
     };
     auto k_loop = [&](int ct) {
@@ -209,12 +242,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           // v_accvgpr_read per value in the hit test (VALU compares cannot read AGPRs) and shuffled panel slices
           // between the two files every tile.  The tile's first slice starts from C = 0 (inline constant).
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            if constexpr (pr == 0 && u == 0)
-              asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[t]) : "a"(areg[kt * 4 + sl]), "v"(cur[t]));
-            else
-              asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[t]) : "a"(areg[kt * 4 + sl]), "v"(cur[t]));
-          }
+          for (int r = 0; r < NRG; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              if constexpr (pr == 0 && u == 0)
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[r][t]) : "a"(areg[r][kt * 4 + sl]), "v"(cur[t]));
+              else
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[r][t]) : "a"(areg[r][kt * 4 + sl]), "v"(cur[t]));
+            }
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (u < 4) {
             if (fetch) {  // two DMA pieces behind each of the first four MFMA groups
@@ -244,7 +279,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int ct = t0; ct < t1; ++ct) {
         k_loop(ct);
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the asm MFMAs' results -> VALU reads: hipcc pads nothing for asm
-        hit_test_tile(acc, ct);
+#pragma unroll
+        for (int r = 0; r < NRG; ++r) {
+          if (!rok[r]) continue;
+          float tg[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][r][h][4 * q]);
+            tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
+          }
+          hit_test_tile(acc[r], tg, ct, rbv[r], hitbuf[r], wcnt[r]);
+        }
       }
     } else {
       for (int ct = t0; ct < t1; ++ct) {
@@ -252,26 +297,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
         // ---- tile maxima of the sample sweep --------------------------------------------------------------------
 #pragma unroll
-        for (int g = 0; g < 16; ++g)
-          taug[g] = fmaxf(taug[g], fmaxf(fmaxf(acc[0][g], acc[1][g]), fmaxf(acc[2][g], acc[3][g])));
-        if ((ct + 1) % a.group_tiles == 0 || ct + 1 == t1) {  // close the group: maximum over its columns
-          const int grp = ct / a.group_tiles;
+        for (int r = 0; r < NRG; ++r) {
 #pragma unroll
-          for (int g = 0; g < 16; ++g) {
-            float m = taug[g];
+          for (int g = 0; g < 16; ++g)
+            taug[r][g] = fmaxf(taug[r][g], fmaxf(fmaxf(acc[r][0][g], acc[r][1][g]), fmaxf(acc[r][2][g], acc[r][3][g])));
+          if ((ct + 1) % a.group_tiles == 0 || ct + 1 == t1) {  // close the group: maximum over its columns
+            const int grp = ct / a.group_tiles;
+            const int grow0 = rbv[r] * 128 + 32 * wave + 4 * h;
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));  // within the 32 lanes of the half
-            if (l31 == 0) a.tmax[(size_t)(grow0 + (g & 3) + 8 * (g >> 2)) * a.ngroups + grp] = m;
-            taug[g] = -3.0e38f;
+            for (int g = 0; g < 16; ++g) {
+              float m = taug[r][g];
+#pragma unroll
+              for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));  // within the 32 lanes of the half
+              if (l31 == 0 && rok[r]) a.tmax[(size_t)(grow0 + (g & 3) + 8 * (g >> 2)) * a.ngroups + grp] = m;
+              taug[r][g] = -3.0e38f;
+            }
           }
         }
       }
     }
-    if constexpr (MODE == 1) {  // flush the wave's hit list (coalesced 8-byte stores) and its count
-      const int n = min(wcnt, HB_CAP);
-      uint2* out = a.hit_list + ((size_t)item * 4 + wave) * HB_CAP;
-      for (int e = lane; e < n; e += 64) out[e] = hitbuf[e];
-      if (lane == 0) a.hit_cnt[item * 4 + wave] = wcnt;
+    if constexpr (MODE == 1) {  // flush the wave's hit lists (coalesced 8-byte stores) and their counts
+#pragma unroll
+      for (int r = 0; r < NRG; ++r) {
+        if (!rok[r]) continue;
+        const size_t li = ((size_t)split * a.rb_count + rbi0 + r) * 4 + wave;
+        const int n = min(wcnt[r], HCAP);
+        uint2* out = a.hit_list + li * (size_t)a.hit_cap;
+        for (int e = lane; e < n; e += 64) out[e] = hitbuf[r][e];
+        if (lane == 0) a.hit_cnt[li] = wcnt[r];
+      }
     }
     __syncthreads();  // every wave is done with the ring before the next item refills it
   }
@@ -343,7 +397,7 @@ __device__ __forceinline__ unsigned order_key(unsigned bits) {  // ascending flo
 // sorted: the re-scoring ranks by exact score.
 constexpr int SEL_CAP = 1024;    // candidates of one row the select can hold (expected: ~5 keep)
 constexpr int SORT_CAP = 2560;   // entries one workgroup sorts (20 KB of LDS: several workgroups per CU)
-__global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, const int32_t* hit_cnt, int32_t S,
+__global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, const int32_t* hit_cnt, int32_t hit_cap, int32_t S,
                                                       int32_t rb_begin, int32_t rb_count, int32_t nsub, int32_t keep,
                                                       int32_t N, float* cval, int32_t* cidx, int32_t* fail_rows,
                                                       int32_t* fail_count) {
@@ -360,9 +414,9 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
   for (int s = 0; s < S; ++s) {
     const size_t li = ((size_t)s * rb_count + rbi) * 4 + w;
     const int c = hit_cnt[li];
-    if (c > HB_CAP && tid == 0) s_bad = 1;  // the list overflowed: hits were dropped
-    const int n = min(c, HB_CAP);
-    const uint2* list = hit_list + li * HB_CAP;
+    if (c > hit_cap && tid == 0) s_bad = 1;  // the list overflowed: hits were dropped
+    const int n = min(c, hit_cap);
+    const uint2* list = hit_list + li * (size_t)hit_cap;
     for (int e = tid; e < n; e += 256) {
       const int rl = (int)(list[e].x >> 27);
       if (rl >= rl0 && rl < rl0 + rows_here) atomicAdd(&hist[rl], 1);
@@ -385,8 +439,8 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
   if (!bad) {
     for (int s = 0; s < S; ++s) {
       const size_t li = ((size_t)s * rb_count + rbi) * 4 + w;
-      const int n = min(hit_cnt[li], HB_CAP);
-      const uint2* list = hit_list + li * HB_CAP;
+      const int n = min(hit_cnt[li], hit_cap);
+      const uint2* list = hit_list + li * (size_t)hit_cap;
       for (int e = tid; e < n; e += 256) {
         const uint2 v = list[e];
         const int rl = (int)(v.x >> 27);
@@ -459,17 +513,18 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
 }
 
 template <int MODE>
-void launch_panel(const PanelArgs& a, int nkt, int grid, hipStream_t s) {
-#define OSC_PANEL(NKT)                                                                                              \
+void launch_panel(const PanelArgs& a, int nkt, int nrg, int grid, hipStream_t s) {
+#define OSC_PANEL(NKT, NRG)                                                                                         \
   do {                                                                                                              \
     constexpr size_t lds_bytes = MODE == 1 ? PANEL_LDS_HITS : PANEL_LDS;                                            \
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NKT, MODE>),                              \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NKT, MODE, NRG>),                         \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                     \
-    hipLaunchKernelGGL((k_panel<NKT, MODE>), dim3(grid), dim3(256), lds_bytes, s, a);                              \
+    hipLaunchKernelGGL((k_panel<NKT, MODE, NRG>), dim3(grid), dim3(256), lds_bytes, s, a);                         \
   } while (0)
-  if (nkt == 6) OSC_PANEL(6);
-  else if (nkt == 12) OSC_PANEL(12);
-  else throw std::runtime_error("launch_panel: unsupported K depth");
+  if (nkt == 6 && nrg == 2) OSC_PANEL(6, 2);
+  else if (nkt == 6 && nrg == 1) OSC_PANEL(6, 1);
+  else if (nkt == 12 && nrg == 1) OSC_PANEL(12, 1);
+  else throw std::runtime_error("launch_panel: unsupported K depth / row groups");
 #undef OSC_PANEL
   HIP_CHECK(hipGetLastError());
 }
@@ -482,6 +537,9 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus) {
   KnnPanelPlan p{};
   p.nkt = knn_panel_nkt(D);
   p.ldh = 64 * p.nkt;
+  // row groups per wave: two where the panel is small enough (D <= 384: 2 x 96 registers), see the file header
+  static const int nrg_env = [] { const char* e = getenv("OSC_KNN_PANEL_NRG"); return e ? atoi(e) : 0; }();
+  p.nrg = (p.nkt == 6 && nrg_env != 1) ? 2 : 1;
   p.npad = ((N + 127) / 128) * 128;
   p.nrb = p.npad / 128;
   p.keep = keep;
@@ -503,12 +561,14 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus) {
   p.sample_rank = ((double)p.nrb / p.sample_tiles * 6.5 >= (double)keep) ? 14 : 16;
   // column splits: whatever leaves the smallest idle tail on `cus` persistent workgroups (per-item overhead ~1 %)
   // ... and few enough hits per wave and item for its LDS list: 32 rows x ~5 keep / S <= ~2/3 of HB_CAP
-  const int s_min = std::max(1, (int)std::ceil(32.0 * 5.0 * keep / (0.66 * HB_CAP)));
+  p.hit_cap = HB_CAP / p.nrg;
+  const int s_min = std::max(1, (int)std::ceil(32.0 * 5.0 * keep / (0.66 * p.hit_cap)));
+  const int nsets = (p.nrb + p.nrg - 1) / p.nrg;  // work items per split
   double best = 1e30;
   p.S = s_min;
   for (int S = s_min; S <= s_min + 8; ++S) {
     if (p.nrb / S < 16 && S > s_min) break;
-    const double rounds = (double)p.nrb * S / std::max(1, cus);
+    const double rounds = (double)nsets * S / std::max(1, cus);
     const double cost = std::ceil(rounds) / rounds * (1.0 + 0.01 * S);
     if (cost < best - 1e-9) {
       best = cost;
@@ -520,7 +580,7 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus) {
   best = 1e30;
   p.SA = 1;
   for (int S = 1; S <= 6 && S <= p.sample_groups; ++S) {
-    const double rounds = (double)p.nrb * S / std::max(1, cus);
+    const double rounds = (double)nsets * S / std::max(1, cus);
     const double cost = std::ceil(rounds) / rounds * (1.0 + 0.03 * S);
     if (cost < best - 1e-9) {
       best = cost;
@@ -528,7 +588,6 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus) {
     }
   }
   p.sample_tiles_per_split = ((p.sample_groups + p.SA - 1) / p.SA) * p.group_tiles;
-  p.hit_cap = HB_CAP;
   return p;
 }
 
@@ -565,7 +624,7 @@ void launch_panel_tilemax(const void* Yh, const void* Ys, const KnnPanelPlan& p,
   a.tmax = tmax;
   a.queue = queue;
   HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
-  launch_panel<0>(a, p.nkt, grid, s);
+  launch_panel<0>(a, p.nkt, p.nrg, grid, s);
 }
 
 void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float* tau, hipStream_t s) {
@@ -591,9 +650,10 @@ void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int r
   a.tau = tau;
   a.hit_list = static_cast<uint2*>(hit_list);
   a.hit_cnt = hit_cnt;
+  a.hit_cap = p.hit_cap;
   a.queue = queue;
   HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
-  launch_panel<1>(a, p.nkt, grid, s);
+  launch_panel<1>(a, p.nkt, p.nrg, grid, s);
 }
 
 void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int32_t N, const void* hit_list,
@@ -604,7 +664,7 @@ void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int3
   int nsub = 1;
   while (nsub < 8 && 5.0 * p.keep * (32 / nsub) > 0.75 * SORT_CAP) nsub *= 2;
   hipLaunchKernelGGL(k_panel_select, dim3((unsigned)(rb_count * 4 * nsub)), dim3(256), 0, s,
-                     static_cast<const uint2*>(hit_list), hit_cnt, p.S, rb_begin, rb_count, nsub, p.keep, N, cval, cidx,
+                     static_cast<const uint2*>(hit_list), hit_cnt, p.hit_cap, p.S, rb_begin, rb_count, nsub, p.keep, N, cval, cidx,
                      fail_rows, fail_count);
   HIP_CHECK(hipGetLastError());
 }

@@ -10,6 +10,7 @@ int knn_panel_nkt(int32_t D);
 struct KnnPanelPlan {
   bool ok;             // the lattice is large enough for sampled thresholds (else: use the tile prefilter)
   int nkt;             // 6 or 12
+  int nrg;             // row groups (32 rows of consecutive 128-row blocks) a wave's register panel holds: 2 at K depth 6, else 1
   int32_t ldh;         // pitch of the fp16 images in halfs = 64 * nkt
   int32_t npad;        // rows of the query image (N rounded up to 128), zero-filled beyond N
   int32_t nrb;         // query row blocks (npad / 128)
@@ -37,8 +38,8 @@ void launch_panel_tilemax(const void* Yh, const void* Ys, const KnnPanelPlan& p,
 // threshold per row = sample_rank-th largest of its tile maxima
 void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float* tau, hipStream_t s);
 // phase B: every (row, column) with fp16 score > tau[row] (diagonal excluded) is appended to the hit list of its
-// (work item, wave): hit_list [(item * 4 + wave) * hit_cap + e] = 8-byte entries {local row << 27 | column, score bits},
-// hit_cnt [item * 4 + wave] (may exceed hit_cap: overflow); item = split * rb_count + (row block - rb_begin)
+// (column split, row block, wave): hit_list [(list * 4 + wave) * hit_cap + e] = 8-byte entries {local row << 27 | column,
+// score bits}, hit_cnt [list * 4 + wave] (may exceed hit_cap: overflow); list = split * rb_count + (row block - rb_begin)
 void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count, const float* tau,
                          void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s);
 // per row: `keep` candidates holding the keep best fp16 scores (unsorted, the minimum in the last slot) -> cval / cidx

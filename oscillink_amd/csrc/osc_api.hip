@@ -232,6 +232,7 @@ struct osc_lattice {
   int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
   int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
   double temporal_mb = 200.0;  // largest solve (5 arrays x N x window) whose update kernels use ordinary instead of nontemporal accesses (OSC_TEMPORAL_MB)
+  bool spmm_deep = true;   // re-ordered lattices: the operator apply with 8 gathers in flight per row (OSC_SPMM_DEEP=0: the usual 2)
   bool blk_init = true;    // the initial residual goes through the blocked matvec as well (OSC_BLK_INIT=0: plain INIT apply)
   int64_t blk_applies = 0; // blocked matvecs enqueued since creation
   int64_t small_solves = 0;
@@ -800,11 +801,12 @@ void build_graph(L& h) {
       }
     } else if (panel) {
       const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true);  // row range + keep for the re-scoring
-      const int grid = std::max(1, std::min(prop.multiProcessorCount, rb_count * pp.S));
+      const int nsets = (rb_count + pp.nrg - 1) / pp.nrg;  // work items per column split (knn_gemm.hip)
+      const int grid = std::max(1, std::min(prop.multiProcessorCount, nsets * pp.S));
       {
         ProfScope ps(h, 3);
         launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
-                             std::max(1, std::min(prop.multiProcessorCount, rb_count * pp.SA)), h.stream);
+                             std::max(1, std::min(prop.multiProcessorCount, nsets * pp.SA)), h.stream);
         launch_panel_tau(p_tmax.p, pp, N, p_tau.p, h.stream);
         p_hits.alloc((size_t)rb_count * pp.S * 4 * pp.hit_cap);  // one list per (work item, wave)
         p_hcnt.alloc((size_t)rb_count * pp.S * 4);
@@ -928,6 +930,10 @@ int32_t auto_slab(const L& h, int32_t ncols) {
   constexpr int32_t kMaxWindow = 2048;  // widest column window one launch covers (8 x 256 floats per row)
   if (h.spmm_slab > 0) return std::min(h.spmm_slab, kMaxWindow);
   if (h.spmm_slab < 0) return std::min(ncols, kMaxWindow);  // OSC_SPMM_SLAB=-1: split only when it must
+  // a lattice stored in a local row order gathers from its XCD's L2 whatever the slab: 256 columns (one 1 KB row piece per
+  // wave, eight of them in flight: k_spmm's UDEEP variant) ran fastest on 1000 clusters x 100 rows at N = 100k, D = 768
+  // (0.69 ms per apply at 64 columns, 0.45 at 128, 0.41 at 256 and 512, 0.44 at 768)
+  if (h.reordered && h.spmm_deep && ncols > 256) return 256;
   // keep the gathered slab (N x slab x 4 B) around 50 MB so it and the streams beside it stay inside 256 MB
   const double budget = 56.0 * 1024 * 1024;
   if ((double)h.N * ncols * 4.0 <= 2.0 * budget) return std::min(ncols, kMaxWindow);
@@ -1020,6 +1026,7 @@ BlockedView blocked_view(L& h, int nb) {
 
 void spmm_slabbed(L& h, int mode, SpmmArgs sa, int grid, int iter = 0) {
   const int32_t c0 = sa.c0, c1 = sa.c1;
+  sa.deep = (h.reordered && h.spmm_deep) ? 1 : 0;
   ProfScope ps(h, mode == SPMM_INIT ? 4 : 0, iter);  // slot 0: AP applies (the CG matvec); slot 4: the INIT apply
   if (const int nb = xs_plan(h, c1 - c0, grid)) {
     // workgroups per XCD: 3 per CU when the operand is row-major (2: 1.37, 4: 1.15 ms vs 1.11), 4 per CU when it is
@@ -1790,6 +1797,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_BLK_MB")) h->blk_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_BLK_EDGES")) h->blk_edges = std::max(0.5, atof(e));
     if (const char* e = getenv("OSC_BLK_INIT")) h->blk_init = atoi(e) != 0;
+    if (const char* e = getenv("OSC_SPMM_DEEP")) h->spmm_deep = atoi(e) != 0;
     if (const char* e = getenv("OSC_TEMPORAL_MB")) h->temporal_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
