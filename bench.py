@@ -96,6 +96,23 @@ class FileRendezvous:
         shutil.rmtree(self.dir, ignore_errors=True)
 
 
+class StdoutToStderr:
+    """Route the PROCESS's stdout (fd 1) to stderr for a while: RCCL prints its version banner to stdout when a communicator
+    is created, and this script's stdout is one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,7 +165,8 @@ def main():
     lat = None
     if comm is not None:
         try:
-            lat = Oscillink(Y, kneighbors=k, deterministic_k=False, device=local_rank, comm=comm)
+            with StdoutToStderr():
+                lat = Oscillink(Y, kneighbors=k, deterministic_k=False, device=local_rank, comm=comm)
         except Exception as e:  # noqa: BLE001 -- reported by every rank below
             comm_error = f"{type(e).__name__}: {e}"
             lat = None

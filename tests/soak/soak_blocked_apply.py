@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Differential soak of the source-blocked CG matvec (csrc/cg_kernels.hip: k_apply_blocked) against the plain apply on
-shapes the test suite does not cover: N 17k-130k (ragged), D 96-1024 in steps of 4 (partial last slab, 1 / 2 / 4 / 8 slab
-groups), k 4-48, i.i.d. and clustered anchors (many edges into one block: the epilogue list), random gates, 1-16 source
-blocks forced, the automatic choice, every third case with a chain prior, and a settle + U* solve per case.  Iteration counts must agree; states to 2e-6."""
+shapes the test suite does not cover: N 17k-270k (ragged), D 96-1024 in steps of 4 (partial last slab, 1 / 2 / 4 / 8 slab
+groups), k 4-64, i.i.d. and clustered anchors (many edges into one block: the epilogue list), random gates, 1-32 source
+blocks forced, the automatic choice (which changes its rule at N = 140k), every third case with a chain prior, and a settle + U* solve per case.  Iteration counts must agree; states to 2e-6."""
 import os
 import sys
 
@@ -21,14 +21,15 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 rng = np.random.default_rng(seed)
 os.environ["OSC_REORDER"] = "0"  # clustered anchors would otherwise be re-ordered (which switches both modes off)
 special = [(100000, 768, 32, "-1"), (33000, 96, 8, "3"), (40001, 100, 12, "5"), (65536, 256, 48, "16"),
-           (130000, 160, 6, "-1"), (17000, 512, 16, "2")]
+           (130000, 160, 6, "-1"), (17000, 512, 16, "2"), (200000, 384, 64, "-1"), (260000, 256, 32, "32"),
+           (141000, 320, 40, "-1"), (139999, 192, 56, "27")]
 bad = 0
 for t in range(count):
     if t < len(special):
         N, D, k, nb = special[t]
     else:
-        N, D, k = int(rng.integers(17000, 110000)), 4 * int(rng.integers(24, 257)), int(rng.integers(4, 49))
-        nb = str(rng.choice([-1, 1, 2, 3, 6, 8, 11, 16]))
+        N, D, k = int(rng.integers(17000, 270000)), 4 * int(rng.integers(24, 257)), int(rng.integers(4, 65))
+        nb = str(rng.choice([-1, -1, 1, 2, 3, 6, 8, 11, 16, 20, 24, 27, 32]))
         if N * D > 60_000_000:
             D = max(96, 4 * (60_000_000 // N // 4))
     kind = ("iid", "clustered")[t % 2]
