@@ -332,16 +332,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // fp32 unit rows -> fp16 image of 16 * Yn, zero beyond (N, D)
-__global__ void k_panel_image(const float* Yn, int32_t ldn, _Float16* Yh, int32_t ldh, int32_t npad, int32_t N, int32_t D) {
+__global__ void k_panel_image(const float* Yn, int32_t ldn, _Float16* Yh, int32_t ldh, int32_t npad, int32_t N, int32_t D,
+                              int32_t scatter) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 halfs
   const int per_row = ldh / 8;
   if (i >= (int64_t)npad * per_row) return;
   const int row = (int)(i / per_row), c0 = (int)(i % per_row) * 8;
+  const int64_t src = row < N ? ((int64_t)row * scatter) % N : 0;  // KnnPanelPlan::scatter
   half8 v;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = c0 + j;
-    v[j] = (row < N && c < D) ? (_Float16)(16.0f * Yn[(size_t)row * ldn + c]) : (_Float16)0.f;
+    v[j] = (row < N && c < D) ? (_Float16)(16.0f * Yn[(size_t)src * ldn + c]) : (_Float16)0.f;
   }
   *(half8*)(Yh + (size_t)row * ldh + c0) = v;
 }
@@ -399,7 +401,7 @@ constexpr int SEL_CAP = 1024;    // candidates of one row the select can hold (e
 constexpr int SORT_CAP = 2560;   // entries one workgroup sorts (20 KB of LDS: several workgroups per CU)
 __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, const int32_t* hit_cnt, int32_t hit_cap, int32_t S,
                                                       int32_t rb_begin, int32_t rb_count, int32_t nsub, int32_t keep,
-                                                      int32_t N, float* cval, int32_t* cidx, int32_t* fail_rows,
+                                                      int32_t N, int32_t scatter, float* cval, int32_t* cidx, int32_t* fail_rows,
                                                       int32_t* fail_count) {
   __shared__ uint2 sorted[SORT_CAP];
   __shared__ int hist[32], start[33], cursor[32], s_bad;
@@ -450,8 +452,9 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
   }
   __syncthreads();
   for (int rl = rl0 + wave; rl < rl0 + rows_here; rl += 4) {
-    const int row = row_base + rl;
-    if (row >= N) continue;
+    const int irow = row_base + rl;  // image row
+    if (irow >= N) continue;
+    const int row = (int)(((int64_t)irow * scatter) % N);  // lattice row (KnnPanelPlan::scatter)
     const int m = bad ? 0 : hist[rl];
     float* ov = cval + (size_t)row * keep;
     int32_t* oi = cidx + (size_t)row * keep;
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
       bits[q] = 0u;
       if (e < m) {
         const uint2 v = ent[e];
-        col[q] = v.x;
+        col[q] = (unsigned)(((int64_t)v.x * scatter) % N);  // image column -> lattice column
         bits[q] = v.y;
         key[q] = order_key(v.y);
       }
@@ -533,8 +536,22 @@ void launch_panel(const PanelArgs& a, int nkt, int nrg, int grid, hipStream_t s)
 
 int knn_panel_nkt(int32_t D) { return D <= 384 ? 6 : D <= 768 ? 12 : 0; }
 
-KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus) {
+KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows) {
   KnnPanelPlan p{};
+  p.scatter = 1;
+  if (scatter_rows && N > 2) {  // ~ N / golden ratio, made coprime to N: consecutive image rows are far-apart lattice rows
+    auto gcd = [](int64_t a, int64_t b) {
+      while (b) {
+        const int64_t t = a % b;
+        a = b;
+        b = t;
+      }
+      return a;
+    };
+    int64_t a = (int64_t)((double)N * 0.6180339887498949) | 1;
+    while (a < N && gcd(a, N) != 1) a += 2;
+    if (a < N) p.scatter = (int32_t)a;
+  }
   p.nkt = knn_panel_nkt(D);
   p.ldh = 64 * p.nkt;
   // row groups per wave: two where the panel is small enough (D <= 384: 2 x 96 registers), see the file header
@@ -594,7 +611,7 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus) {
 void launch_panel_image(const float* Yn, int32_t ldn, void* Yh, const KnnPanelPlan& p, int32_t N, int32_t D, hipStream_t s) {
   const int64_t n = (int64_t)p.npad * (p.ldh / 8);
   hipLaunchKernelGGL(k_panel_image, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Yn, ldn,
-                     static_cast<_Float16*>(Yh), p.ldh, p.npad, N, D);
+                     static_cast<_Float16*>(Yh), p.ldh, p.npad, N, D, p.scatter);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -664,7 +681,7 @@ void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int3
   int nsub = 1;
   while (nsub < 8 && 5.0 * p.keep * (32 / nsub) > 0.75 * SORT_CAP) nsub *= 2;
   hipLaunchKernelGGL(k_panel_select, dim3((unsigned)(rb_count * 4 * nsub)), dim3(256), 0, s,
-                     static_cast<const uint2*>(hit_list), hit_cnt, p.hit_cap, p.S, rb_begin, rb_count, nsub, p.keep, N, cval, cidx,
+                     static_cast<const uint2*>(hit_list), hit_cnt, p.hit_cap, p.S, rb_begin, rb_count, nsub, p.keep, N, p.scatter, cval, cidx,
                      fail_rows, fail_count);
   HIP_CHECK(hipGetLastError());
 }

@@ -759,7 +759,10 @@ void build_graph(L& h) {
   DevBuf<int32_t> p_hcnt;
   DevBuf<unsigned> p_queue;
   if (panel) {
-    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount);
+    // (image rows scattered over the lattice rows in single-process builds: knn_gemm.hpp, KnnPanelPlan::scatter)
+    const char* sc_env = getenv("OSC_KNN_PANEL_SCATTER");
+    const bool scatter_on = !(sc_env && atoi(sc_env) == 0);
+    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, scatter_on && parts == 1);
     p_img.alloc((size_t)pp.npad * pp.ldh / 2);
     p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
     p_tmax.alloc((size_t)pp.npad * pp.sample_groups);

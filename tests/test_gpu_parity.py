@@ -894,6 +894,37 @@ def test_panel_prefilter_route_gives_the_exact_lists(amd, N, D, k, kind, monkeyp
         assert info["panel"]["fallback_rows"] <= 8
 
 
+def test_panel_prefilter_on_anchors_that_arrive_grouped(amd, monkeypatch):
+    """Anchors in cluster order (documents, topics): the 32 rows of a wave of the panel kernel would all have their
+    ~cluster-size best columns in the same one or two column tiles, their shared hit list would overflow and every row
+    would fall back to the exact kernel.  The prefilter therefore works on an image whose rows are scattered over the
+    lattice rows (KnnPanelPlan::scatter); the lattice it delivers is the one of the unscattered build and of the exact
+    route, and only the rows the proof cannot decide (tight clusters) are redone."""
+    rng = np.random.default_rng(123)
+    N, D, k, csize = 24000, 200, 24, 120
+    centers = rng.standard_normal((N // csize, D)).astype(np.float32)
+    Y = (centers[np.repeat(np.arange(N // csize), csize)] + 0.35 * rng.standard_normal((N, D))).astype(np.float32)
+    out = {}
+    for tag, mode, scatter in (("scatter", "panel", "1"), ("plain", "panel", "0"), ("exact", "exact", "1")):
+        monkeypatch.setenv("OSC_KNN_MODE", mode)
+        monkeypatch.setenv("OSC_KNN_PANEL_SCATTER", scatter)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        out[tag] = (lat.build_info(), _knn_sets(lat, N, k), lat.graph_csr())
+        lat.close()
+    assert out["scatter"][0]["prefilter"] == 2 and out["plain"][0]["prefilter"] == 2
+    # unscattered: (almost) every row overflows into the fallback; scattered: a small fraction
+    assert out["plain"][0]["fallback_rows"] > N // 2, out["plain"][0]
+    assert out["scatter"][0]["fallback_rows"] < N // 10, out["scatter"][0]
+    from tests._fullsize import near_tie_gap
+
+    for tag in ("plain", "exact"):
+        rows = np.nonzero((out["scatter"][1] != out[tag][1]).any(axis=1))[0]
+        assert rows.size <= N // 200, (tag, rows.size)
+        for r in rows:
+            members = sorted(set(out["scatter"][1][r].tolist()) ^ set(out[tag][1][r].tolist()))
+            assert near_tie_gap(Y, int(r), members) < 4e-6, (tag, int(r))
+
+
 def test_internal_row_order_is_invisible(amd, orc, monkeypatch):
     """Clustered anchors in shuffled order: the automatic BFS re-order kicks in (sampled clustering coefficient), an
     i.i.d. lattice stays as it is, and every API result is identical to the run with re-ordering disabled."""
