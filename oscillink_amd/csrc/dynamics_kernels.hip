@@ -35,45 +35,58 @@ __global__ __launch_bounds__(256) void k_sum_max(const float* v, int64_t n, doub
   }
 }
 
-// order: value descending, index ascending
-__device__ __forceinline__ bool before(float v, int64_t i, float bv, int64_t bi) { return v > bv || (v == bv && i < bi); }
+// order: value descending, then the caller's (row, column) ids ascending -- the reference ranks its flows with a stable sort
+// over argwhere order (lattice.py:879-881), i.e. ties go to the smaller API (i, j); on a lattice stored in an internal row
+// order the ELL position would break exact ties differently, and a block's cut at K could then drop an entry the
+// reference keeps
+__device__ __forceinline__ bool before(float v, int64_t k, float bv, int64_t bk) { return v > bv || (v == bv && k < bk); }
 
-__global__ __launch_bounds__(256) void k_top_select(const float* v, const int32_t* col, int64_t n, int K, float* out_val,
-                                                    int64_t* out_idx, int32_t* out_col) {
+__global__ __launch_bounds__(256) void k_top_select(const float* v, const int32_t* col, const int32_t* api_id, int32_t width,
+                                                    int64_t n, int K, float* out_val, int64_t* out_idx, int32_t* out_col) {
   __shared__ float sv[256];
-  __shared__ int64_t si[256];
+  __shared__ int64_t sk[256], si[256];
   const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
   const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  auto key_of = [&](int64_t i) -> int64_t {  // (API row, API column) of ELL entry i
+    const int32_t r = (int32_t)(i / width), c = col[i];
+    const int64_t ar = api_id ? api_id[r] : r, ac = api_id ? api_id[c] : c;
+    return (ar << 32) | ac;
+  };
   float pv = __uint_as_float(0x7F800000u);  // +inf: everything comes after the (virtual) previous pick
-  int64_t pi = -1;
+  int64_t pk = -1;
   for (int r = 0; r < K; ++r) {
     float bv = 0.f;
-    int64_t bi = -1;
+    int64_t bk = -1, bi = -1;
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
       const float x = v[i];
       if (!(x > 0.f)) continue;
-      if (!before(pv, pi, x, i)) continue;  // not after the previous pick
-      if (bi < 0 || before(x, i, bv, bi)) {
+      const int64_t k = key_of(i);
+      if (!before(pv, pk, x, k)) continue;  // not after the previous pick
+      if (bi < 0 || before(x, k, bv, bk)) {
         bv = x;
+        bk = k;
         bi = i;
       }
     }
     sv[threadIdx.x] = bv;
+    sk[threadIdx.x] = bk;
     si[threadIdx.x] = bi;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
       if ((int)threadIdx.x < o) {
         const float ov = sv[threadIdx.x + o];
-        const int64_t oi = si[threadIdx.x + o];
-        if (oi >= 0 && (si[threadIdx.x] < 0 || before(ov, oi, sv[threadIdx.x], si[threadIdx.x]))) {
+        const int64_t ok = sk[threadIdx.x + o], oi = si[threadIdx.x + o];
+        if (oi >= 0 && (si[threadIdx.x] < 0 || before(ov, ok, sv[threadIdx.x], sk[threadIdx.x]))) {
           sv[threadIdx.x] = ov;
+          sk[threadIdx.x] = ok;
           si[threadIdx.x] = oi;
         }
       }
       __syncthreads();
     }
     pv = sv[0];
-    pi = si[0];
+    pk = sk[0];
+    const int64_t pi = si[0];
     __syncthreads();
     if (threadIdx.x == 0) {
       const size_t o = (size_t)blockIdx.x * K + r;
@@ -120,9 +133,9 @@ void launch_sum_max(const float* v, int64_t n, int nblocks, double* psum, float*
   hipLaunchKernelGGL(k_sum_max, dim3(nblocks), dim3(256), 0, s, v, n, psum, pmax);
   HIP_CHECK(hipGetLastError());
 }
-void launch_top_select(const float* v, const int32_t* col, int64_t n, int nblocks, int K, float* out_val,
-                       int64_t* out_idx, int32_t* out_col, hipStream_t s) {
-  hipLaunchKernelGGL(k_top_select, dim3(nblocks), dim3(256), 0, s, v, col, n, K, out_val, out_idx, out_col);
+void launch_top_select(const float* v, const int32_t* col, const int32_t* api_id, int32_t width, int64_t n, int nblocks, int K,
+                       float* out_val, int64_t* out_idx, int32_t* out_col, hipStream_t s) {
+  hipLaunchKernelGGL(k_top_select, dim3(nblocks), dim3(256), 0, s, v, col, api_id, width, n, K, out_val, out_idx, out_col);
   HIP_CHECK(hipGetLastError());
 }
 void launch_bfs_seeds(const float* move2, int64_t N, float thr, int32_t* dist, hipStream_t s) {

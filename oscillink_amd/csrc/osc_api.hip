@@ -2574,7 +2574,8 @@ int osc_dynamics(osc_handle h, const float* U_prev, const float* U_next, double*
       tv.alloc((size_t)nb3 * K);
       ti.alloc((size_t)nb3 * K);
       tc.alloc((size_t)nb3 * K);
-      launch_top_select(flows.p, l.ell_col.p, (int64_t)ne, nb3, K, tv.p, ti.p, tc.p, l.stream);
+      launch_top_select(flows.p, l.ell_col.p, permuted(l) ? l.perm_d.p : nullptr, l.width, (int64_t)ne, nb3, K, tv.p, ti.p, tc.p,
+                        l.stream);
       htv.resize((size_t)nb3 * K);
       hti.resize((size_t)nb3 * K);
       htc.resize((size_t)nb3 * K);
