@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential soak of the panel prefilter route (csrc/knn_gemm.hip) against the all-fp32 kernel on shapes and data the
 test suite does not cover: N 16k-60k (ragged, also exact multiples of 128), D 8-768 (both K depths, D = 384 / 385 at the
-boundary), k 1-64, i.i.d. / clustered / duplicated / scaled anchors, zero rows.  Every edge present on one side only must
+boundary), k 1-64, i.i.d. / clustered / duplicated / scaled / grouped (cluster by cluster) anchors, zero rows.  Every edge present on one side only must
 be a rank-k near-tie of one of its end rows (gap below fp32 summation noise)."""
 import os
 import sys
@@ -21,8 +21,11 @@ for t in range(count):
         N, D, k = special[t]
     else:
         N, D, k = int(rng.integers(16384, 60000)), int(rng.integers(8, 769)), int(rng.integers(1, 65))
-    kind = ("iid", "clustered", "dups", "scaled", "zeros")[t % 5]
-    if kind == "clustered":
+    kind = ("iid", "clustered", "dups", "scaled", "zeros", "grouped")[t % 6]
+    if kind == "grouped":  # anchors handed over cluster by cluster (the row scatter of the prefilter image)
+        C_ = int(rng.integers(40, 300))
+        Y = (rng.standard_normal((C_, D))[np.sort(rng.integers(0, C_, N))] + 0.35 * rng.standard_normal((N, D))).astype(np.float32)
+    elif kind == "clustered":
         C_ = int(rng.integers(20, 400))
         Y = (rng.standard_normal((C_, D))[rng.integers(0, C_, N)] + 0.1 * rng.standard_normal((N, D))).astype(np.float32)
     elif kind == "dups":
