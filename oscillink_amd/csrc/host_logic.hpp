@@ -186,16 +186,17 @@ inline int xs_groups(int32_t ncols, int cap = 8) {
   const int g = (nsl % 8 == 0) ? 8 : (nsl % 4 == 0) ? 4 : (nsl % 2 == 0) ? 2 : 1;
   return std::min(g, cap);
 }
-// ... halved until the slabs in flight (groups x N x 128 B) fit 128 MiB of the Infinity Cache; 0 = the mode does not pay
-// (measured: shrinking below 4 groups loses to the general path -- config 5's shape 56.4 ms general, 54.2 at 4 groups,
-// 57.1 at 2, 60.7 at 1; config 4's shape loses at every count)
-inline int xs_groups_for(int64_t N, int32_t ncols, int cap) {
+// ... halved until the slabs in flight (groups x N x 128 B) fit 128 MiB of the Infinity Cache; 0 = the mode does not pay:
+// below min_reduced groups (the plain slab apply loses to the general path under 4 groups -- config 5's shape 56.4 ms
+// general, 54.2 at 4 groups, 57.1 at 2, 60.7 at 1 --, the blocked matvec still wins at 2: xs_plan in osc_api.hip; config
+// 4's shape loses at every count)
+inline int xs_groups_for(int64_t N, int32_t ncols, int cap, int min_reduced = 4) {
   const int natural = xs_groups(ncols, cap);
   int g = natural;
   const double cap_bytes = 128.0 * 1024 * 1024;
   while (g > 1 && (double)g * (double)N * 128.0 > cap_bytes) g >>= 1;
   if ((double)g * (double)N * 128.0 > cap_bytes) return 0;
-  if (g != natural && g < 4) return 0;
+  if (g != natural && g < min_reduced) return 0;
   return g;
 }
 // Work decomposition of k_apply_blocked: xs workgroups per XCD take part; the XCDs form xs_groups slab groups, the

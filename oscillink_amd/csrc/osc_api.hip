@@ -215,6 +215,7 @@ struct osc_lattice {
   bool p_blocked = true;   // slab-major search direction in xs mode (OSC_P_BLOCKED=0 keeps it row-major)
   int xs_nb = 0;           // workgroups per XCD in that mode; 0 = automatic (OSC_XS_NB)
   int xs_groups_cap = 8;   // upper bound on the slab groups (= slabs in flight) of that mode (OSC_XS_GROUPS)
+  int xs_groups_min = 2;   // fewest slab groups the mode is kept for when the natural count had to be reduced (OSC_XS_MIN_GROUPS)
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
   DevBuf<uint32_t> res_bits, arrive;  // arrive: per-iteration barrier counters (+1 status word) of the one-launch path
@@ -955,7 +956,8 @@ int32_t auto_slab(const L& h, int32_t ncols) {
 // 8 slabs (205 MB) in flight, 4 % with 4 (xs_groups_for); 36 % slower at N = 1M, D = 384.
 // (the counts themselves: host_logic.hpp)
 int xs_groups(int32_t ncols, int cap = 8) { return host::xs_groups(ncols, cap); }
-int xs_groups_for(const L& h, int32_t ncols) { return host::xs_groups_for(h.N, ncols, h.xs_groups_cap); }
+int xs_groups_for(const L& h, int32_t ncols) { return host::xs_groups_for(h.N, ncols, h.xs_groups_cap, h.xs_groups_min); }
+int blocked_plan(const L& h, bool with_path);
 int xs_plan(const L& h, int32_t ncols, int grid) {
   if (grid < 8 || (grid & 7) != 0) return 0;
   const int nb = std::max(1, std::min(grid / 8, h.xs_nb > 0 ? h.xs_nb : 96));
@@ -964,7 +966,13 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   if (h.spmm_slab != 0 || h.reordered || (h.ld & 31) != 0 || (h.c0 & 31) != 0) return 0;
   // from N = 32768 on, and from 16384 for windows of >= 256 columns (N = 20000, D = 256: apply 43.5 -> 31.4 us)
   if (h.N < 16384 || (h.N < 32768 && ncols < 256) || ncols < 96) return 0;
-  if (xs_groups_for(h, ncols) == 0) return 0;
+  const int xg = xs_groups_for(h, ncols);
+  if (xg == 0) return 0;
+  // Two slab groups (262k < N <= 524k: four XCDs share a slab) pay only under the blocked matvec -- measured in round 3
+  // against the general path: 300k x 768 k 32 25.96 -> 22.33 ms per settle, 400k x 512 k 32 22.70 -> 19.10, 300k x 768 k 64
+  // 43.1 -> 36.3, 500k x 384 k 16 a tie; the plain slab apply at two groups loses (config 5's shape: 57.1 vs 56.4 ms) and one
+  // group loses either way (700k x 384: 22.8 -> 24.5, config 4: 32.3 -> 34.4)
+  if (xg < 4 && xg != xs_groups(ncols, h.xs_groups_cap) && blocked_plan(h, false) == 0) return 0;
   return nb;
 }
 
@@ -1791,6 +1799,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_GRID_CAP")) h->grid_cap = std::max(1, atoi(e));
     if (const char* e = getenv("OSC_SPMM_XS")) h->spmm_xs = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_XS_NB")) h->xs_nb = std::max(1, atoi(e));
+    if (const char* e = getenv("OSC_XS_MIN_GROUPS")) h->xs_groups_min = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("OSC_XS_GROUPS")) {
       const int g = atoi(e);
       h->xs_groups_cap = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;

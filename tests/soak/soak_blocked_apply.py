@@ -22,7 +22,8 @@ rng = np.random.default_rng(seed)
 os.environ["OSC_REORDER"] = "0"  # clustered anchors would otherwise be re-ordered (which switches both modes off)
 special = [(100000, 768, 32, "-1"), (33000, 96, 8, "3"), (40001, 100, 12, "5"), (65536, 256, 48, "16"),
            (130000, 160, 6, "-1"), (17000, 512, 16, "2"), (200000, 384, 64, "-1"), (260000, 256, 32, "32"),
-           (141000, 320, 40, "-1"), (139999, 192, 56, "27")]
+           (141000, 320, 40, "-1"), (139999, 192, 56, "27"), (300000, 256, 32, "-1"), (450000, 128, 24, "-1"),
+           (524000, 96, 12, "-1")]
 bad = 0
 for t in range(count):
     if t < len(special):
