@@ -215,6 +215,9 @@ struct osc_lattice {
   bool p_blocked = true;   // slab-major search direction in xs mode (OSC_P_BLOCKED=0 keeps it row-major)
   int xs_nb = 0;           // workgroups per XCD in that mode; 0 = automatic (OSC_XS_NB)
   int xs_groups_cap = 8;   // upper bound on the slab groups (= slabs in flight) of that mode (OSC_XS_GROUPS)
+  int xs_min_cols = 32;    // narrowest column window the mode is used for (OSC_XS_MIN_COLS; 96 until round 3 -- with the
+                           // blocked matvec under it, one- and two-slab windows win too: 100k x 64 k 16 0.505 -> 0.425 ms per
+                           // settle, 100k x 32 0.352 -> 0.309, 200k x 64 k 32 1.43 -> 0.97, 60k x 64 k 32 0.438 -> 0.387)
   int xs_groups_min = 2;   // fewest slab groups the mode is kept for when the natural count had to be reduced (OSC_XS_MIN_GROUPS)
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
@@ -965,7 +968,7 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   if (h.spmm_xs == 1) return nb;
   if (h.spmm_slab != 0 || h.reordered || (h.ld & 31) != 0 || (h.c0 & 31) != 0) return 0;
   // from N = 32768 on, and from 16384 for windows of >= 256 columns (N = 20000, D = 256: apply 43.5 -> 31.4 us)
-  if (h.N < 16384 || (h.N < 32768 && ncols < 256) || ncols < 96) return 0;
+  if (h.N < 16384 || (h.N < 32768 && ncols < 256) || ncols < h.xs_min_cols) return 0;
   const int xg = xs_groups_for(h, ncols);
   if (xg == 0) return 0;
   // Two slab groups (262k < N <= 524k: four XCDs share a slab) pay only under the blocked matvec -- measured in round 3
@@ -1799,6 +1802,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_GRID_CAP")) h->grid_cap = std::max(1, atoi(e));
     if (const char* e = getenv("OSC_SPMM_XS")) h->spmm_xs = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_XS_NB")) h->xs_nb = std::max(1, atoi(e));
+    if (const char* e = getenv("OSC_XS_MIN_COLS")) h->xs_min_cols = std::max(32, atoi(e));
     if (const char* e = getenv("OSC_XS_MIN_GROUPS")) h->xs_groups_min = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("OSC_XS_GROUPS")) {
       const int g = atoi(e);
