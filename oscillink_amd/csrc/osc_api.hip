@@ -218,6 +218,7 @@ struct osc_lattice {
   int xs_min_cols = 32;    // narrowest column window the mode is used for (OSC_XS_MIN_COLS; 96 until round 3 -- with the
                            // blocked matvec under it, one- and two-slab windows win too: 100k x 64 k 16 0.505 -> 0.425 ms per
                            // settle, 100k x 32 0.352 -> 0.309, 200k x 64 k 32 1.43 -> 0.97, 60k x 64 k 32 0.438 -> 0.387)
+  int xs_min_rows = 6144, xs_min_rows_narrow = 32768;  // smallest lattice the mode is used for: windows of >= 256 columns / narrower ones (OSC_XS_MIN_ROWS="a,b")
   int xs_groups_min = 2;   // fewest slab groups the mode is kept for when the natural count had to be reduced (OSC_XS_MIN_GROUPS)
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
@@ -967,8 +968,13 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   if (h.spmm_xs == 0) return 0;
   if (h.spmm_xs == 1) return nb;
   if (h.spmm_slab != 0 || h.reordered || (h.ld & 31) != 0 || (h.c0 & 31) != 0) return 0;
-  // from N = 32768 on, and from 16384 for windows of >= 256 columns (N = 20000, D = 256: apply 43.5 -> 31.4 us)
-  if (h.N < 16384 || (h.N < 32768 && ncols < 256) || ncols < h.xs_min_cols) return 0;
+  // from N = 32768 on, and from 6144 (16384 until round 3) for windows of >= 256 columns (N = 20000, D = 256: apply 43.5 -> 31.4 us)
+  if (h.N < h.xs_min_rows || (h.N < h.xs_min_rows_narrow && ncols < 256) || ncols < h.xs_min_cols) return 0;
+  // below 16384 rows (round 3: the floor was 16384) a 32-column slab is at most 2 MB -- it sits in its XCD's L2 whole,
+  // where the general path spreads N x window over all eight L2s -- which pays once a row has enough gathers: per settle
+  // 6500 x 768 k 32 0.520 -> 0.437 ms, 9000 x 1024 k 32 0.925 -> 0.697, 8192 x 1536 k 32 1.32 -> 0.91, 14000 x 256 k 32 0.406
+  // -> 0.329, 9000 x 256 k 16 0.236 -> 0.219, 7000 x 512 k 16 0.299 -> 0.280; at k = 8 it loses (14000 x 320: 0.307 -> 0.329)
+  if (h.N < 16384 && (double)h.nnz < 10.0 * (double)h.N) return 0;
   const int xg = xs_groups_for(h, ncols);
   if (xg == 0) return 0;
   // Two slab groups (262k < N <= 524k: four XCDs share a slab) pay only under the blocked matvec -- measured in round 3
@@ -1803,6 +1809,10 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_SPMM_XS")) h->spmm_xs = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_XS_NB")) h->xs_nb = std::max(1, atoi(e));
     if (const char* e = getenv("OSC_XS_MIN_COLS")) h->xs_min_cols = std::max(32, atoi(e));
+    if (const char* e = getenv("OSC_XS_MIN_ROWS")) {
+      int a = 0, b = 0;
+      if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) h->xs_min_rows = a, h->xs_min_rows_narrow = b;
+    }
     if (const char* e = getenv("OSC_XS_MIN_GROUPS")) h->xs_groups_min = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("OSC_XS_GROUPS")) {
       const int g = atoi(e);
