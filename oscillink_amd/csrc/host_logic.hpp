@@ -247,7 +247,7 @@ inline int64_t blocked_list_extent(int64_t N, const BlockedGeom& g, int gather_w
 // whatever k is and however many XCDs share a slab (the per-rank windows of a sharded config-3 solve, two to eight XCDs
 // per slab at N = 100k, also run fastest at 3.3).  Config 5 (N = 200k, k = 64): 16 -> 24 blocks took the L2 misses per
 // apply from 367 M to 183 M, the bytes fetched from 45.6 to 22.5 GB and the apply from 6.98 to 5.00 ms.
-inline double blocked_edges_per_block(int64_t N) { return N <= 140000 ? 3.3 : 2.4; }
+inline double blocked_edges_per_block(int64_t N) { return N <= 140000 ? 3.3 : 2.5; }
 inline int blocked_block_count(double mean_deg, double edges_per_block, int max_blocks) {
   const int nb = (int)std::max(2.0, std::floor(mean_deg / edges_per_block + 0.5));
   return std::min(nb, max_blocks);

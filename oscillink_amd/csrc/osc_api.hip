@@ -233,7 +233,7 @@ struct osc_lattice {
   int blk_nb = 0;          // blocks of the copy held (0 = none / stale)
   int spmm_blocked = -1;   // -1 by lattice size, 0 off, > 0 = that many source blocks (OSC_SPMM_BLOCKED)
   double blk_mb = 2.0;     // smallest slab (N x 128 B, MiB) the blocked apply is chosen for (OSC_BLK_MB)
-  double blk_edges = 0.0;  // edges of a row per source block the block count aims at; 0 = by lattice size: 3.3 / 2.4 (OSC_BLK_EDGES)
+  double blk_edges = 0.0;  // edges of a row per source block the block count aims at; 0 = by lattice size: 3.3 / 2.5 (OSC_BLK_EDGES)
   int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
   int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
   double temporal_mb = 200.0;  // largest solve (5 arrays x N x window) whose update kernels use ordinary instead of nontemporal accesses (OSC_TEMPORAL_MB)
