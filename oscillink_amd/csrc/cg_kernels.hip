@@ -708,7 +708,9 @@ __global__ __launch_bounds__(256) void k_init_finish(const InitFinishArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int LPR, int NCH>
+// WITHX = false: the x update of this iteration is left to the next iteration's k_update_p (or to k_update_x behind the
+// last one): this kernel then moves r and Ap only (run_cg).
+template <int LPR, int NCH, bool WITHX>
 __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
   constexpr int RPW = 64 / LPR;
   constexpr int CPW = NCH * LPR * 4;
@@ -739,13 +741,17 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
     for (int ch = 0; ch < NCH; ++ch) {
       if (!cok[ch]) continue;
       const size_t off = (size_t)row * ld + coff[ch];
-      float4 x = ld4_sel(a.X + off, tmp), p = ld4_sel(a.P + p_off(a, row, coff[ch]), tmp), r = ld4_sel(a.R + off, tmp);
+      float4 r = ld4_sel(a.R + off, tmp);
       const float4 ap = ld4_sel(a.AP + off, tmp);
-      x.x = fmaf(p.x, al[ch].x, x.x); x.y = fmaf(p.y, al[ch].y, x.y);
-      x.z = fmaf(p.z, al[ch].z, x.z); x.w = fmaf(p.w, al[ch].w, x.w);
+      if constexpr (WITHX) {
+        float4 x = ld4_sel(a.X + off, tmp);
+        const float4 p = ld4_sel(a.P + p_off(a, row, coff[ch]), tmp);
+        x.x = fmaf(p.x, al[ch].x, x.x); x.y = fmaf(p.y, al[ch].y, x.y);
+        x.z = fmaf(p.z, al[ch].z, x.z); x.w = fmaf(p.w, al[ch].w, x.w);
+        st4_sel(a.X + off, x, tmp);
+      }
       r.x = fmaf(-ap.x, al[ch].x, r.x); r.y = fmaf(-ap.y, al[ch].y, r.y);
       r.z = fmaf(-ap.z, al[ch].z, r.z); r.w = fmaf(-ap.w, al[ch].w, r.w);
-      st4_sel(a.X + off, x, tmp);
       st4_sel(a.R + off, r, tmp);
       rr[ch] = mulacc4(r, r, rr[ch]);
       const float4 z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
@@ -756,7 +762,10 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
   block_fold<LPR, NCH>(rz, red, a.part_rz, ld, a.c0, a.c1);
 }
 
-template <int LPR, int NCH>
+// WITHX: also the PREVIOUS iteration's x update, x += alpha p with the p this kernel is about to replace (alpha is still
+// that iteration's: the next reduce_alpha comes behind the matvec).  WITHX and UPD_P = false: only that (behind the last
+// iteration of a solve).
+template <int LPR, int NCH, bool WITHX, bool UPD_P = true>
 __global__ __launch_bounds__(256) void k_update_p(const UpdateArgs a) {
   constexpr int RPW = 64 / LPR;
   if (a.gate != nullptr && *a.gate <= a.gate_tol) return;
@@ -766,29 +775,38 @@ __global__ __launch_bounds__(256) void k_update_p(const UpdateArgs a) {
   const bool tmp = a.temporal != 0;
   int coff[NCH];
   bool cok[NCH];
-  float4 be[NCH];
+  float4 be[NCH], al[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     coff[ch] = a.c0 + (ch * LPR + lr) * 4;
     cok[ch] = coff[ch] < a.c1;
-    be[ch] = cok[ch] ? ld4(a.beta + coff[ch]) : f4(0.f);
+    be[ch] = (cok[ch] && UPD_P) ? ld4(a.beta + coff[ch]) : f4(0.f);
+    al[ch] = (cok[ch] && WITHX) ? ld4(a.alpha + coff[ch]) : f4(0.f);
   }
   const int64_t rend = a.N;  // streaming kernels: plain grid-stride over the row range
   for (int64_t rb = a.row0 + ((int64_t)blockIdx.x * 4 + wave) * RPW; rb < rend; rb += (int64_t)gridDim.x * 4 * RPW) {
     const int row = (int)rb + sub;
     if (row >= rend) continue;
     float invMd = 1.f;
-    if (a.op.precond) invMd = 1.f / (fmaf(a.op.md_B, a.B[row], a.op.md_const) + 1e-12f);
+    if (UPD_P && a.op.precond) invMd = 1.f / (fmaf(a.op.md_B, a.B[row], a.op.md_const) + 1e-12f);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       if (!cok[ch]) continue;
       const size_t off = (size_t)row * ld + coff[ch];
       const size_t poff = p_off(a, row, coff[ch]);
-      const float4 r = ld4_sel(a.R + off, tmp);
       float4 p = ld4_sel(a.P + poff, tmp);
-      p.x = fmaf(p.x, be[ch].x, r.x * invMd); p.y = fmaf(p.y, be[ch].y, r.y * invMd);
-      p.z = fmaf(p.z, be[ch].z, r.z * invMd); p.w = fmaf(p.w, be[ch].w, r.w * invMd);
-      st4(a.P + poff, p);
+      if constexpr (WITHX) {
+        float4 x = ld4_sel(a.X + off, tmp);
+        x.x = fmaf(p.x, al[ch].x, x.x); x.y = fmaf(p.y, al[ch].y, x.y);
+        x.z = fmaf(p.z, al[ch].z, x.z); x.w = fmaf(p.w, al[ch].w, x.w);
+        st4_sel(a.X + off, x, tmp);
+      }
+      if constexpr (UPD_P) {
+        const float4 r = ld4_sel(a.R + off, tmp);
+        p.x = fmaf(p.x, be[ch].x, r.x * invMd); p.y = fmaf(p.y, be[ch].y, r.y * invMd);
+        p.z = fmaf(p.z, be[ch].z, r.z * invMd); p.w = fmaf(p.w, be[ch].w, r.w * invMd);
+        st4(a.P + poff, p);
+      }
     }
   }
 }
@@ -1070,15 +1088,35 @@ void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s) {
 
 void launch_update_xr(const UpdateArgs& a, int grid, hipStream_t s) {
   const Shape sh = pick_shape(a.c1 - a.c0);
-#define CALL(L, C) hipLaunchKernelGGL((k_update_xr<L, C>), dim3(grid), dim3(256), 0, s, a)
-  OSC_SHAPE_SWITCH(sh, CALL);
+#define CALL(L, C) hipLaunchKernelGGL((k_update_xr<L, C, true>), dim3(grid), dim3(256), 0, s, a)
+#define CALL_NOX(L, C) hipLaunchKernelGGL((k_update_xr<L, C, false>), dim3(grid), dim3(256), 0, s, a)
+  if (a.xmode & OSC_XMODE_XR_SKIPS_X) {
+    OSC_SHAPE_SWITCH(sh, CALL_NOX);
+  } else {
+    OSC_SHAPE_SWITCH(sh, CALL);
+  }
 #undef CALL
+#undef CALL_NOX
   HIP_CHECK(hipGetLastError());
 }
 
 void launch_update_p(const UpdateArgs& a, int grid, hipStream_t s) {
   const Shape sh = pick_shape(a.c1 - a.c0);
-#define CALL(L, C) hipLaunchKernelGGL((k_update_p<L, C>), dim3(grid), dim3(256), 0, s, a)
+#define CALL(L, C) hipLaunchKernelGGL((k_update_p<L, C, false>), dim3(grid), dim3(256), 0, s, a)
+#define CALL_X(L, C) hipLaunchKernelGGL((k_update_p<L, C, true>), dim3(grid), dim3(256), 0, s, a)
+  if (a.xmode & OSC_XMODE_P_APPLIES_X) {
+    OSC_SHAPE_SWITCH(sh, CALL_X);
+  } else {
+    OSC_SHAPE_SWITCH(sh, CALL);
+  }
+#undef CALL
+#undef CALL_X
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_update_x(const UpdateArgs& a, int grid, hipStream_t s) {  // x += alpha p
+  const Shape sh = pick_shape(a.c1 - a.c0);
+#define CALL(L, C) hipLaunchKernelGGL((k_update_p<L, C, true, false>), dim3(grid), dim3(256), 0, s, a)
   OSC_SHAPE_SWITCH(sh, CALL);
 #undef CALL
   HIP_CHECK(hipGetLastError());
@@ -1100,6 +1138,17 @@ void launch_reduce_beta(const float* part_rr, const float* part_rz, int nb, int3
                         float* host_slot) {
   hipLaunchKernelGGL(k_reduce_beta, dim3(red_grid(c0, c1)), dim3(1024), 0, s, part_rr, part_rz, nb, ld, c0, c1, rz,
                      beta, res_bits_slot, g, done_ctr, host_slot);
+  HIP_CHECK(hipGetLastError());
+}
+namespace {
+// one word device -> host-mapped memory (the globally reduced residual of a sharded solve, behind its all-reduce)
+__global__ void k_publish_word(const uint32_t* src, uint32_t* host_slot) {
+  *reinterpret_cast<volatile uint32_t*>(host_slot) = *reinterpret_cast<const volatile uint32_t*>(src);
+  __threadfence_system();
+}
+}  // namespace
+void launch_publish_word(const uint32_t* src, uint32_t* host_slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_publish_word, dim3(1), dim3(1), 0, s, src, host_slot);
   HIP_CHECK(hipGetLastError());
 }
 void launch_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols, hipStream_t s) {

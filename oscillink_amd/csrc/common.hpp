@@ -181,7 +181,12 @@ struct UpdateArgs {
   // mid-size lattice): X, R, AP are then read and written with ordinary loads / stores so that the next kernel finds them
   // there; 0: streamed nontemporally (they would only push the gathered operand out).
   int32_t temporal;
+  // where the x update happens (run_cg): 0 = in k_update_xr, next to the r update (x, r, p, Ap read; x, r written);
+  // OSC_XMODE_XR_SKIPS_X: not there; OSC_XMODE_P_APPLIES_X: k_update_p applies the PREVIOUS iteration's while it has p in
+  // hand (launch_update_x behind the last iteration) -- one array pass less per iteration
+  int32_t xmode;
 };
+constexpr int32_t OSC_XMODE_XR_SKIPS_X = 1, OSC_XMODE_P_APPLIES_X = 2;
 
 struct Gate {
   const float* p;
@@ -242,6 +247,7 @@ int blocked_resident_per_cu();
 void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s);
 void launch_update_xr(const UpdateArgs& a, int grid, hipStream_t s);
 void launch_update_p(const UpdateArgs& a, int grid, hipStream_t s);
+void launch_update_x(const UpdateArgs& a, int grid, hipStream_t s);  // x += alpha p (UpdateArgs::xmode)
 // column reductions over `nb` partial rows
 void launch_reduce_init(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* rz, hipStream_t s);
 void launch_reduce_alpha(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, const double* rz,
@@ -249,6 +255,7 @@ void launch_reduce_alpha(const float* part, int nb, int32_t ld, int32_t c0, int3
 void launch_reduce_beta(const float* part_rr, const float* part_rz, int nb, int32_t ld, int32_t c0, int32_t c1,
                         double* rz, float* beta, uint32_t* res_bits_slot, Gate g, hipStream_t s,
                         uint32_t* done_ctr = nullptr, float* host_slot = nullptr);
+void launch_publish_word(const uint32_t* src, uint32_t* host_slot, hipStream_t s);
 void launch_reduce_sum(const float* part, int nb, int32_t ld, int32_t c0, int32_t c1, double* out_cols,
                        hipStream_t s);
 void launch_axpby(float* out, const float* a, float ca, const float* b, float cb, int64_t n, hipStream_t s);

@@ -224,7 +224,8 @@ struct osc_lattice {
   DevBuf<double> rz, colsum;
   DevBuf<uint32_t> res_bits, arrive;  // arrive: per-iteration barrier counters (+1 status word) of the one-launch path
   bool small_path = true;             // OSC_SMALL_PATH=0 disables the one-launch CG for small lattices
-  int predicted_iters = 0;            // iterations the last general-path solve of this handle took (0 = unknown)
+  int predicted_iters[3] = {0, 0, 0};  // iterations the last general-path solve of each kind (CgBuffers::kind) took (0 = unknown)
+  bool x_defer = true;                // the x update rides in the next iteration's p update (run_cg; OSC_X_DEFER=0: beside the r update)
   DevBuf<int32_t> ell_col_t;          // transposed ELL for the one-launch path (built on first use per graph)
   DevBuf<float> ell_w_t;
   bool ell_t_ready = false;
@@ -246,6 +247,12 @@ struct osc_lattice {
   size_t res_host_n = 0;
   bool mapped_residual = true;  // OSC_MAPPED_RES=0: copy + event per iteration instead
   std::vector<hipEvent_t> iter_events;
+  // sharded solves: the stop test's all-reduce runs on a second stream beside the next iteration's p update and matvec
+  // (run_cg); step_events[it] = "iteration it's local residual is out" (OSC_COMM_OVERLAP=0: all-reduce in the solve's stream)
+  hipStream_t comm_stream = nullptr;
+  std::vector<hipEvent_t> step_events;
+  bool comm_overlap = true;
+  bool comm_stream_busy = false;  // a solve left work on comm_stream (at most a speculative iteration's all-reduce + publish)
   std::vector<float> history;
   // column shard (multi-GPU, column-sharded CG); single GPU: [0, ld)
   int32_t c0 = 0, c1 = 0;
@@ -281,7 +288,10 @@ struct osc_lattice {
       (void)hipEventDestroy(s.b);
     }
     for (auto e : prof_pool) (void)hipEventDestroy(e);
+    if (comm_stream && comm_stream_busy) (void)hipStreamSynchronize(comm_stream);
+    for (auto e : step_events) (void)hipEventDestroy(e);
     park_ctrl();
+    release_stream(device, comm_stream);
     release_stream(device, stream);
   }
   void park_ctrl();
@@ -417,7 +427,16 @@ void download_api_order(L& h, float* dst, const float* src) {
 
 // residual slots + arrival counters on the device, their host-mapped mirror (the device publishes each iteration's
 // residual into it; also the read-back buffer of the one-launch path) and the per-iteration events
+// the second stream of an overlapped sharded solve (run_cg) writes residual slots and their host mirror: it must be idle
+// before those are cleared, resized or handed to another path
+void drain_comm_stream(L& h) {
+  if (!h.comm_stream_busy) return;
+  HIP_CHECK(hipStreamSynchronize(h.comm_stream));
+  h.comm_stream_busy = false;
+}
+
 void ensure_ctrl(L& h, size_t slots) {
+  drain_comm_stream(h);
   if (h.res_bits.n < 2 * slots) h.res_bits.alloc(2 * slots);  // [residual bits | arrival counters]
   if (!h.res_host && h.iter_events.empty()) {  // a parked control block of a destroyed handle, if any
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -1091,6 +1110,7 @@ struct CgBuffers {  // the arrays one solve works on (all N x ld)
   // one-launch small kernel may give up at its barrier -- writes here instead and reports it in CgResult::sol, so a
   // failed attempt never leaves the caller's state partly advanced.  nullptr: X is never aliased.
   float* Xalt = nullptr;
+  int kind = 0;  // 0 settle, 1 U*, 2 single right-hand side: repeated solves of one kind take the same iteration count
 };
 
 struct CgResult {
@@ -1185,8 +1205,26 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   // the host polls that word (no 4-byte copy, event record and event wait per iteration).  Under a communicator the
   // residual first goes through the all-reduce, so the copy + event path stays.
   const bool mapped = h.comm == nullptr && h.mapped_residual;
+  // Sharded (column windows): the stop test needs max over the ranks of the residual -- a 4-byte all-reduce per iteration,
+  // tens of microseconds of latency on xGMI next to ~180 us of kernels per iteration in an 8-rank window of config 3.
+  // With the x update deferred (below) a speculative iteration writes scratch arrays only (r, p, Ap, alpha, beta), so it
+  // needs no gate and the solve's stream never waits for the all-reduce: that goes to a second stream behind an event
+  // per iteration, followed by a one-thread kernel that publishes the reduced word into the host-mapped slot the host
+  // polls, as on one GPU.  The host alone decides when to stop; a wrong guess of the last iteration costs one iteration
+  // of device time instead of five gated-off launches.
+  const bool xdefer = h.x_defer;
+  const bool overlap = h.comm != nullptr && h.comm_overlap && h.mapped_residual && xdefer;
+  if (overlap) {
+    if (!h.comm_stream) h.comm_stream = acquire_stream(h.device);
+    while (h.step_events.size() < nslots) {
+      hipEvent_t e;
+      HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h.step_events.push_back(e);
+    }
+  }
+  const bool polled = mapped || overlap;
   constexpr uint32_t kPending = 0xFFFFFFFFu;  // never a residual (those are sqrt(...) >= 0 or a canonical NaN)
-  if (mapped)
+  if (polled)
     for (size_t i = 0; i < nslots; ++i) reinterpret_cast<volatile uint32_t*>(h.res_host)[i] = kPending;
   const float* res_dev = reinterpret_cast<const float*>(h.res_bits.p);
   SpmmArgs sa{};
@@ -1320,23 +1358,43 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   sa.xblk = pblk ? h.N : 0;
   sa.pblk = 0;
   h.blk_last = ba.nb;
+  // Deferred x update: iteration it's x += alpha p is applied by iteration it + 1's p update, which reads p anyway (x, r,
+  // p in / x, p out there, r, Ap in / r out in the x-r kernel: 8 array passes per iteration instead of 9), or by
+  // finish_x behind an iteration that has no successor enqueued.  x_done = iterations whose x update is applied or rides
+  // in an enqueued p update; x_rides_gated = the iteration whose update rides in a GATED p update (0: none).
+  int x_done = 0, x_rides_gated = 0;
+  auto finish_x = [&](int it) {
+    ua.gate = nullptr;
+    ua.xmode = OSC_XMODE_XR_SKIPS_X | OSC_XMODE_P_APPLIES_X;
+    for_windows(ua, [&](const UpdateArgs& w) { launch_update_x(w, grid, h.stream); });
+    x_done = it;
+    x_rides_gated = 0;
+  };
   auto enqueue_iter = [&](int it) {  // everything of iteration `it` up to its residual, gated on iteration it-1
-    const Gate g{it > 1 ? res_dev + (it - 1) : nullptr, tol};
-    sa.gate = g.p;
+    const Gate g{it > 1 && !overlap ? res_dev + (it - 1) : nullptr, tol};
+    const Gate ge = g;
+    sa.gate = ge.p;
     sa.gate_tol = tol;
-    ua.gate = g.p;
+    ua.gate = ge.p;
     ua.gate_tol = tol;
     if (it > 1) {
       ProfScope ps(h, 2, it);
-      for_windows(ua, [&](const UpdateArgs& w) { launch_update_p(w, grid, h.stream); });  // p = z + beta p (solver.py:32-36)
+      // p = z + beta p (solver.py:32-36), and iteration it - 1's x += alpha p (solver.py:27) with the p it replaces
+      ua.xmode = xdefer ? (OSC_XMODE_XR_SKIPS_X | (x_done < it - 1 ? OSC_XMODE_P_APPLIES_X : 0)) : 0;
+      for_windows(ua, [&](const UpdateArgs& w) { launch_update_p(w, grid, h.stream); });
+      if (xdefer && x_done < it - 1) {
+        x_done = it - 1;
+        x_rides_gated = g.p != nullptr ? it - 1 : 0;  // applied only if iteration it - 1 did not converge
+      }
     }
+    ua.xmode = xdefer ? OSC_XMODE_XR_SKIPS_X : 0;
     if (ba.nb > 0) {  // Ap and column sums of p.Ap
       ProfScope ps(h, 0, it);
-      ba.gate = g.p;
+      ba.gate = ge.p;
       ba.gate_tol = tol;
       launch_apply_blocked(ba, grid, h.stream);
       if (cf.chunks > 0) {
-        cf.gate = g.p;
+        cf.gate = ge.p;
         cf.gate_tol = tol;
         launch_chain_fix(cf, h.stream);
       }
@@ -1344,7 +1402,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     } else {
       spmm_slabbed(h, SPMM_AP, sa, grid, it);
     }
-    launch_reduce_alpha(h.part0.p, grid + (ba.nb > 0 ? cf.chunks : 0), b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
+    launch_reduce_alpha(h.part0.p, grid + (ba.nb > 0 ? cf.chunks : 0), b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, ge, h.stream);
     {
       ProfScope ps(h, 1, it);
       for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });
@@ -1355,13 +1413,20 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       return;
     }
     launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream);
+    if (overlap) {  // max over the shards (solver.py:29) and its way to the host, beside the next iteration's first kernels
+      HIP_CHECK(hipEventRecord(h.step_events[(size_t)it], h.stream));
+      HIP_CHECK(hipStreamWaitEvent(h.comm_stream, h.step_events[(size_t)it], 0));
+      h.comm->allreduce(h.res_bits.p + it, 1, COMM_F32, COMM_MAX, h.comm_stream);
+      launch_publish_word(h.res_bits.p + it, reinterpret_cast<uint32_t*>(h.res_host_dev + it), h.comm_stream);
+      return;
+    }
     // column-sharded: the stop test is the max over all shards (solver.py:29)
     if (h.comm) h.comm->allreduce(h.res_bits.p + it, 1, COMM_F32, COMM_MAX, h.stream);
     HIP_CHECK(hipMemcpyAsync(h.res_host + it, h.res_bits.p + it, 4, hipMemcpyDeviceToHost, h.stream));
     HIP_CHECK(hipEventRecord(h.iter_events[(size_t)it], h.stream));
   };
   auto wait_residual = [&](int it) -> float {
-    if (!mapped) {
+    if (!polled) {
       HIP_CHECK(hipEventSynchronize(h.iter_events[(size_t)it]));
       return h.res_host[it];
     }
@@ -1375,7 +1440,8 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
         return v;
       }
       if ((spin & 0x3FFF) == 0) {  // every ~16k polls: has the stream died or drained without publishing?
-        const hipError_t q = hipStreamQuery(h.stream);
+        hipError_t q = hipStreamQuery(h.stream);
+        if (q == hipSuccess && overlap) q = hipStreamQuery(h.comm_stream);  // the word comes out of the second stream
         if (q != hipSuccess && q != hipErrorNotReady) hip_check(q, "hipStreamQuery (CG residual wait)", __FILE__, __LINE__);
         if (q == hipSuccess && *slot == kPending) throw HipError("CG iteration finished without publishing its residual");
         if (now_ms() - t_start > 120000.0) throw HipError("timeout waiting for a CG residual");
@@ -1392,11 +1458,17 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   // launches of a needless speculative iteration cost ~22 us (8 % of a settle at N = 20000, D = 128).  A wrong guess
   // costs one host round trip: the iteration is then enqueued after its predecessor's residual has been read.
   // (Every rank of a sharded solve sees the same residuals, hence takes the same decisions.)
-  const int stop_guess = h.predicted_iters;
+  const int stop_guess = h.predicted_iters[b.kind];
   int enqueued = 1;
   enqueue_iter(1);
   for (int it = 1; it <= max_iters; ++it) {
-    if (it < max_iters && it != stop_guess && enqueued == it) enqueue_iter(++enqueued);  // speculative: no-ops if `it` converged
+    if (it < max_iters && it != stop_guess && enqueued == it) {
+      enqueue_iter(++enqueued);  // speculative: no-ops if `it` converged (overlap: ungated, scratch arrays only)
+    } else if (xdefer && x_done < it) {
+      // nothing is enqueued behind this iteration for now (the expected last one): its x update goes out at once.  The
+      // host has seen iteration it - 1 unconverged, so iteration `it` is a real one whatever its residual will say.
+      finish_x(it);
+    }
     const float res = wait_residual(it);
     h.history.push_back(res);
     out.res = res;
@@ -1406,11 +1478,16 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     }
     if (it < max_iters && enqueued == it) enqueue_iter(++enqueued);  // the guess was wrong: go on
   }
-  h.predicted_iters = out.iters;
+  h.predicted_iters[b.kind] = out.iters;
+  // the last iteration's x update rode in a gated p update that did not run (the solve converged under a speculative
+  // iteration): alpha and p are still that iteration's
+  if (xdefer && x_rides_gated == out.iters && x_done == out.iters) finish_x(out.iters);
   // The solution is complete once the last residual is out; what may still be queued are the gated-off launches of
   // the speculative iteration (they return at once and write nothing).  With the mapped read-back the stream is left
   // to drain on its own -- later calls are ordered behind it anyway; the copy + event path keeps its full wait.
-  if (!mapped || h.prof_on) sync(h);
+  // (overlap: the same; the second stream is drained by whoever next touches the residual slots it writes -- drain_comm_stream)
+  if (overlap) h.comm_stream_busy = true;
+  if (!polled || h.prof_on) sync(h);
   for (size_t i = prof_mark; i < h.prof_pending.size(); ++i)  // speculative (gated-off) launches are not samples
     if (h.prof_pending[i].iter > out.iters) h.prof_pending[i].which = -1;
   return out;
@@ -1826,6 +1903,8 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_SPMM_DEEP")) h->spmm_deep = atoi(e) != 0;
     if (const char* e = getenv("OSC_TEMPORAL_MB")) h->temporal_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
+    if (const char* e = getenv("OSC_COMM_OVERLAP")) h->comm_overlap = atoi(e) != 0;
+    if (const char* e = getenv("OSC_X_DEFER")) h->x_defer = atoi(e) != 0;
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
     if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_SHARD")) h->shard_mode = !strcmp(e, "row") ? 1 : 0;
@@ -2219,6 +2298,7 @@ int osc_solve_ustar(osc_handle h, float tol, int32_t max_iters, float* Ustar_out
     sync(l);
     const double t0 = now_ms();
     CgBuffers b{l.Y.p, l.X.p, l.R.p, l.P.p, l.AP.p, l.U.p, l.Y.p, l.B.p, l.psi.p, l.ld, l.c0, l.c1};
+    b.kind = 1;
     const CgResult r = run_cg(l, op, b, path_active(l), max_iters, tol);
     l.Ustar.swap(l.X);
     if (l.shard_mode == 0) gather_columns(l, l.Ustar.p);  // receipts read whole rows of U* (row mode: already whole)
@@ -2323,6 +2403,7 @@ int osc_cg_single_rhs(osc_handle h, float gamma, const float* s, float tol, int3
     op.rbY = 1.0f;
     op.rbB = 0.f;
     CgBuffers b{X0.p, X.p, R.p, P.p, AP.p, S.p, S.p, l.B.p, psi0.p, ld1, 0, ld1};
+    b.kind = 2;
     // scratch sized for ld >= 4 already
     std::unique_ptr<Comm> saved = std::move(l.comm);  // the diffusion solve is replicated, not sharded
     CgResult r;
@@ -2831,6 +2912,7 @@ int osc_comm_loopback_id(char id_out[128]) {
 int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world) {
   return guarded(h, [&](L& l) {
     if (world < 1 || rank < 0 || rank >= world) throw Invalid("osc_comm_init: bad rank/world");
+    drain_comm_stream(l);
     l.comm.reset();
     l.rank = rank;
     l.world = world;
@@ -2839,6 +2921,11 @@ int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world)
       l.c0 = 0;
       l.c1 = l.dcols;
     }
+    if (world == 1 && l.shard_mode == 0)  // measurement hook (osc_create): one rank's window of a wider solve, now WITH the
+      if (const char* e = getenv("OSC_FAKE_COL_SHARD")) {  // communicator machinery of a sharded solve around it
+        int r = 0, w = 1;
+        if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) std::tie(l.c0, l.c1) = host::column_shard(l.dcols, r, w);
+      }
     if (l.c1 <= l.c0) throw Invalid("osc_comm_init: more ranks than 4-column groups");
     l.comm = comm_create(id, rank, world, l.device);
     ++l.graph_epoch;

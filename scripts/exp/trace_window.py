@@ -9,7 +9,12 @@ from oscillink_amd import Oscillink
 rng = np.random.default_rng(0)
 Y = rng.standard_normal((N, D), dtype=np.float32)
 psi = Y[:32].mean(0); psi = (psi / np.linalg.norm(psi)).astype(np.float32)
-lat = Oscillink(Y, kneighbors=k); lat.set_query(psi)
+if os.environ.get("OSC_SHARD_TIMES_RCCL"):  # with a one-rank RCCL communicator: the sharded code path of run_cg
+    from oscillink_amd.sharding import rccl_unique_id
+    lat = Oscillink(Y, kneighbors=k, comm=(rccl_unique_id(), 0, 1))
+else:
+    lat = Oscillink(Y, kneighbors=k)
+lat.set_query(psi)
 ts = []
 for _ in range(12):
     lat.reset_U(); t0 = time.perf_counter(); st = lat.settle(max_iters=12, tol=1e-3); ts.append(time.perf_counter() - t0)

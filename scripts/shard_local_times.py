@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-rank compute of a column-sharded settle, measured on ONE GPU: OSC_FAKE_COL_SHARD=r/w makes the handle work on rank
 r's column slab of w without a communicator (no all-reduce(max), so this is the compute floor of the multi-GPU bench: the
-strong-scaling ceiling is t(1) / t(w)).
+strong-scaling ceiling is t(1) / t(w)).  With OSC_SHARD_TIMES_RCCL=1 the handle also gets a ONE-rank RCCL communicator, so
+the solve runs the sharded code path (stop test through ncclAllReduce, on the second stream or -- OSC_COMM_OVERLAP=0 --
+inside the solve's stream): what that machinery costs per settle before any xGMI latency.
 usage: shard_local_times.py [c3|c4|c5] [ranks ...]   (default: c3 1 2 4 8; c4 = 1M x 384 k 16; c5 = 200k x 1536 k 64 + chain)"""
 import ctypes as C
 import os
@@ -24,7 +26,12 @@ psi = (psi / np.linalg.norm(psi)).astype(np.float32)
 base = None
 for w in [int(a) for a in (args or ["1", "2", "4", "8"])]:
     os.environ["OSC_FAKE_COL_SHARD"] = f"0/{w}"
-    lat = Oscillink(Y, kneighbors=k)
+    if os.environ.get("OSC_SHARD_TIMES_RCCL"):
+        from oscillink_amd.sharding import rccl_unique_id
+
+        lat = Oscillink(Y, kneighbors=k, comm=(rccl_unique_id(), 0, 1))
+    else:
+        lat = Oscillink(Y, kneighbors=k)
     lat.set_query(psi)
     if cfg == "c5":
         lat.add_chain(list(range(8)), lamP=0.2)

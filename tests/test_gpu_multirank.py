@@ -196,12 +196,17 @@ def test_end_to_end_sharded_build_and_solve_vs_oracle(amd, orc, mode, monkeypatc
         assert dH == pytest.approx(dH_ref, rel=TOL)
 
 
-@pytest.mark.parametrize("mode", ["column", "row"])
+@pytest.mark.parametrize("mode", ["column", "row", "column-inline"])
 def test_stop_points_around_the_speculative_iteration(amd, mode, monkeypatch):
     """The host enqueues iteration it+1 (its kernels AND its collectives) before it reads iteration it's residual.
     Three stop points on every rank: convergence exactly at max_iters (no speculative iteration was enqueued),
     convergence before max_iters (the speculative iteration's collectives run gated-off on every rank), and no
     convergence at all (max_iters hit).  State and iteration counts must equal the single-handle run's."""
+    if mode == "column-inline":  # the stop test's all-reduce inside the solve's stream instead of beside it (run_cg)
+        mode = "column"
+        monkeypatch.setenv("OSC_COMM_OVERLAP", "0")
+    else:
+        monkeypatch.delenv("OSC_COMM_OVERLAP", raising=False)
     monkeypatch.setenv("OSC_SHARD", mode)
     monkeypatch.setenv("OSC_SMALL_PATH", "0")
     case = load_case("c2_n1200_d128_k16")
@@ -235,6 +240,82 @@ def test_stop_points_around_the_speculative_iteration(amd, mode, monkeypatch):
             assert gi == wi and len(gh) == len(wh)
             assert np.allclose(gh, wh, rtol=1e-3 if mode == "row" else 1e-6)
             assert relerr(gU, wU) < 2e-6  # same recurrences; only the summation order inside a row differs
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_overlapped_stop_test_gives_the_inline_results(amd, overlap, monkeypatch):
+    """Column-sharded solves with the residual all-reduce on the second stream (default) and inside the solve's stream:
+    the same recurrences, so residual histories and states are bit-identical between the two and across repeated
+    solves of one handle with changing iteration counts (a wrong guess of the last iteration leaves an ungated p update
+    and matvec of the never-used next iteration behind: they must not leak into the state)."""
+    monkeypatch.delenv("OSC_SHARD", raising=False)
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    monkeypatch.setenv("OSC_COMM_OVERLAP", overlap)
+    rng = np.random.default_rng(31)
+    N, D, k = 3000, 96, 12
+    Y = rng.standard_normal((N, D), dtype=np.float32)
+    psi = (Y[:9].mean(0) / np.linalg.norm(Y[:9].mean(0))).astype(np.float32)
+
+    def run(lat):
+        lat.set_query(psi)
+        out = []
+        for tol, max_iters in ((1e-3, 12), (1e-6, 40), (1e-2, 12), (1e-6, 3), (1e-3, 12)):
+            lat.reset_U()
+            st = dict(lat.settle(max_iters=max_iters, tol=tol))
+            out.append((st["iters"], lat.residual_history(), lat.U.copy()))
+            us = lat.solve_Ustar(tol=tol, max_iters=max_iters, use_cache=False).copy()
+            out.append((lat.last_ustar["iters"], lat.residual_history(), us))
+        return out
+
+    single = amd.Oscillink(Y, kneighbors=k)
+    want = run(single)
+    assert len({w[0] for w in want}) >= 3  # the iteration count does change from solve to solve
+
+    def rank_fn(rank, comm):
+        return run(amd.Oscillink(Y, kneighbors=k, comm=comm))
+
+    for got in _ranks(3, rank_fn):
+        for (gi, gh, gU), (wi, wh, wU) in zip(got, want):
+            assert gi == wi and len(gh) == len(wh)
+            assert np.allclose(gh, wh, rtol=1e-6)
+            assert relerr(gU, wU) < 2e-6
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_rccl_communicator_of_one_rank_runs_the_sharded_path(amd, overlap, monkeypatch):
+    """The RCCL backend itself (ncclCommInitRank, ncclAllReduce on the solve's second stream, the broadcasts of the
+    column gather) with the one rank a one-GPU box allows: same results as without a communicator."""
+    import ctypes as C
+
+    from oscillink_amd.sharding import rccl_unique_id
+
+    monkeypatch.delenv("OSC_SHARD", raising=False)
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    monkeypatch.setenv("OSC_COMM_OVERLAP", overlap)
+    rng = np.random.default_rng(32)
+    N, D, k = 2500, 64, 10
+    Y = rng.standard_normal((N, D), dtype=np.float32)
+    psi = (Y[:5].mean(0) / np.linalg.norm(Y[:5].mean(0))).astype(np.float32)
+
+    def run(lat):
+        lat.set_query(psi)
+        st = dict(lat.settle(max_iters=12, tol=1e-3))
+        U = lat.U.copy()
+        st2 = dict(lat.settle(max_iters=12, tol=1e-5))
+        Us = lat.solve_Ustar().copy()
+        return st["iters"], st2["iters"], lat.residual_history(), U, lat.U.copy(), Us, lat.receipt()["deltaH_total"]
+
+    want = run(amd.Oscillink(Y, kneighbors=k))
+    lat = amd.Oscillink(Y, kneighbors=k, comm=(rccl_unique_id(), 0, 1))
+    kind = C.create_string_buffer(16)
+    world = C.c_int32(0)
+    lat._call("osc_comm_info", None, C.byref(world), None, kind, 16)
+    assert (kind.value.decode(), int(world.value)) == ("rccl", 1)
+    got = run(lat)
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    for a, b in zip(got[3:6], want[3:6]):
+        assert np.array_equal(a, b)
+    assert got[6] == want[6]
 
 
 def test_mismatched_collective_sequences_fail_instead_of_hanging(amd, monkeypatch):

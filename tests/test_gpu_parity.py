@@ -1312,3 +1312,45 @@ def test_source_blocked_apply_on_injected_degenerate_graphs(amd, kind, monkeypat
     for mode in ("2", "7", "16"):
         assert out[mode][0] == out["0"][0], (kind, mode)
         assert relerr(out[mode][1], out["0"][1]) < 1e-6 and relerr(out[mode][2], out["0"][2]) < 1e-6, (kind, mode)
+
+
+@pytest.mark.parametrize("path", ["plain", "slab", "blocked"])
+def test_deferred_x_update_leaves_the_same_state_at_every_stop_point(amd, path, monkeypatch):
+    """run_cg applies iteration it's x += alpha p inside iteration it + 1's p update (or in a kernel of its own behind an
+    iteration that has no successor enqueued); OSC_X_DEFER=0 is the loop with the x update next to the r update.  The
+    arithmetic per element is the same, so states, residual histories and iteration counts must be bit-identical --
+    whatever the stop point is relative to the iteration count the handle guesses from its previous solve of that kind:
+    convergence at the guess, before it (under a speculative iteration), after it, and max_iters without convergence."""
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    monkeypatch.delenv("OSC_REORDER", raising=False)
+    if path == "plain":
+        monkeypatch.setenv("OSC_SPMM_XS", "0")
+    else:
+        monkeypatch.setenv("OSC_SPMM_XS", "1")
+        monkeypatch.setenv("OSC_SPMM_BLOCKED", "3" if path == "blocked" else "0")
+    rng = np.random.default_rng(77)
+    N, D, k = 3100, 96, 12
+    Y = rng.standard_normal((N, D), dtype=np.float32)
+    psi = (Y[:7].mean(0) / np.linalg.norm(Y[:7].mean(0))).astype(np.float32)
+
+    def run(defer):
+        monkeypatch.setenv("OSC_X_DEFER", defer)
+        lat = amd.Oscillink(Y, kneighbors=k)
+        lat.set_query(psi)
+        lat.add_chain([3, 40, 41, 900], lamP=0.3)
+        out = []
+        for tol, max_iters, inertia in ((1e-3, 12, 0.0), (1e-3, 12, 0.0), (1e-6, 40, 0.0), (1e-2, 12, 0.3), (1e-7, 3, 0.0),
+                                        (1e-3, 1, 0.0), (1e-3, 12, 0.0)):
+            lat.reset_U()
+            st = dict(lat.settle(max_iters=max_iters, tol=tol, inertia=inertia))
+            out.append((st["iters"], lat.residual_history(), lat.U.copy()))
+            us = lat.solve_Ustar(tol=tol, max_iters=max_iters, use_cache=False).copy()
+            out.append((lat.last_ustar["iters"], lat.residual_history(), us))
+        lat.close()
+        return out
+
+    a, b = run("1"), run("0")
+    assert len({x[0] for x in a}) >= 4
+    for (ia, ha, Ua), (ib, hb, Ub) in zip(a, b):
+        assert ia == ib and ha == hb
+        assert np.array_equal(Ua, Ub)
