@@ -368,13 +368,23 @@ __device__ __forceinline__ void blk_fold(float4 dot, float (&red)[NW][32], float
   }
 }
 
-template <int GM, int CW>
-__global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_apply_blocked(const BlkArgs a) {
+// INIT (BlkInit): the solve's initial residual in the same launch.  X holds x0 slab-major, and where a row's sums are
+// complete the epilogue forms r = rhs - A x0 with rhs = rbU x0 + rbY y + rbB B psi (y = ii.Y's row, or x0 itself: the
+// warm-started settle, whose rhs state term IS x0, and the U* solve, which starts from Y and has no state term),
+// z = M^-1 r, stores r row-major and z SLAB-MAJOR into ii.Z -- the first search direction, in the array the caller uses
+// as P from here on --, copies x0 into the solution array where that is another one, and the column sums are those of
+// r . z.  Saves the separate pass over A x0, x0, y, r, p (k_init_finish: five array passes) for one more row read or
+// write here.
+template <int GM, int CW, bool INIT = false>
+__global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_apply_blocked(const BlkArgs a,
+                                                                                                            const BlkInit ii) {
   constexpr int SL = OSC_BLK_SLOTS, NT = (CW + 1) * 64;
   __shared__ __attribute__((aligned(16))) float red[CW + 1][32];
   // per gathering wave: the slots of each of its rows in the current block, and (other half) in the next one
   __shared__ __attribute__((aligned(16))) int2 stage[2][GM][CW][8 * SL];
-  if (a.gate != nullptr && *a.gate <= a.gate_tol) return;
+  if constexpr (!INIT) {  // (the INIT pass is never speculative)
+    if (a.gate != nullptr && *a.gate <= a.gate_tol) return;
+  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane >> 3, lr = lane & 7;
   const int32_t ld = a.ld;
@@ -484,28 +494,42 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
       // Own rows / gates / rest descriptors of EC groups at a time (these loads miss).  Loads and stores of a wave retire
       // in issue order, so the loads of batch k + 1 are issued BEFORE the stores of batch k: otherwise every batch would
       // also wait for the previous batch's stores to be acknowledged.
-      constexpr int EC = 2, NBATCH = (GM + EC - 1) / EC;
+      constexpr int EC = INIT ? 1 : 2, NBATCH = (GM + EC - 1) / EC;  // (INIT: the y rows take the second group's registers; two groups: 72 spills)
       float4 xs[2][EC];
+      float4 ys[2][INIT ? EC : 1];
       int2 rr[2][EC];
       float bv[2][EC];
-      auto fetch = [&](int k, float4 (&x)[EC], int2 (&r)[EC], float (&bb)[EC]) {
+      float4 psi4 = f4(0.f);
+      float* zbase = nullptr;
+      const uint32_t ldb = (uint32_t)ld * 4u, cb = (uint32_t)(p.sc0 + lr * 4) * 4u;
+      // (INIT: the 14 dwords of `ii` cost the kernel 22 scalar-register spills into vector lanes; reading them from the
+      // kernel-argument segment here, per closing sub-phase, was tried -- 12 spills, the same 700 us at config 3)
+      if constexpr (INIT) {
+        if (cok) psi4 = ld4(ii.psi + p.sc0 + lr * 4);
+        zbase = ii.Z + (size_t)(p.sc0 >> 5) * (size_t)a.N * 32;
+      }
+      auto fetch = [&](int k, float4 (&x)[EC], float4 (&y)[INIT ? EC : 1], int2 (&r)[EC], float (&bb)[EC]) {
 #pragma unroll
         for (int i = 0; i < EC; ++i) {
           const int g = k * EC + i, row = row_first + g * w8;
           x[i] = f4(0.f);
           r[i] = make_int2(0, 0);
           bb[i] = 0.f;
+          if constexpr (INIT) y[i] = f4(0.f);
           if (g < GM && g < ng && row < rhi && cok) {
             x[i] = ld4_at(xbase, (uint32_t)row * 128u + lr16);
             r[i] = ld2_at(a.rest, (uint32_t)row * 8u);  // edges beyond SL per block: {first, count}, ascending columns
             bb[i] = ld1_at(a.B, (uint32_t)row * 4u);
+            if constexpr (INIT) {  // (byte offsets of a row-major array fit 32 bits: launch_apply_blocked checks N * ld)
+              if (ii.Y != nullptr) y[i] = ld4_stream(reinterpret_cast<const float*>(reinterpret_cast<const char*>(ii.Y) + ((uint32_t)row * ldb + cb)));
+            }
           }
         }
       };
-      fetch(0, xs[0], rr[0], bv[0]);
+      fetch(0, xs[0], ys[0], rr[0], bv[0]);
 #pragma unroll
       for (int k = 0; k < NBATCH; ++k) {
-        if (k + 1 < NBATCH) fetch(k + 1, xs[(k + 1) & 1], rr[(k + 1) & 1], bv[(k + 1) & 1]);
+        if (k + 1 < NBATCH) fetch(k + 1, xs[(k + 1) & 1], ys[(k + 1) & 1], rr[(k + 1) & 1], bv[(k + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < EC; ++i) {
           const int g = k * EC + i, row = row_first + g * w8;
@@ -521,8 +545,24 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
           o.y = cs * xs[k & 1][i].y - a.cW * acc[g].y;
           o.z = cs * xs[k & 1][i].z - a.cW * acc[g].z;
           o.w = cs * xs[k & 1][i].w - a.cW * acc[g].w;
-          st4_stream(a.OUT + ((size_t)(uint32_t)row * (uint32_t)ld + (uint32_t)(p.sc0 + lr * 4)), o);
-          dot[0] = mulacc4(xs[k & 1][i], o, dot[0]);
+          if constexpr (INIT) {
+            const float4 x = xs[k & 1][i], y = ii.Y != nullptr ? ys[k & 1][i] : x;
+            const float qb = ii.rbB * bv[k & 1][i];
+            const float invMd = 1.f / (fmaf(ii.md_B, bv[k & 1][i], ii.md_const) + 1e-12f);  // (no preconditioner: md_B = 0, md_const = 1)
+            float4 r, z;  // (k_init_finish's expressions)
+            r.x = (ii.rbU * x.x + ii.rbY * y.x + qb * psi4.x) - o.x;
+            r.y = (ii.rbU * x.y + ii.rbY * y.y + qb * psi4.y) - o.y;
+            r.z = (ii.rbU * x.z + ii.rbY * y.z + qb * psi4.z) - o.z;
+            r.w = (ii.rbU * x.w + ii.rbY * y.w + qb * psi4.w) - o.w;
+            z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
+            st4_stream(reinterpret_cast<float*>(reinterpret_cast<char*>(ii.R) + ((uint32_t)row * ldb + cb)), r);
+            if (ii.Xcopy != nullptr) st4_stream(reinterpret_cast<float*>(reinterpret_cast<char*>(ii.Xcopy) + ((uint32_t)row * ldb + cb)), x);
+            st4(reinterpret_cast<float*>(reinterpret_cast<char*>(zbase) + ((uint32_t)row * 128u + lr16)), z);
+            dot[0] = mulacc4(r, z, dot[0]);
+          } else {
+            st4_stream(a.OUT + ((size_t)(uint32_t)row * (uint32_t)ld + (uint32_t)(p.sc0 + lr * 4)), o);
+            dot[0] = mulacc4(xs[k & 1][i], o, dot[0]);
+          }
         }
       }
     }
@@ -1040,16 +1080,21 @@ void launch_chain_fix(const ChainFixArgs& a, hipStream_t s) {
 }
 int blocked_resident_per_cu() {
   int n = 0;
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_apply_blocked<kBlkGroups, kBlkGatherWaves>, (kBlkGatherWaves + 1) * 64, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_apply_blocked<kBlkGroups, kBlkGatherWaves, false>, (kBlkGatherWaves + 1) * 64, 0));
   return n;
 }
 
-void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s) {
+void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s, const BlkInit* init) {
   if (grid < 8 || (grid & 7) != 0 || a.xs < 1 || a.xs > grid / 8 || a.xs_groups < 1 || 8 % a.xs_groups != 0 || a.groups < 1 ||
       a.groups > kBlkGroups || a.slices < 1 || a.nb < 1 || a.nb > OSC_MAX_SRC_BLOCKS || !a.slots || !a.rest ||
       (int64_t)a.N * a.ld * 4 >= ((int64_t)1 << 32) || (a.c0 & 31) != 0)
     throw std::runtime_error("blocked apply: unsupported arguments");
-  hipLaunchKernelGGL((k_apply_blocked<kBlkGroups, kBlkGatherWaves>), dim3(grid), dim3((kBlkGatherWaves + 1) * 64), 0, s, a);
+  if (init != nullptr) {
+    if (!init->R || !init->Z || !init->psi || init->Z == a.X) throw std::runtime_error("blocked apply: bad INIT arguments");
+    hipLaunchKernelGGL((k_apply_blocked<kBlkGroups, kBlkGatherWaves, true>), dim3(grid), dim3((kBlkGatherWaves + 1) * 64), 0, s, a, *init);
+  } else {
+    hipLaunchKernelGGL((k_apply_blocked<kBlkGroups, kBlkGatherWaves, false>), dim3(grid), dim3((kBlkGatherWaves + 1) * 64), 0, s, a, BlkInit{});
+  }
   HIP_CHECK(hipGetLastError());
 }
 

@@ -122,6 +122,16 @@ struct BlkArgs {
   int32_t nb, groups, slices;  // source blocks; row groups (of 8 rows) per gathering wave and slice; dest-row slices
 };
 
+// k_apply_blocked as the solve's INIT pass (r = rhs - A x0, z, r . z in the matvec's epilogue): see the kernel
+struct BlkInit {
+  const float* Y;    // rhs term, row-major; nullptr: it is x0 (BlkArgs::X)
+  float* Xcopy;      // nullptr, or the solution array x0 is copied to (row-major)
+  float* R;          // residual out, row-major
+  float* Z;          // z = M^-1 r out, SLAB-major like BlkArgs::X (must not be that array)
+  const float* psi;  // [ld]
+  float rbU, rbY, rbB, md_B, md_const;  // no preconditioner: md_B = 0, md_const = 1
+};
+
 enum SpmmMode { SPMM_AP = 0, SPMM_INIT = 1, SPMM_DOT = 2 };
 
 struct SpmmArgs {
@@ -242,7 +252,7 @@ void launch_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, in
 void launch_init_finish(const InitFinishArgs& a, int grid, hipStream_t s);
 int chain_fix_chunks(int32_t prows);
 void launch_chain_fix(const ChainFixArgs& a, hipStream_t s);
-void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s);
+void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s, const BlkInit* init = nullptr);
 int blocked_resident_per_cu();
 void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s);
 void launch_update_xr(const UpdateArgs& a, int grid, hipStream_t s);

@@ -240,6 +240,7 @@ struct osc_lattice {
   double temporal_mb = 200.0;  // largest solve (5 arrays x N x window) whose update kernels use ordinary instead of nontemporal accesses (OSC_TEMPORAL_MB)
   bool spmm_deep = true;   // re-ordered lattices: the operator apply with 8 gathers in flight per row (OSC_SPMM_DEEP=0: the usual 2)
   bool blk_init = true;    // the initial residual goes through the blocked matvec as well (OSC_BLK_INIT=0: plain INIT apply)
+  bool blk_init_fused = true;  // ... and is formed in that launch's epilogue where it can be (OSC_BLK_INIT=2: separate finish pass)
   int64_t blk_applies = 0; // blocked matvecs enqueued since creation
   int64_t small_solves = 0;
   float* res_host = nullptr;  // pinned, host-mapped mirror of res_bits for the per-iteration read-back
@@ -1302,7 +1303,36 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
 
   // (an inertia start hands over x0 IN the AP array, which the blocked matvec would overwrite with A x0 before
   // init_finish has read x0: such a solve keeps the gathering INIT kernel, which reads x0 completely first)
-  if (ba.nb > 0 && h.blk_init && b.x0 != b.AP) {
+  float* Pbuf = b.P;   // search direction / operator output: the fused INIT pass below leaves p in the AP array and
+  float* APbuf = b.AP;  // swaps the two for the rest of the solve
+  // (the rhs rows the fused pass can take besides x0 itself: one -- the state term must be x0 or absent, and if y is a
+  // third array the solution array must be x0)
+  const bool fuse_u = b.rhsU == b.x0 || op.rbU == 0.f;
+  const bool fuse_y = b.rhsY == b.x0 || b.X == b.x0;
+  if (ba.nb > 0 && h.blk_init && h.blk_init_fused && fuse_u && fuse_y && b.x0 != b.AP && cf.chunks == 0) {
+    // r = b - A x0 INSIDE the blocked matvec (the in-place warm-started settle: x0 is also the rhs state term and the
+    // solution array; the U* solve: x0 is Y, no state term): x0 -> slab-major (into P), then one launch gathers A x0 and
+    // leaves r, z (slab-major, in the AP array), x0 in the solution array and the r . z column sums
+    ProfScope ps(h, 4, 0);
+    launch_rows_to_slab(b.x0, b.P, h.N, b.ld, b.c0, b.c1, grid, h.stream);
+    BlkInit bi{};
+    bi.Y = b.rhsY == b.x0 ? nullptr : b.rhsY;
+    bi.Xcopy = b.X == b.x0 ? nullptr : b.X;
+    bi.R = b.R;
+    bi.Z = b.AP;
+    bi.psi = b.psi;
+    bi.rbU = b.rhsU == b.x0 ? op.rbU : 0.f;
+    bi.rbY = op.rbY;
+    bi.rbB = op.rbB;
+    bi.md_B = op.precond ? op.md_B : 0.f;
+    bi.md_const = op.precond ? op.md_const : 1.f;
+    ba.gate = nullptr;
+    ba.OUT = nullptr;
+    launch_apply_blocked(ba, grid, h.stream, &bi);
+    std::swap(Pbuf, APbuf);
+    ba.X = Pbuf;
+    ba.OUT = APbuf;
+  } else if (ba.nb > 0 && h.blk_init && b.x0 != b.AP) {
     // r = b - A x0 around the blocked matvec: x0 -> slab-major (into P), A x0 -> AP, then r, z, p = z, r . z
     ProfScope ps(h, 4, 0);
     launch_rows_to_slab(b.x0, b.P, h.N, b.ld, b.c0, b.c1, grid, h.stream);
@@ -1341,8 +1371,8 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   ua.temporal = 5.0 * (double)h.N * (double)(b.c1 - b.c0) * 4.0 <= h.temporal_mb * 1048576.0;
   ua.X = b.X;
   ua.R = b.R;
-  ua.P = b.P;
-  ua.AP = b.AP;
+  ua.P = Pbuf;
+  ua.AP = APbuf;
   ua.B = b.B;
   ua.alpha = h.alpha.p;
   ua.beta = h.beta.p;
@@ -1353,8 +1383,8 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   ua.ld = b.ld;
   ua.c0 = b.c0;
   ua.c1 = b.c1;
-  sa.X = b.P;
-  sa.OUT = b.AP;
+  sa.X = Pbuf;
+  sa.OUT = APbuf;
   sa.xblk = pblk ? h.N : 0;
   sa.pblk = 0;
   h.blk_last = ba.nb;
@@ -1899,7 +1929,10 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_SPMM_BLOCKED")) h->spmm_blocked = atoi(e);
     if (const char* e = getenv("OSC_BLK_MB")) h->blk_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_BLK_EDGES")) h->blk_edges = std::max(0.5, atof(e));
-    if (const char* e = getenv("OSC_BLK_INIT")) h->blk_init = atoi(e) != 0;
+    if (const char* e = getenv("OSC_BLK_INIT")) {
+      h->blk_init = atoi(e) != 0;
+      h->blk_init_fused = atoi(e) == 1;
+    }
     if (const char* e = getenv("OSC_SPMM_DEEP")) h->spmm_deep = atoi(e) != 0;
     if (const char* e = getenv("OSC_TEMPORAL_MB")) h->temporal_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
