@@ -589,6 +589,16 @@ __global__ __launch_bounds__(64) void k_chain_fix(const ChainFixArgs a) {
       float acc = 0.f;
       for (int e = 0; e < d; ++e) acc = fmaf(a.pw[(size_t)s * a.pwidth + e], xs[(size_t)a.pcol[(size_t)s * a.pwidth + e] * 32], acc);
       const float o = -a.cP * acc;
+      if (a.initR != nullptr) {  // behind the fused INIT pass: r and z of this row lack the chain term, and so does r . z
+        const float invMd = 1.f / (fmaf(a.md_B, a.B[i], a.md_const) + 1e-12f);
+        float* zp = a.initZ + (size_t)(col >> 5) * (size_t)a.N * 32 + (size_t)i * 32 + (col & 31);
+        const float r0 = a.initR[(size_t)i * a.ld + col], z0 = *zp;
+        const float r1 = r0 - o, z1 = r1 * invMd;
+        a.initR[(size_t)i * a.ld + col] = r1;
+        *zp = z1;
+        dotc += r1 * z1 - r0 * z0;
+        continue;
+      }
       a.OUT[(size_t)i * a.ld + col] += o;
       dotc = fmaf(xs[(size_t)i * 32], o, dotc);
     }

@@ -228,6 +228,12 @@ struct ChainFixArgs {
   const float* gate;
   float gate_tol, cP;
   int32_t prows, pwidth, N, ld, c0, c1, part_row0, chunks;
+  // behind k_apply_blocked's INIT pass (BlkInit): patch r (row-major), z (slab-major) and the r . z partials of the path
+  // rows instead of OUT / x . out; nullptr otherwise
+  float* initR;
+  float* initZ;
+  const float* B;
+  float md_B, md_const;  // no preconditioner: 0, 1
 };
 // initial residual of a solve around the blocked matvec: rows_to_slab copies the columns [c0, c1) of a row-major array into
 // the slab-major layout the blocked matvec gathers from; init_finish turns AP = A x0 into r = b - A x0, z = r / (Md + eps),

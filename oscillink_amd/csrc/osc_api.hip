@@ -1303,13 +1303,14 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
 
   // (an inertia start hands over x0 IN the AP array, which the blocked matvec would overwrite with A x0 before
   // init_finish has read x0: such a solve keeps the gathering INIT kernel, which reads x0 completely first)
+  int init_part_rows = grid;  // rows of r . z partials the INIT pass leaves (+ the chain fix-up's behind the fused pass)
   float* Pbuf = b.P;   // search direction / operator output: the fused INIT pass below leaves p in the AP array and
   float* APbuf = b.AP;  // swaps the two for the rest of the solve
   // (the rhs rows the fused pass can take besides x0 itself: one -- the state term must be x0 or absent, and if y is a
   // third array the solution array must be x0)
   const bool fuse_u = b.rhsU == b.x0 || op.rbU == 0.f;
   const bool fuse_y = b.rhsY == b.x0 || b.X == b.x0;
-  if (ba.nb > 0 && h.blk_init && h.blk_init_fused && fuse_u && fuse_y && b.x0 != b.AP && cf.chunks == 0) {
+  if (ba.nb > 0 && h.blk_init && h.blk_init_fused && fuse_u && fuse_y && b.x0 != b.AP) {
     // r = b - A x0 INSIDE the blocked matvec (the in-place warm-started settle: x0 is also the rhs state term and the
     // solution array; the U* solve: x0 is Y, no state term): x0 -> slab-major (into P), then one launch gathers A x0 and
     // leaves r, z (slab-major, in the AP array), x0 in the solution array and the r . z column sums
@@ -1329,9 +1330,22 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     ba.gate = nullptr;
     ba.OUT = nullptr;
     launch_apply_blocked(ba, grid, h.stream, &bi);
+    if (cf.chunks > 0) {  // the chain prior's rows: their r, z and r . z still lack the chain term
+      ChainFixArgs ci = cf;
+      ci.gate = nullptr;
+      ci.initR = b.R;
+      ci.initZ = b.AP;
+      ci.B = b.B;
+      ci.md_B = bi.md_B;
+      ci.md_const = bi.md_const;
+      launch_chain_fix(ci, h.stream);
+      init_part_rows = grid + cf.chunks;
+    }
     std::swap(Pbuf, APbuf);
     ba.X = Pbuf;
     ba.OUT = APbuf;
+    cf.X = Pbuf;
+    cf.OUT = APbuf;
   } else if (ba.nb > 0 && h.blk_init && b.x0 != b.AP) {
     // r = b - A x0 around the blocked matvec: x0 -> slab-major (into P), A x0 -> AP, then r, z, p = z, r . z
     ProfScope ps(h, 4, 0);
@@ -1365,7 +1379,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   } else {
     spmm_slabbed(h, SPMM_INIT, sa, grid);
   }
-  launch_reduce_init(h.part0.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.stream);
+  launch_reduce_init(h.part0.p, init_part_rows, b.ld, b.c0, b.c1, h.rz.p, h.stream);
   UpdateArgs ua{};
   ua.pblk = pblk ? h.N : 0;
   ua.temporal = 5.0 * (double)h.N * (double)(b.c1 - b.c0) * 4.0 <= h.temporal_mb * 1048576.0;
