@@ -760,7 +760,9 @@ __global__ __launch_bounds__(256) void k_init_finish(const InitFinishArgs a) {
 // ---------------------------------------------------------------------------------------------
 // WITHX = false: the x update of this iteration is left to the next iteration's k_update_p (or to k_update_x behind the
 // last one): this kernel then moves r and Ap only (run_cg).
-template <int LPR, int NCH, bool WITHX>
+// STORE_R = false (with WITHX): the form for an iteration expected to be the solve's last -- x is finished here and the new
+// r only feeds the two column sums; should the solve go on after all, the host has the r update redone with a store.
+template <int LPR, int NCH, bool WITHX, bool STORE_R = true>
 __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
   constexpr int RPW = 64 / LPR;
   constexpr int CPW = NCH * LPR * 4;
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(256) void k_update_xr(const UpdateArgs a) {
       }
       r.x = fmaf(-ap.x, al[ch].x, r.x); r.y = fmaf(-ap.y, al[ch].y, r.y);
       r.z = fmaf(-ap.z, al[ch].z, r.z); r.w = fmaf(-ap.w, al[ch].w, r.w);
-      st4_sel(a.R + off, r, tmp);
+      if constexpr (STORE_R) st4_sel(a.R + off, r, tmp);
       rr[ch] = mulacc4(r, r, rr[ch]);
       const float4 z = make_float4(r.x * invMd, r.y * invMd, r.z * invMd, r.w * invMd);
       rz[ch] = mulacc4(r, z, rz[ch]);
@@ -1145,13 +1147,17 @@ void launch_update_xr(const UpdateArgs& a, int grid, hipStream_t s) {
   const Shape sh = pick_shape(a.c1 - a.c0);
 #define CALL(L, C) hipLaunchKernelGGL((k_update_xr<L, C, true>), dim3(grid), dim3(256), 0, s, a)
 #define CALL_NOX(L, C) hipLaunchKernelGGL((k_update_xr<L, C, false>), dim3(grid), dim3(256), 0, s, a)
-  if (a.xmode & OSC_XMODE_XR_SKIPS_X) {
+#define CALL_LAST(L, C) hipLaunchKernelGGL((k_update_xr<L, C, true, false>), dim3(grid), dim3(256), 0, s, a)
+  if (a.xmode & OSC_XMODE_XR_LAST) {
+    OSC_SHAPE_SWITCH(sh, CALL_LAST);
+  } else if (a.xmode & OSC_XMODE_XR_SKIPS_X) {
     OSC_SHAPE_SWITCH(sh, CALL_NOX);
   } else {
     OSC_SHAPE_SWITCH(sh, CALL);
   }
 #undef CALL
 #undef CALL_NOX
+#undef CALL_LAST
   HIP_CHECK(hipGetLastError());
 }
 

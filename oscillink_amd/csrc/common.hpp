@@ -193,10 +193,11 @@ struct UpdateArgs {
   int32_t temporal;
   // where the x update happens (run_cg): 0 = in k_update_xr, next to the r update (x, r, p, Ap read; x, r written);
   // OSC_XMODE_XR_SKIPS_X: not there; OSC_XMODE_P_APPLIES_X: k_update_p applies the PREVIOUS iteration's while it has p in
-  // hand (launch_update_x behind the last iteration) -- one array pass less per iteration
+  // hand (launch_update_x behind the last iteration) -- one array pass less per iteration; OSC_XMODE_XR_LAST: k_update_xr
+  // in the form for the expected last iteration (x finished there, the new r not stored)
   int32_t xmode;
 };
-constexpr int32_t OSC_XMODE_XR_SKIPS_X = 1, OSC_XMODE_P_APPLIES_X = 2;
+constexpr int32_t OSC_XMODE_XR_SKIPS_X = 1, OSC_XMODE_P_APPLIES_X = 2, OSC_XMODE_XR_LAST = 4;
 
 struct Gate {
   const float* p;

@@ -226,6 +226,7 @@ struct osc_lattice {
   bool small_path = true;             // OSC_SMALL_PATH=0 disables the one-launch CG for small lattices
   int predicted_iters[3] = {0, 0, 0};  // iterations the last general-path solve of each kind (CgBuffers::kind) took (0 = unknown)
   bool x_defer = true;                // the x update rides in the next iteration's p update (run_cg; OSC_X_DEFER=0: beside the r update)
+  bool x_last_form = true;            // ... and the expected last iteration finishes x itself without storing r (OSC_X_DEFER=2: off)
   DevBuf<int32_t> ell_col_t;          // transposed ELL for the one-launch path (built on first use per graph)
   DevBuf<float> ell_w_t;
   bool ell_t_ready = false;
@@ -1406,7 +1407,11 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   // p in / x, p out there, r, Ap in / r out in the x-r kernel: 8 array passes per iteration instead of 9), or by
   // finish_x behind an iteration that has no successor enqueued.  x_done = iterations whose x update is applied or rides
   // in an enqueued p update; x_rides_gated = the iteration whose update rides in a GATED p update (0: none).
-  int x_done = 0, x_rides_gated = 0;
+  // The iteration expected to be the last (the count of the handle's previous solve of this kind, or max_iters) takes
+  // k_update_xr's "last" form instead: x finished next to the r update, the new r not stored (five passes instead of
+  // three there and three in finish_x); r_unstored = that iteration until its r has been stored after all.
+  int x_done = 0, x_rides_gated = 0, r_unstored = 0;
+  const int stop_guess = h.predicted_iters[b.kind];
   auto finish_x = [&](int it) {
     ua.gate = nullptr;
     ua.xmode = OSC_XMODE_XR_SKIPS_X | OSC_XMODE_P_APPLIES_X;
@@ -1414,7 +1419,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     x_done = it;
     x_rides_gated = 0;
   };
-  auto enqueue_iter = [&](int it) {  // everything of iteration `it` up to its residual, gated on iteration it-1
+  auto enqueue_iter = [&](int it, bool speculative) {  // everything of iteration `it` up to its residual, gated on iteration it-1
     const Gate g{it > 1 && !overlap ? res_dev + (it - 1) : nullptr, tol};
     const Gate ge = g;
     sa.gate = ge.p;
@@ -1431,7 +1436,8 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
         x_rides_gated = g.p != nullptr ? it - 1 : 0;  // applied only if iteration it - 1 did not converge
       }
     }
-    ua.xmode = xdefer ? OSC_XMODE_XR_SKIPS_X : 0;
+    // (an UNGATED speculative iteration must not touch x: it may turn out never to have been one)
+    const bool last_form = xdefer && h.x_last_form && (it == stop_guess || it == max_iters) && !(overlap && speculative);
     if (ba.nb > 0) {  // Ap and column sums of p.Ap
       ProfScope ps(h, 0, it);
       ba.gate = ge.p;
@@ -1449,7 +1455,12 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     launch_reduce_alpha(h.part0.p, grid + (ba.nb > 0 ? cf.chunks : 0), b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, ge, h.stream);
     {
       ProfScope ps(h, 1, it);
+      ua.xmode = !xdefer ? 0 : last_form ? OSC_XMODE_XR_LAST : OSC_XMODE_XR_SKIPS_X;
       for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });
+      if (last_form) {
+        x_done = it;
+        r_unstored = it;
+      }
     }
     if (mapped) {
       launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream,
@@ -1502,12 +1513,11 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   // launches of a needless speculative iteration cost ~22 us (8 % of a settle at N = 20000, D = 128).  A wrong guess
   // costs one host round trip: the iteration is then enqueued after its predecessor's residual has been read.
   // (Every rank of a sharded solve sees the same residuals, hence takes the same decisions.)
-  const int stop_guess = h.predicted_iters[b.kind];
   int enqueued = 1;
-  enqueue_iter(1);
+  enqueue_iter(1, false);
   for (int it = 1; it <= max_iters; ++it) {
     if (it < max_iters && it != stop_guess && enqueued == it) {
-      enqueue_iter(++enqueued);  // speculative: no-ops if `it` converged (overlap: ungated, scratch arrays only)
+      enqueue_iter(++enqueued, true);  // speculative: no-ops if `it` converged (overlap: ungated, scratch arrays only)
     } else if (xdefer && x_done < it) {
       // nothing is enqueued behind this iteration for now (the expected last one): its x update goes out at once.  The
       // host has seen iteration it - 1 unconverged, so iteration `it` is a real one whatever its residual will say.
@@ -1520,12 +1530,20 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       out.iters = it;
       break;
     }
-    if (it < max_iters && enqueued == it) enqueue_iter(++enqueued);  // the guess was wrong: go on
+    if (it < max_iters && enqueued == it) {  // the guess was wrong: go on
+      if (r_unstored == it) {  // ... from the r this iteration computed but did not keep
+        ua.gate = nullptr;
+        ua.xmode = OSC_XMODE_XR_SKIPS_X;
+        for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });
+        r_unstored = 0;
+      }
+      enqueue_iter(++enqueued, false);
+    }
   }
   h.predicted_iters[b.kind] = out.iters;
   // the last iteration's x update rode in a gated p update that did not run (the solve converged under a speculative
   // iteration): alpha and p are still that iteration's
-  if (xdefer && x_rides_gated == out.iters && x_done == out.iters) finish_x(out.iters);
+  if (xdefer && x_rides_gated == out.iters) finish_x(out.iters);
   // The solution is complete once the last residual is out; what may still be queued are the gated-off launches of
   // the speculative iteration (they return at once and write nothing).  With the mapped read-back the stream is left
   // to drain on its own -- later calls are ordered behind it anyway; the copy + event path keeps its full wait.
@@ -1951,7 +1969,10 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_TEMPORAL_MB")) h->temporal_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
     if (const char* e = getenv("OSC_COMM_OVERLAP")) h->comm_overlap = atoi(e) != 0;
-    if (const char* e = getenv("OSC_X_DEFER")) h->x_defer = atoi(e) != 0;
+    if (const char* e = getenv("OSC_X_DEFER")) {
+      h->x_defer = atoi(e) != 0;
+      h->x_last_form = atoi(e) == 1;
+    }
     if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
     if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_SHARD")) h->shard_mode = !strcmp(e, "row") ? 1 : 0;
