@@ -562,8 +562,13 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
   p.keep = keep;
   // Thresholds: the sample holds one column in rho; tau = the 14th largest tile maximum ~ the 15th-17th best sample
   // score, so about rho * 16 columns of the full sweep beat it (gamma-distributed: 0.1 % of the rows see fewer than
-  // rho * 6 or more than rho * 32).  rho = keep / 4 puts `keep` at the low tail and 8 keep slots above the high one.
-  const double rho = std::max(6.0, keep / 4.0);
+  // rho * 6 or more than rho * 32).  rho = keep / 4 puts `keep` at the low tail and 8 keep slots above the high one;
+  // OSC_KNN_PANEL_RHO overrides it.
+  static const double rho_env = [] { const char* e = getenv("OSC_KNN_PANEL_RHO"); return e ? atof(e) : 0.0; }();
+  // (round 3, config 4's shape, keep = 24: rho 6 / 8 / 12 / 16 -> build 798 / 790 / 775 / 784 ms with 6 / 1 / 1 / 129 rows sent
+  // to the exact kernel; from 24 on the folded group maxima put tau so low that every hit list overflows.  Config 3,
+  // keep = 48: 8 / 12 / 16 -> 26.5 / 22.2 / 26.8 ms.  Hence at least 12.)
+  const double rho = rho_env > 0.0 ? rho_env : std::max(12.0, keep / 4.0);
   p.sample_tiles = (int32_t)std::max(24.0, std::min(p.nrb / 2.0, std::round(p.nrb / rho)));
   // tile maxima are folded over groups of consecutive sample tiles so that a row has at most 128 of them (the r-th
   // largest group maximum is still a lower bound of the r-th best sample score)
@@ -579,7 +584,7 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
   // column splits: whatever leaves the smallest idle tail on `cus` persistent workgroups (per-item overhead ~1 %)
   // ... and few enough hits per wave and item for its LDS list: 32 rows x ~5 keep / S <= ~2/3 of HB_CAP
   p.hit_cap = HB_CAP / p.nrg;
-  const int s_min = std::max(1, (int)std::ceil(32.0 * 5.0 * keep / (0.66 * p.hit_cap)));
+  const int s_min = std::max(1, (int)std::ceil(32.0 * std::max(5.0 * keep, 20.0 * rho) / (0.66 * p.hit_cap)));
   const int nsets = (p.nrb + p.nrg - 1) / p.nrg;  // work items per split
   double best = 1e30;
   p.S = s_min;
