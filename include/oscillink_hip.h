@@ -131,7 +131,7 @@ int osc_clear_chain(osc_handle h);                      /* lattice.py:151-157 */
 int osc_set_lams(osc_handle h, float lamG, float lamC, float lamQ);
 int osc_get_U(osc_handle h, float* out);                /* N x D */
 int osc_get_Y(osc_handle h, float* out);                /* N x D: the device's private copy of the anchors */
-int osc_set_U(osc_handle h, const float* U_or_null);    /* NULL -> U = Y (device copy) */
+int osc_set_U(osc_handle h, const float* U_or_null);    /* NULL -> U = Y (device copy, ordered by the handle's stream: returns without waiting for it) */
 
 /* ---- solves --------------------------------------------------------------------------------- */
 /* settle (lattice.py:159-230) + cg_solve (solver.py:6-37): one implicit-Euler step

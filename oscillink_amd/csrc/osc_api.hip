@@ -2314,7 +2314,7 @@ int osc_set_U(osc_handle h, const float* U) {
       HIP_CHECK(hipMemcpyAsync(l.U.p, l.Y.p, (size_t)l.N * l.ld * 4, hipMemcpyDeviceToDevice, l.stream));
       l.u_sharded = false;
     }
-    sync(l);
+    if (U) sync(l);  // (the caller's buffer is free on return; the device-side reset is ordered by the stream)
   });
 }
 

@@ -161,10 +161,14 @@ class OscillinkLattice:
         self._call("osc_set_U", nat.f32(v))
         self._U_host = v.copy()
 
-    def reset_U(self) -> None:
-        """U <- Y on the device (the state right after construction); used by benchmark loops."""
+    def reset_U(self, wait: bool = True) -> None:
+        """U <- Y on the device (the state right after construction); used by benchmark loops.  The copy is ordered by
+        the handle's stream, so whatever follows sees the reset state either way; `wait=False` returns without waiting
+        for it (a timing loop that wants the reset outside its clock keeps the default)."""
         self._call("osc_set_U", None)
         self._U_host = None
+        if wait:
+            nat.check(nat.lib().osc_device_synchronize(self._device), None, "osc_device_synchronize")
 
     @property
     def B_diag(self) -> np.ndarray:
