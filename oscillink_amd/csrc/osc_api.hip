@@ -218,7 +218,7 @@ struct osc_lattice {
   int xs_min_cols = 32;    // narrowest column window the mode is used for (OSC_XS_MIN_COLS; 96 until round 3 -- with the
                            // blocked matvec under it, one- and two-slab windows win too: 100k x 64 k 16 0.505 -> 0.425 ms per
                            // settle, 100k x 32 0.352 -> 0.309, 200k x 64 k 32 1.43 -> 0.97, 60k x 64 k 32 0.438 -> 0.387)
-  int xs_min_rows = 6144, xs_min_rows_narrow = 32768;  // smallest lattice the mode is used for: windows of >= 256 columns / narrower ones (OSC_XS_MIN_ROWS="a,b")
+  int xs_min_rows = 6144, xs_min_rows_narrow = 0;  // smallest lattice the mode is used for: windows of >= 256 columns / narrower ones (0: by width, xs_plan) (OSC_XS_MIN_ROWS="a,b")
   int xs_groups_min = 2;   // fewest slab groups the mode is kept for when the natural count had to be reduced (OSC_XS_MIN_GROUPS)
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
@@ -990,7 +990,12 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   if (h.spmm_xs == 1) return nb;
   if (h.spmm_slab != 0 || h.reordered || (h.ld & 31) != 0 || (h.c0 & 31) != 0) return 0;
   // from N = 32768 on, and from 6144 (16384 until round 3) for windows of >= 256 columns (N = 20000, D = 256: apply 43.5 -> 31.4 us)
-  if (h.N < h.xs_min_rows || (h.N < h.xs_min_rows_narrow && ncols < 256) || ncols < h.xs_min_cols) return 0;
+  // narrower windows: 32768 rows, but 12288 where the window is whole groups of four slabs (every XCD pair a slab of its
+  // own) and 24576 for other windows of >= 128 columns (scripts/exp/xs_narrow_sweep.py, k = 16, per settle: 20000 x 128
+  // 246 -> 223 us, 32000 x 128 347 -> 301, 12000 x 128 192 -> 186, 32000 x 192 484 -> 438, 24000 x 192 393 -> 378, 20000 x
+  // 192 345 -> 360; 64 and 32 columns: a tie or a loss up to 32000 rows)
+  const int narrow_rows = h.xs_min_rows_narrow > 0 ? h.xs_min_rows_narrow : ncols < 128 ? 32768 : (ncols % 128) == 0 ? 12288 : 24576;
+  if (h.N < h.xs_min_rows || (h.N < narrow_rows && ncols < 256) || ncols < h.xs_min_cols) return 0;
   // below 16384 rows (round 3: the floor was 16384) a 32-column slab is at most 2 MB -- it sits in its XCD's L2 whole,
   // where the general path spreads N x window over all eight L2s -- which pays once a row has enough gathers: per settle
   // 6500 x 768 k 32 0.520 -> 0.437 ms, 9000 x 1024 k 32 0.925 -> 0.697, 8192 x 1536 k 32 1.32 -> 0.91, 14000 x 256 k 32 0.406
