@@ -312,7 +312,16 @@ def test_rccl_communicator_of_one_rank_runs_the_sharded_path(amd, overlap, monke
     lat._call("osc_comm_info", None, C.byref(world), None, kind, 16)
     assert (kind.value.decode(), int(world.value)) == ("rccl", 1)
     got = run(lat)
-    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    assert got[0] == want[0] and got[1] == want[1]
+    import os
+
+    if os.environ.get("OSC_REORDER"):  # a forced internal row order is not taken under a communicator: other summation order
+        assert np.allclose(got[2], want[2], rtol=1e-5)
+        for a, b in zip(got[3:6], want[3:6]):
+            assert relerr(a, b) < 2e-6
+        assert got[6] == pytest.approx(want[6], rel=1e-5)
+        return
+    assert got[2] == want[2]
     for a, b in zip(got[3:6], want[3:6]):
         assert np.array_equal(a, b)
     assert got[6] == want[6]
