@@ -1126,11 +1126,13 @@ struct CgResult {
   float* sol = nullptr;  // the buffer that holds the solution (b.X, or b.Xalt)
 };
 
-// cg_solve (solver.py:6-37) on the device; returns after the stream is idle.
-// The host enqueues iteration it+1 before it reads iteration it's residual; every kernel of a speculative iteration
-// carries a gate (residual of the previous iteration, tol) and is a no-op once the CG has converged, so the
-// reference's "stop before the beta/p update" semantics hold exactly while the stream never drains between
-// iterations.
+// cg_solve (solver.py:6-37) on the device; returns once the last residual is out (what may still be queued then touches
+// scratch arrays only, and later calls are ordered behind it by the stream).
+// The host enqueues iteration it+1 before it reads iteration it's residual.  On one GPU every kernel of a speculative
+// iteration carries a gate (residual of the previous iteration, tol) and is a no-op once the CG has converged; under
+// a communicator it carries none and writes scratch arrays only (the x update of an iteration is applied by its
+// successor's p update or by the host's order, never speculatively).  Either way the reference's "stop before the
+// beta/p update" semantics hold exactly while the stream never drains between iterations.
 // Small lattices: the whole solve in ONE launch with the state in LDS (small_kernels.hip).  Returns false when the
 // lattice does not fit that path (or its barrier timed out) and the general path must run.
 bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol,
@@ -1210,7 +1212,8 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, (h.res_bits.n / 2 + nslots) * 4, h.stream));
   // Single GPU: the last workgroup of each iteration's beta reduction writes the residual into host-mapped memory and
   // the host polls that word (no 4-byte copy, event record and event wait per iteration).  Under a communicator the
-  // residual first goes through the all-reduce, so the copy + event path stays.
+  // residual first goes through the all-reduce (below; OSC_COMM_OVERLAP=0 or OSC_MAPPED_RES=0: in the solve's stream,
+  // read back by copy + event).
   const bool mapped = h.comm == nullptr && h.mapped_residual;
   // Sharded (column windows): the stop test needs max over the ranks of the residual -- a 4-byte all-reduce per iteration,
   // tens of microseconds of latency on xGMI next to ~180 us of kernels per iteration in an 8-rank window of config 3.
@@ -1425,11 +1428,11 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     x_rides_gated = 0;
   };
   auto enqueue_iter = [&](int it, bool speculative) {  // everything of iteration `it` up to its residual, gated on iteration it-1
+    // (overlap: no gates -- an iteration writes scratch arrays only until the host has seen its predecessor unconverged)
     const Gate g{it > 1 && !overlap ? res_dev + (it - 1) : nullptr, tol};
-    const Gate ge = g;
-    sa.gate = ge.p;
+    sa.gate = g.p;
     sa.gate_tol = tol;
-    ua.gate = ge.p;
+    ua.gate = g.p;
     ua.gate_tol = tol;
     if (it > 1) {
       ProfScope ps(h, 2, it);
@@ -1445,11 +1448,11 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     const bool last_form = xdefer && h.x_last_form && (it == stop_guess || it == max_iters) && !(overlap && speculative);
     if (ba.nb > 0) {  // Ap and column sums of p.Ap
       ProfScope ps(h, 0, it);
-      ba.gate = ge.p;
+      ba.gate = g.p;
       ba.gate_tol = tol;
       launch_apply_blocked(ba, grid, h.stream);
       if (cf.chunks > 0) {
-        cf.gate = ge.p;
+        cf.gate = g.p;
         cf.gate_tol = tol;
         launch_chain_fix(cf, h.stream);
       }
@@ -1457,7 +1460,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     } else {
       spmm_slabbed(h, SPMM_AP, sa, grid, it);
     }
-    launch_reduce_alpha(h.part0.p, grid + (ba.nb > 0 ? cf.chunks : 0), b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, ge, h.stream);
+    launch_reduce_alpha(h.part0.p, grid + (ba.nb > 0 ? cf.chunks : 0), b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
     {
       ProfScope ps(h, 1, it);
       ua.xmode = !xdefer ? 0 : last_form ? OSC_XMODE_XR_LAST : OSC_XMODE_XR_SKIPS_X;
@@ -1515,8 +1518,9 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   const size_t prof_mark = h.prof_pending.size();
   // Iteration it + 1 is enqueued before iteration it's residual is read -- except behind the iteration the previous
   // solve of this handle converged in: repeated settles of one lattice take the same count, and the five gated-off
-  // launches of a needless speculative iteration cost ~22 us (8 % of a settle at N = 20000, D = 128).  A wrong guess
-  // costs one host round trip: the iteration is then enqueued after its predecessor's residual has been read.
+  // launches of a needless speculative iteration cost ~22 us (8 % of a settle at N = 20000, D = 128; ungated under a
+  // communicator: a whole iteration).  A wrong guess the other way costs one host round trip: the iteration is then
+  // enqueued after its predecessor's residual has been read.
   // (Every rank of a sharded solve sees the same residuals, hence takes the same decisions.)
   int enqueued = 1;
   enqueue_iter(1, false);
