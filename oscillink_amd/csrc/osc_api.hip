@@ -1231,6 +1231,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       h.step_events.push_back(e);
     }
+    h.comm_stream_busy = true;  // from here on (also if the solve is abandoned half way): drained before the slots are reused
   }
   const bool polled = mapped || overlap;
   constexpr uint32_t kPending = 0xFFFFFFFFu;  // never a residual (those are sqrt(...) >= 0 or a canonical NaN)
@@ -1557,7 +1558,6 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   // the speculative iteration (they return at once and write nothing).  With the mapped read-back the stream is left
   // to drain on its own -- later calls are ordered behind it anyway; the copy + event path keeps its full wait.
   // (overlap: the same; the second stream is drained by whoever next touches the residual slots it writes -- drain_comm_stream)
-  if (overlap) h.comm_stream_busy = true;
   if (!polled || h.prof_on) sync(h);
   for (size_t i = prof_mark; i < h.prof_pending.size(); ++i)  // speculative (gated-off) launches are not samples
     if (h.prof_pending[i].iter > out.iters) h.prof_pending[i].which = -1;
