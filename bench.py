@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--max-iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the build / U* / receipt timings after the timed region")
+    ap.add_argument("--extras", action="store_true",
+                    help="run those timings in a multi-GPU run as well (default there: skipped -- they are collective calls "
+                         "outside the timed region, and the one JSON line should not depend on them)")
     ap.add_argument("--shard", choices=["column", "row"], default="column",
                     help="multi-GPU CG partitioning: column slabs (one all-reduce(max) per iteration, default) or "
                          "row blocks (halo exchange of p + all-reduces of D-vectors, the north-star wording)")
@@ -311,8 +314,10 @@ def main():
                                 "frac": settle_gbs / (HBM_PEAK_GBS * world)}},
     }
 
-    if not args.no_extras:
+    if not args.no_extras and (not launched or args.extras):
         out.update(extras(lat, N, D, args, launched))
+    elif launched:
+        out["extras"] = "skipped in a multi-GPU run (--extras runs them: sharded rebuilds, U* solves, receipts)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lat, Y, psi, args)
     if rank == 0:
