@@ -141,7 +141,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    launched = world > 1
+    # (rehearsal on a one-GPU box: OSC_BENCH_FORCE_COMM=1 takes the multi-GPU code path -- rendezvous, the library's RCCL
+    # communicator, the sharded solve with its second stream, barriers -- with the one rank RCCL allows there)
+    launched = world > 1 or bool(os.environ.get("OSC_BENCH_FORCE_COMM"))
 
     from oscillink_amd import Oscillink
     from oscillink_amd import _native as nat
