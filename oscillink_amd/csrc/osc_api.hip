@@ -253,7 +253,7 @@ struct osc_lattice {
   // (run_cg); step_events[it] = "iteration it's local residual is out" (OSC_COMM_OVERLAP=0: all-reduce in the solve's stream)
   hipStream_t comm_stream = nullptr;
   std::vector<hipEvent_t> step_events;
-  bool comm_overlap = true;
+  int comm_overlap = -1;  // 1 / 0: always / never; -1: from four ranks on (run_cg)
   bool comm_stream_busy = false;  // a solve left work on comm_stream (at most a speculative iteration's all-reduce + publish)
   std::vector<float> history;
   // column shard (multi-GPU, column-sharded CG); single GPU: [0, ld)
@@ -1223,7 +1223,12 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   // polls, as on one GPU.  The host alone decides when to stop; a wrong guess of the last iteration costs one iteration
   // of device time instead of five gated-off launches.
   const bool xdefer = h.x_defer;
-  const bool overlap = h.comm != nullptr && h.comm_overlap && h.mapped_residual && xdefer;
+  // What it costs (one-rank RCCL communicator, all-reduce latency ~0: DESIGN.md section 6): ~17 us once per solve for the
+  // second stream's hand-over at the last iteration, and the expected last iteration's own form (an ungated speculative
+  // iteration must not touch x): 47 us at 768 columns, 6 at 96.  What it saves: every all-reduce latency but the last.
+  // Hence by default from four ranks on (narrow windows, 15-30 us per all-reduce); OSC_COMM_OVERLAP=1 / 0 force it.
+  const bool want_overlap = h.comm_overlap == 1 || (h.comm_overlap < 0 && h.world >= 4);
+  const bool overlap = h.comm != nullptr && want_overlap && h.mapped_residual && xdefer;
   if (overlap) {
     if (!h.comm_stream) h.comm_stream = acquire_stream(h.device);
     while (h.step_events.size() < nslots) {
@@ -1977,7 +1982,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     if (const char* e = getenv("OSC_SPMM_DEEP")) h->spmm_deep = atoi(e) != 0;
     if (const char* e = getenv("OSC_TEMPORAL_MB")) h->temporal_mb = std::max(0.0, atof(e));
     if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
-    if (const char* e = getenv("OSC_COMM_OVERLAP")) h->comm_overlap = atoi(e) != 0;
+    if (const char* e = getenv("OSC_COMM_OVERLAP")) h->comm_overlap = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("OSC_X_DEFER")) {
       h->x_defer = atoi(e) != 0;
       h->x_last_form = atoi(e) == 1;
