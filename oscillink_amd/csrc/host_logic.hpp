@@ -8,6 +8,7 @@
 //   xs_groups / blocked_geometry / blocked_list_extent : launch geometry of the XCD-affine and source-blocked matvec
 //   blocked_block_count               : how many source blocks the blocked matvec walks
 //   blk_place_row                     : host model of k_blk_count / k_blk_fill (one row of the block-major graph copy)
+//   CgXSchedule                       : which launch of a CG solve carries which iteration's x update (run_cg)
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -291,6 +292,56 @@ inline void blk_place_row(const int32_t* cols, const float* w, int deg, int32_t 
   for (int q = 0; q < nb; ++q)
     for (int t = tail[(size_t)q]; t < SL; ++t) slots[(size_t)q * SL + t] = BlkEntry{std::min(N - 1, q * rpb), 0.f};
 }
+
+// ---- where the x update of a CG iteration happens (run_cg in osc_api.hip) ---------------------------------------------
+// The solve's host loop enqueues iteration it + 1 before it has read iteration it's residual, so a launch may belong to
+// an iteration that never was one.  With the x update deferred (x += alpha p of iteration it is applied by iteration
+// it + 1's p update, which reads p anyway) this object decides, launch by launch, which kernel carries which x update,
+// so that every real iteration's update is applied exactly once, with that iteration's alpha and p, and none of an
+// iteration behind the one the solve stopped in:
+//   * gated solves (one GPU): every launch of iteration it carries the gate "residual(it - 1) > tol" and is a no-op
+//     otherwise -- an x update that rides in a gated-off p update must be made up for at the end (alpha and p are intact
+//     then: everything behind the stop is a no-op);
+//   * ungated solves (a sharded solve whose stop test runs beside it): a speculative launch must not touch x at all.
+// The iteration expected to be the last (stop_guess, or max_iters) finishes x itself in its x-r kernel and does not
+// store the new r; if the solve goes on after all, r is stored by redoing that kernel's r part first.
+struct CgXSchedule {
+  bool xdefer = true, last_form = true, ungated = false;
+  int stop_guess = 0, max_iters = 1;
+  int x_done = 0;         // iterations whose x update is applied or rides in an enqueued launch
+  int x_rides_gated = 0;  // the iteration whose x update rides in a GATED p update (0: none)
+  int r_unstored = 0;     // the iteration whose x-r kernel did not store r (0: none)
+  enum XrForm { XR_WITH_X = 0, XR_SKIPS_X = 1, XR_LAST = 2 };
+  struct IterForm {
+    bool p_applies_x;  // this iteration's p update also applies the previous iteration's x update
+    XrForm xr;
+  };
+  // iteration `it` is being enqueued; speculative: before its predecessor's residual has been read
+  IterForm enqueue(int it, bool speculative) {
+    IterForm f{false, XR_WITH_X};
+    if (!xdefer) return f;
+    if (it > 1 && x_done < it - 1) {
+      f.p_applies_x = true;
+      x_done = it - 1;
+      x_rides_gated = ungated ? 0 : it - 1;
+    }
+    const bool last = last_form && (it == stop_guess || it == max_iters) && !(ungated && speculative);
+    f.xr = last ? XR_LAST : XR_SKIPS_X;
+    if (last) x_done = it, r_unstored = it;
+    return f;
+  }
+  // no successor of `it` is enqueued for now and the host has seen its predecessor unconverged: apply its x update now?
+  bool finish_before_wait(int it) const { return xdefer && x_done < it; }
+  // the solve goes on behind `it`: must its r be stored first (by redoing the r part of its x-r kernel)?
+  bool restore_r(int it) {
+    if (r_unstored != it) return false;
+    r_unstored = 0;
+    return true;
+  }
+  // the solve stopped in `iters`: apply its x update now (it rode in a gated p update that did not run)?
+  bool finish_at_end(int iters) const { return xdefer && x_rides_gated == iters; }
+  void finished(int it) { x_done = it, x_rides_gated = 0; }  // after the x update of `it` was launched on its own
+};
 
 }  // namespace host
 }  // namespace osc

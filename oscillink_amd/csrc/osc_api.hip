@@ -1419,19 +1419,23 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   h.blk_last = ba.nb;
   // Deferred x update: iteration it's x += alpha p is applied by iteration it + 1's p update, which reads p anyway (x, r,
   // p in / x, p out there, r, Ap in / r out in the x-r kernel: 8 array passes per iteration instead of 9), or by
-  // finish_x behind an iteration that has no successor enqueued.  x_done = iterations whose x update is applied or rides
-  // in an enqueued p update; x_rides_gated = the iteration whose update rides in a GATED p update (0: none).
-  // The iteration expected to be the last (the count of the handle's previous solve of this kind, or max_iters) takes
-  // k_update_xr's "last" form instead: x finished next to the r update, the new r not stored (five passes instead of
-  // three there and three in finish_x); r_unstored = that iteration until its r has been stored after all.
-  int x_done = 0, x_rides_gated = 0, r_unstored = 0;
+  // finish_x behind an iteration that has no successor enqueued.  The iteration expected to be the last (the count of
+  // the handle's previous solve of this kind, or max_iters) takes k_update_xr's "last" form instead: x finished next
+  // to the r update, the new r not stored (five passes instead of three there and three in finish_x).  Which launch
+  // carries which update is decided by host::CgXSchedule (host_logic.hpp; swept against a model of the device's
+  // gating on the CPU box, tests/host_logic/sweep_host_logic.cpp).
   const int stop_guess = h.predicted_iters[b.kind];
+  host::CgXSchedule xs;
+  xs.xdefer = xdefer;
+  xs.last_form = h.x_last_form;
+  xs.ungated = overlap;
+  xs.stop_guess = stop_guess;
+  xs.max_iters = max_iters;
   auto finish_x = [&](int it) {
     ua.gate = nullptr;
     ua.xmode = OSC_XMODE_XR_SKIPS_X | OSC_XMODE_P_APPLIES_X;
     for_windows(ua, [&](const UpdateArgs& w) { launch_update_x(w, grid, h.stream); });
-    x_done = it;
-    x_rides_gated = 0;
+    xs.finished(it);
   };
   auto enqueue_iter = [&](int it, bool speculative) {  // everything of iteration `it` up to its residual, gated on iteration it-1
     // (overlap: no gates -- an iteration writes scratch arrays only until the host has seen its predecessor unconverged)
@@ -1440,18 +1444,13 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     sa.gate_tol = tol;
     ua.gate = g.p;
     ua.gate_tol = tol;
+    const host::CgXSchedule::IterForm form = xs.enqueue(it, speculative);
     if (it > 1) {
       ProfScope ps(h, 2, it);
       // p = z + beta p (solver.py:32-36), and iteration it - 1's x += alpha p (solver.py:27) with the p it replaces
-      ua.xmode = xdefer ? (OSC_XMODE_XR_SKIPS_X | (x_done < it - 1 ? OSC_XMODE_P_APPLIES_X : 0)) : 0;
+      ua.xmode = form.p_applies_x ? OSC_XMODE_P_APPLIES_X : 0;
       for_windows(ua, [&](const UpdateArgs& w) { launch_update_p(w, grid, h.stream); });
-      if (xdefer && x_done < it - 1) {
-        x_done = it - 1;
-        x_rides_gated = g.p != nullptr ? it - 1 : 0;  // applied only if iteration it - 1 did not converge
-      }
     }
-    // (an UNGATED speculative iteration must not touch x: it may turn out never to have been one)
-    const bool last_form = xdefer && h.x_last_form && (it == stop_guess || it == max_iters) && !(overlap && speculative);
     if (ba.nb > 0) {  // Ap and column sums of p.Ap
       ProfScope ps(h, 0, it);
       ba.gate = g.p;
@@ -1469,12 +1468,8 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     launch_reduce_alpha(h.part0.p, grid + (ba.nb > 0 ? cf.chunks : 0), b.ld, b.c0, b.c1, h.rz.p, h.alpha.p, g, h.stream);
     {
       ProfScope ps(h, 1, it);
-      ua.xmode = !xdefer ? 0 : last_form ? OSC_XMODE_XR_LAST : OSC_XMODE_XR_SKIPS_X;
+      ua.xmode = form.xr == host::CgXSchedule::XR_LAST ? OSC_XMODE_XR_LAST : form.xr == host::CgXSchedule::XR_SKIPS_X ? OSC_XMODE_XR_SKIPS_X : 0;
       for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });
-      if (last_form) {
-        x_done = it;
-        r_unstored = it;
-      }
     }
     if (mapped) {
       launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream,
@@ -1533,7 +1528,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   for (int it = 1; it <= max_iters; ++it) {
     if (it < max_iters && it != stop_guess && enqueued == it) {
       enqueue_iter(++enqueued, true);  // speculative: no-ops if `it` converged (overlap: ungated, scratch arrays only)
-    } else if (xdefer && x_done < it) {
+    } else if (xs.finish_before_wait(it)) {
       // nothing is enqueued behind this iteration for now (the expected last one): its x update goes out at once.  The
       // host has seen iteration it - 1 unconverged, so iteration `it` is a real one whatever its residual will say.
       finish_x(it);
@@ -1546,11 +1541,10 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       break;
     }
     if (it < max_iters && enqueued == it) {  // the guess was wrong: go on
-      if (r_unstored == it) {  // ... from the r this iteration computed but did not keep
+      if (xs.restore_r(it)) {  // ... from the r this iteration computed but did not keep
         ua.gate = nullptr;
         ua.xmode = OSC_XMODE_XR_SKIPS_X;
         for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });
-        r_unstored = 0;
       }
       enqueue_iter(++enqueued, false);
     }
@@ -1558,7 +1552,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   h.predicted_iters[b.kind] = out.iters;
   // the last iteration's x update rode in a gated p update that did not run (the solve converged under a speculative
   // iteration): alpha and p are still that iteration's
-  if (xdefer && x_rides_gated == out.iters) finish_x(out.iters);
+  if (xs.finish_at_end(out.iters)) finish_x(out.iters);
   // The solution is complete once the last residual is out; what may still be queued are the gated-off launches of
   // the speculative iteration (they return at once and write nothing).  With the mapped read-back the stream is left
   // to drain on its own -- later calls are ordered behind it anyway; the copy + event path keeps its full wait.

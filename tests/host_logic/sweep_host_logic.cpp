@@ -212,7 +212,79 @@ static void check_blk_place(const Graph& g) {
   }
 }
 
+// ---- CgXSchedule against a model of the device ---------------------------------------------------------------------
+// The host loop of run_cg (osc_api.hip) is replayed here verbatim; the "device" executes the launches in order with the
+// gating rule of the kernels (a gated launch of iteration it runs iff iteration it - 1 did not converge; an ungated
+// one always runs) and tracks which iteration's values p, alpha and r hold.  Checked: every iteration up to the one the
+// solve stopped in has its x update applied exactly once, with its own p and alpha; no other; every kernel that reads
+// r finds the r it expects; the host never launches anything for an iteration it should not.
+static void check_cg_schedule(int max_iters, int stop_guess, int converge_at, bool ungated, bool xdefer, bool last_form) {
+  CgXSchedule xs;
+  xs.xdefer = xdefer, xs.last_form = last_form, xs.ungated = ungated, xs.stop_guess = stop_guess, xs.max_iters = max_iters;
+  // device state: the iteration whose p / alpha / r the arrays hold (p: 1 after the INIT pass, r: 0 = r of x0)
+  int p_ver = 1, alpha_ver = 0, r_ver = 0;
+  std::vector<int> x_applied((size_t)max_iters + 3, 0);
+  auto converged = [&](int it) { return converge_at > 0 && it == converge_at; };
+  // a launch of iteration `it` runs on the device iff ...
+  auto runs = [&](int it, bool gated) { return !gated || it == 1 || !converged(it - 1); };
+  const bool gated = !ungated;
+  auto apply_x = [&](int it_expected) {  // x += alpha p with whatever the arrays hold
+    CHECK(p_ver == alpha_ver, "x update with p of iteration %d and alpha of iteration %d", p_ver, alpha_ver);
+    CHECK(p_ver == it_expected, "x update meant for iteration %d applied with p of iteration %d", it_expected, p_ver);
+    ++x_applied[(size_t)p_ver];
+  };
+  auto enqueue_iter = [&](int it, bool speculative) {
+    const CgXSchedule::IterForm f = xs.enqueue(it, speculative);
+    if (it > 1 && runs(it, gated)) {  // update_p: [x += alpha p,] p = z(r) + beta p
+      if (f.p_applies_x) apply_x(it - 1);
+      CHECK(r_ver == it - 1, "p update of iteration %d reads r of iteration %d", it, r_ver);
+      p_ver = it;
+    }
+    CHECK(it > 1 || !f.p_applies_x, "iteration 1 has no predecessor");
+    if (runs(it, gated)) alpha_ver = it;  // matvec + reduce_alpha
+    if (runs(it, gated)) {                // x-r kernel
+      CHECK(r_ver == it - 1, "x-r kernel of iteration %d reads r of iteration %d", it, r_ver);
+      if (f.xr == CgXSchedule::XR_WITH_X || f.xr == CgXSchedule::XR_LAST) apply_x(it);
+      if (f.xr != CgXSchedule::XR_LAST) r_ver = it;
+    }
+    CHECK(xdefer || f.xr == CgXSchedule::XR_WITH_X, "not deferred: the x-r kernel updates x");
+  };
+  auto finish_x = [&](int it) {  // ungated launch on its own
+    apply_x(it);
+    xs.finished(it);
+  };
+  int iters = max_iters, enqueued = 1;
+  enqueue_iter(1, false);
+  for (int it = 1; it <= max_iters; ++it) {
+    if (it < max_iters && it != stop_guess && enqueued == it) enqueue_iter(++enqueued, true);
+    else if (xs.finish_before_wait(it)) finish_x(it);
+    if (converged(it)) {
+      iters = it;
+      break;
+    }
+    if (it < max_iters && enqueued == it) {
+      if (xs.restore_r(it)) {
+        CHECK(r_ver == it - 1, "redoing the r update of iteration %d from r of iteration %d", it, r_ver);
+        r_ver = it;
+      }
+      enqueue_iter(++enqueued, false);
+    }
+  }
+  if (xs.finish_at_end(iters)) finish_x(iters);
+  for (int it = 1; it <= max_iters + 1; ++it)
+    CHECK(x_applied[(size_t)it] == (it <= iters ? 1 : 0),
+          "max_iters %d guess %d converge_at %d ungated %d defer %d last %d: x update of iteration %d applied %d times (solve stopped in %d)",
+          max_iters, stop_guess, converge_at, (int)ungated, (int)xdefer, (int)last_form, it, x_applied[(size_t)it], iters);
+}
+
 int main(int argc, char** argv) {
+  for (int max_iters = 1; max_iters <= 9; ++max_iters)
+    for (int guess = 0; guess <= max_iters + 2; ++guess)
+      for (int conv = 0; conv <= max_iters + 1; ++conv)  // 0 / beyond max_iters: never converges
+        for (int m = 0; m < 8; ++m) {
+          if ((m & 1) != 0 && (m & 2) == 0) continue;  // (ungated iterations need the deferred x update: run_cg never combines these)
+          check_cg_schedule(max_iters, guess, conv > max_iters ? 0 : conv, (m & 1) != 0, (m & 2) != 0, (m & 4) != 0);
+        }
   const int64_t max_n = argc > 1 ? std::atoll(argv[1]) : 200000;
   std::mt19937_64 rng(12345);
   std::vector<int64_t> ns;
