@@ -222,7 +222,13 @@ struct osc_lattice {
   int xs_groups_min = 2;   // fewest slab groups the mode is kept for when the natural count had to be reduced (OSC_XS_MIN_GROUPS)
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
-  DevBuf<uint32_t> res_bits, arrive;  // arrive: per-iteration barrier counters (+1 status word) of the one-launch path
+  DevBuf<uint32_t> res_bits;  // residual slots of the row-sharded solve
+  // Zeroed control words of the solves (residual slots, arrival counters): a ring of segments, one per solve, cleared all
+  // at once when it wraps -- hipMemsetAsync costs ~15 us of HOST time per call on this stack, during which the device
+  // sits idle at the start of a solve (7 % of a settle at N = 20000, D = 128; a quarter of one at N = 80)
+  DevBuf<uint32_t> ctrl_ring;
+  size_t ctrl_seg = 0;   // words per segment
+  int ctrl_next = 0;     // next free segment
   bool small_path = true;             // OSC_SMALL_PATH=0 disables the one-launch CG for small lattices
   int predicted_iters[3] = {0, 0, 0};  // iterations the last general-path solve of each kind (CgBuffers::kind) took (0 = unknown)
   bool x_defer = true;                // the x update rides in the next iteration's p update (run_cg; OSC_X_DEFER=0: beside the r update)
@@ -435,6 +441,23 @@ void drain_comm_stream(L& h) {
   if (!h.comm_stream_busy) return;
   HIP_CHECK(hipStreamSynchronize(h.comm_stream));
   h.comm_stream_busy = false;
+}
+
+constexpr int OSC_CTRL_RING = 32;
+// `words` zeroed control words for one solve (valid until OSC_CTRL_RING further solves have taken theirs)
+uint32_t* ctrl_segment(L& h, size_t words) {
+  drain_comm_stream(h);  // (the second stream of a sharded solve may still write the previous solve's words)
+  const size_t seg = (words + 63) / 64 * 64;
+  if (h.ctrl_seg < seg || h.ctrl_next >= OSC_CTRL_RING || h.ctrl_ring.p == nullptr) {
+    if (h.ctrl_seg < seg) {
+      if (h.ctrl_ring.p != nullptr) sync(h);  // (launches of earlier solves may still read their gates from the old ring)
+      h.ctrl_seg = seg;
+      h.ctrl_ring.alloc(seg * OSC_CTRL_RING);
+    }
+    HIP_CHECK(hipMemsetAsync(h.ctrl_ring.p, 0, h.ctrl_seg * OSC_CTRL_RING * 4, h.stream));  // behind every earlier solve's launches
+    h.ctrl_next = 0;
+  }
+  return h.ctrl_ring.p + (size_t)(h.ctrl_next++) * h.ctrl_seg;
 }
 
 void ensure_ctrl(L& h, size_t slots) {
@@ -1142,9 +1165,8 @@ bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, 
   if (C <= 0) return false;
   const size_t nslots = (size_t)max_iters + 2;
   const size_t nctl = 2 * nslots + 2;  // [residual slots | arrival counters | status]: one memset, one read-back
-  if (h.arrive.n < nctl) h.arrive.alloc(nctl);
   ensure_ctrl(h, nctl);
-  HIP_CHECK(hipMemsetAsync(h.arrive.p, 0, nctl * 4, h.stream));
+  uint32_t* ctl = ctrl_segment(h, nctl);
   SmallArgs a{};
   if (!h.ell_t_ready) {
     h.ell_col_t.alloc((size_t)h.N * h.width);
@@ -1167,15 +1189,15 @@ bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, 
   a.Y = b.rhsY;
   a.B = b.B;
   a.psi = b.psi;
-  a.res_bits = h.arrive.p;
-  a.arrive = h.arrive.p + nslots;
-  a.status = h.arrive.p + 2 * nslots;
+  a.res_bits = ctl;
+  a.arrive = ctl + nslots;
+  a.status = ctl + 2 * nslots;
   a.N = (int32_t)h.N;
   a.ld = b.ld;
   a.max_iters = max_iters;
   a.tol = tol;
   launch_settle_small(a, C, h.stream);
-  HIP_CHECK(hipMemcpyAsync(h.res_host, h.arrive.p, nctl * 4, hipMemcpyDeviceToHost, h.stream));
+  HIP_CHECK(hipMemcpyAsync(h.res_host, ctl, nctl * 4, hipMemcpyDeviceToHost, h.stream));
   sync(h);
   uint32_t st;
   std::memcpy(&st, h.res_host + 2 * nslots, 4);
@@ -1207,9 +1229,8 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   const int grid = cg_grid(h);
   const size_t nslots = (size_t)max_iters + 2;
   ensure_ctrl(h, nslots);
-  uint32_t* done_ctr = h.res_bits.p + h.res_bits.n / 2;  // second half of the control array
-  // (one fill for both halves: each fill is a launch of its own, ~5 us in front of a solve that may take 100)
-  HIP_CHECK(hipMemsetAsync(h.res_bits.p, 0, (h.res_bits.n / 2 + nslots) * 4, h.stream));
+  uint32_t* const res_slots = ctrl_segment(h, 2 * nslots);  // zeroed: [residual per iteration | arrival counter per iteration]
+  uint32_t* done_ctr = res_slots + nslots;
   // Single GPU: the last workgroup of each iteration's beta reduction writes the residual into host-mapped memory and
   // the host polls that word (no 4-byte copy, event record and event wait per iteration).  Under a communicator the
   // residual first goes through the all-reduce (below; OSC_COMM_OVERLAP=0 or OSC_MAPPED_RES=0: in the solve's stream,
@@ -1242,7 +1263,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   constexpr uint32_t kPending = 0xFFFFFFFFu;  // never a residual (those are sqrt(...) >= 0 or a canonical NaN)
   if (polled)
     for (size_t i = 0; i < nslots; ++i) reinterpret_cast<volatile uint32_t*>(h.res_host)[i] = kPending;
-  const float* res_dev = reinterpret_cast<const float*>(h.res_bits.p);
+  const float* res_dev = reinterpret_cast<const float*>(res_slots);
   SpmmArgs sa{};
   sa.g = graph_view(h, with_path);
   sa.op = op;
@@ -1472,21 +1493,21 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       for_windows(ua, [&](const UpdateArgs& w) { launch_update_xr(w, grid, h.stream); });
     }
     if (mapped) {
-      launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream,
+      launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, res_slots + it, g, h.stream,
                          done_ctr + it, h.res_host_dev + it);
       return;
     }
-    launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, h.res_bits.p + it, g, h.stream);
+    launch_reduce_beta(h.part0.p, h.part1.p, grid, b.ld, b.c0, b.c1, h.rz.p, h.beta.p, res_slots + it, g, h.stream);
     if (overlap) {  // max over the shards (solver.py:29) and its way to the host, beside the next iteration's first kernels
       HIP_CHECK(hipEventRecord(h.step_events[(size_t)it], h.stream));
       HIP_CHECK(hipStreamWaitEvent(h.comm_stream, h.step_events[(size_t)it], 0));
-      h.comm->allreduce(h.res_bits.p + it, 1, COMM_F32, COMM_MAX, h.comm_stream);
-      launch_publish_word(h.res_bits.p + it, reinterpret_cast<uint32_t*>(h.res_host_dev + it), h.comm_stream);
+      h.comm->allreduce(res_slots + it, 1, COMM_F32, COMM_MAX, h.comm_stream);
+      launch_publish_word(res_slots + it, reinterpret_cast<uint32_t*>(h.res_host_dev + it), h.comm_stream);
       return;
     }
     // column-sharded: the stop test is the max over all shards (solver.py:29)
-    if (h.comm) h.comm->allreduce(h.res_bits.p + it, 1, COMM_F32, COMM_MAX, h.stream);
-    HIP_CHECK(hipMemcpyAsync(h.res_host + it, h.res_bits.p + it, 4, hipMemcpyDeviceToHost, h.stream));
+    if (h.comm) h.comm->allreduce(res_slots + it, 1, COMM_F32, COMM_MAX, h.stream);
+    HIP_CHECK(hipMemcpyAsync(h.res_host + it, res_slots + it, 4, hipMemcpyDeviceToHost, h.stream));
     HIP_CHECK(hipEventRecord(h.iter_events[(size_t)it], h.stream));
   };
   auto wait_residual = [&](int it) -> float {
