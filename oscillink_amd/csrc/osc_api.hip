@@ -1164,9 +1164,15 @@ bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, 
   const int C = small_pick_cols((int32_t)h.N, b.ld);
   if (C <= 0) return false;
   const size_t nslots = (size_t)max_iters + 2;
-  const size_t nctl = 2 * nslots + 2;  // [residual slots | arrival counters | status]: one memset, one read-back
+  const size_t nctl = 2 * nslots + 2;  // [residual slots | arrival counters | status | finish counter]
   ensure_ctrl(h, nctl);
   uint32_t* ctl = ctrl_segment(h, nctl);
+  // the kernel's last workgroup publishes residuals + a "done" word into host-mapped memory and the host polls that
+  // word (OSC_MAPPED_RES=0: copy of the control words + stream wait, as before)
+  const bool polled = h.mapped_residual;
+  constexpr uint32_t kPending = 0xFFFFFFFFu;
+  volatile uint32_t* host_words = reinterpret_cast<volatile uint32_t*>(h.res_host);
+  if (polled) host_words[nslots] = kPending;
   SmallArgs a{};
   if (!h.ell_t_ready) {
     h.ell_col_t.alloc((size_t)h.N * h.width);
@@ -1192,16 +1198,35 @@ bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, 
   a.res_bits = ctl;
   a.arrive = ctl + nslots;
   a.status = ctl + 2 * nslots;
+  a.finish = ctl + 2 * nslots + 1;
+  a.host_words = polled ? reinterpret_cast<uint32_t*>(h.res_host_dev) : nullptr;
   a.N = (int32_t)h.N;
   a.ld = b.ld;
   a.max_iters = max_iters;
   a.tol = tol;
   launch_settle_small(a, C, h.stream);
-  HIP_CHECK(hipMemcpyAsync(h.res_host, ctl, nctl * 4, hipMemcpyDeviceToHost, h.stream));
-  sync(h);
-  uint32_t st;
-  std::memcpy(&st, h.res_host + 2 * nslots, 4);
-  if (st != 0) return false;  // barrier timeout (GPU shared with other persistent work): take the general path
+  if (polled) {
+    const double t_start = now_ms();
+    for (uint64_t spin = 1; host_words[nslots] == kPending; ++spin) {
+      if ((spin & 0x3FFF) == 0) {  // every ~16k polls: has the stream died or drained without the word?
+        const hipError_t q = hipStreamQuery(h.stream);
+        if (q != hipSuccess && q != hipErrorNotReady) hip_check(q, "hipStreamQuery (one-launch solve)", __FILE__, __LINE__);
+        if (q == hipSuccess && host_words[nslots] == kPending) throw HipError("one-launch solve finished without its done word");
+        if (now_ms() - t_start > 120000.0) throw HipError("timeout waiting for the one-launch solve");
+      }
+      __builtin_ia32_pause();
+    }
+    if (host_words[nslots] != 0u) {
+      sync(h);       // (the kernel's other workgroups are on their way out)
+      return false;  // barrier timeout (GPU shared with other persistent work): take the general path
+    }
+  } else {
+    HIP_CHECK(hipMemcpyAsync(h.res_host, ctl, nctl * 4, hipMemcpyDeviceToHost, h.stream));
+    sync(h);
+    uint32_t st;
+    std::memcpy(&st, h.res_host + 2 * nslots, 4);
+    if (st != 0) return false;  // barrier timeout (GPU shared with other persistent work): take the general path
+  }
   h.history.clear();
   out = CgResult{max_iters, 0.f, xout};
   for (int it = 1; it <= max_iters; ++it) {

@@ -17,6 +17,10 @@ struct SmallArgs {
   uint32_t* res_bits;  // [max_iters + 2] residual per iteration (float bits, atomicMax), zeroed by the host
   uint32_t* arrive;    // [max_iters + 2] arrival counters, zeroed by the host
   uint32_t* status;    // 0 ok, 2 = barrier timeout
+  uint32_t* finish;    // nullptr, or a zeroed counter: workgroups that have stored their rows of X
+  // nullptr, or host-mapped words (device address): [1 .. iterations run] residual bits, [max_iters + 2] "done" (the
+  // host sets it to a pending pattern; the kernel writes 0 behind the residuals, or 2 when its barrier gave up)
+  uint32_t* host_words;
   int32_t N, ld, max_iters;
   float tol;
 };

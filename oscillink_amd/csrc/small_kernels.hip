@@ -188,7 +188,13 @@ __global__ __launch_bounds__(T) void k_settle_small(const SmallArgs a) {
       }
       *s_fail = fail;
       *s_res = __uint_as_float(atomicMax(a.res_bits + it, 0u));  // returning atomic: the value at the memory side
-      if (fail) atomicExch(a.status, 2u);
+      if (fail) {
+        atomicExch(a.status, 2u);
+        if (a.host_words != nullptr) {  // tell the polling host at once (every block that gives up writes the same word)
+          *reinterpret_cast<volatile uint32_t*>(a.host_words + a.max_iters + 2) = 2u;
+          __threadfence_system();
+        }
+      }
     }
     __syncthreads();
     if (*s_fail) return;
@@ -212,6 +218,25 @@ __global__ __launch_bounds__(T) void k_settle_small(const SmallArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c)
       if (col0 + c < a.ld) a.X[(size_t)row * a.ld + col0 + c] = x[row * C + c];
+  }
+  if (a.host_words == nullptr) return;
+  // The last workgroup to get here publishes the residuals of the iterations that ran and a "done" word into host-mapped
+  // memory: the host polls that word instead of paying a copy, an event and a stream wait for a solve of 60-100 us.
+  // (Every workgroup's rows of X are out before it counts itself in.)
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    *s_fail = atomicAdd(a.finish, 1u) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!*s_fail) return;
+  for (int i = 1 + tid; i <= it; i += T)
+    *reinterpret_cast<volatile uint32_t*>(a.host_words + i) = atomicMax(a.res_bits + i, 0u);
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    *reinterpret_cast<volatile uint32_t*>(a.host_words + a.max_iters + 2) = 0u;
+    __threadfence_system();
   }
 }
 
