@@ -192,6 +192,9 @@ def main():
     lat._call("osc_comm_info", C.byref(c_rank), C.byref(c_world), C.byref(c_mode), c_kind, 32)
     comm_info = {"kind": c_kind.value.decode(), "world": int(c_world.value), "rank": int(c_rank.value),
                  "shard": "row" if c_mode.value == 1 else "column"}
+    ov = os.environ.get("OSC_COMM_OVERLAP")  # where the stop test's all-reduce runs (library default: by world size)
+    comm_info["stop_test"] = ("none" if comm_info["kind"] == "none" else
+                              "second stream" if (ov not in (None, "0") or (ov is None and comm_info["world"] >= 4)) else "solve's stream")
     if launched and (comm_info["kind"] != "rccl" or comm_info["world"] != world):
         print(f"bench.py: rank {rank}: communicator reports {comm_info}, expected rccl over {world} ranks", file=sys.stderr,
               flush=True)
