@@ -2,30 +2,45 @@
 """Benchmark of the lattice settle hot path on MI355X (BASELINE.json metric: settles/sec + ms/settle at N x D).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3          # starts its own 8 ranks (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              # ... or runs as one rank of a launcher's job
 
 Workload: BASELINE.json configs[2] -- N=100000, D=768, k=32, fp32, synthetic Gaussian anchors
-(default_rng(0).standard_normal), psi = normalise(mean of the first 32 rows), lams (1.0, 0.5, 4.0), row cap 1.0.
-One *step* = one `settle(dt=1, max_iters=12, tol=1e-3)` from the freshly built state (U reset to Y on the
-device inside the timed region, so every step does identical work: 4-5 CG iterations).  The graph build
-(kNN + mutual + cap + Laplacian weights) is timed separately, as the reference's own harness does
+(default_rng(seed).standard_normal), psi = normalise(mean of the first 32 rows), lams (1.0, 0.5, 4.0), row cap 1.0.
+One *step* = `reset_U` (U <- Y on the device, a 307 MB device-to-device copy that is INSIDE the timed step) + one
+`settle(dt=1, max_iters=12, tol=1e-3)` from that state, so every step does identical work: 4-5 CG iterations.  The
+graph build (kNN + mutual + cap + Laplacian weights) is timed separately, as the reference's own harness does
 (scripts/scale_benchmark.py:44-46).
+
+Protocol (/root/reference/scripts/scale_benchmark.py:23-53 seeds its runs): seeds {0, 1, 2} on
+one GPU (one seed under a communicator unless --seeds says otherwise), per seed W warm-up steps and then EXACTLY K
+timed steps between barrier + device drain on both sides; every step is also timed by itself (the host returns from
+a settle when it has read the last residual).  `ms_per_step` = median over all timed steps (max over the ranks of
+the per-rank medians), p10 / p90 beside it, `value` = 1000 / median; the bracketed regions' mean is reported as
+`ms_per_step_mean` (max over ranks).
 
 N > 1: strong scaling of the same settle -- the CG is column-sharded (per-column alpha/beta), each rank owns a
 D/N column slab and the only per-iteration exchange is one RCCL all-reduce(max) of the residual.  This script uses no
-PyTorch: the launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; the ncclUniqueId travels through a
+PyTorch: a launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; the ncclUniqueId travels through a
 rendezvous directory on the node, the timing barrier and the max over ranks go through the library's own communicator
-(osc_comm_allreduce_f64).  If the communicator cannot be set up on every rank the run FAILS (exit code 3, no JSON line):
-N independent replicas are not a measurement of this job.  The JSON line carries `comm` = what the library's communicator
-reports (kind "rccl", world N) so that a reader can see RCCL really spanned N ranks.
+(osc_comm_allreduce_f64).  Started WITHOUT a launcher (`python bench.py --gpus N`, no RANK / WORLD_SIZE in the
+environment) the script is its own launcher: the parent never loads the library or touches a GPU, checks that N
+devices are visible (else exit 3 before any build), builds the library, starts N fresh child processes of itself with
+the launcher environment set, waits with a time limit, kills stragglers, forwards rank 0's ONE JSON line and exits
+with the worst child's code.  If the communicator cannot be set up on every rank the run FAILS (exit code 3, no JSON
+line): N independent replicas are not a measurement of this job.  The JSON line carries `comm` = what the library's
+communicator reports (kind "rccl", world N, RCCL's version) so that a reader can see RCCL really spanned N ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with these extra objects:
   roofline        : the operator apply (SpMM, the CG matvec): algorithmic bytes per launch / mean launch time (HIP
                     events on the library's own stream) against the 8 TB/s HBM3E peak; `settle` = the whole settle's
-                    algorithmic bytes / ms_per_step; `traffic` only from a committed PMC profile taken with THIS build.
+                    algorithmic bytes / ms_per_step; `traffic` only from a committed PMC profile taken with THIS build;
+                    `per_rank` = every rank's window apply against its own algorithmic bytes.
   knn             : the lattice build: route, device time, GEMM+top-k kernel time, 2 N^2 D flops against the MFMA peak.
   ustar_solve_ms, receipt_ms : medians of the stationary solve and of light / full receipts (U* resident).
+  first_settle_ms, mispredict_settle_ms : what a fresh handle's first settle and a settle whose iteration count the
+                    handle guessed wrong cost (the loop predicts its last iteration from the previous solve).
   cpu_baseline    : the CPU oracle (NumPy/SciPy CSR restatement, oracle/) on the same settle: warm-up + >= 3
                     repetitions, median and p10/p90, column-parallel on the host cores.
 """
@@ -37,7 +52,11 @@ import json
 import math
 import os
 import shutil
+import signal
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -113,6 +132,154 @@ class StdoutToStderr:
         return False
 
 
+# ---- self-launcher: `python bench.py --gpus N` without torch.distributed.run ----------------------------------------
+EXIT_REFUSED = 3  # the job this command line asks for cannot be measured here (too few devices / no communicator)
+
+
+def visible_device_count() -> int:
+    """HIP devices this process tree would see, counted by a short-lived CHILD (the launcher parent must never
+    initialise a GPU itself: its children are fresh processes, and a parent holding a context would also occupy one of
+    the box's few process slots on the card).  0 when the runtime is missing or reports an error."""
+    code = ("import ctypes\n"
+            "n = ctypes.c_int(0)\n"
+            "try:\n"
+            "    lib = None\n"
+            "    for name in ('libamdhip64.so', '/opt/rocm/lib/libamdhip64.so'):\n"
+            "        try:\n"
+            "            lib = ctypes.CDLL(name)\n"
+            "            break\n"
+            "        except OSError:\n"
+            "            pass\n"
+            "    ok = lib is not None and lib.hipGetDeviceCount(ctypes.byref(n)) == 0\n"
+            "    print(n.value if ok else 0)\n"
+            "except Exception:\n"
+            "    print(0)\n")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                           timeout=180)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def free_port() -> int:
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(world: int, child_argv: list, timeout_s: float = 1500.0, grace_s: float = 20.0, env_extra=None,
+                 out=None, err=None) -> int:
+    """Start `world` fresh processes running `child_argv` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set (what torch.distributed.run would provide), wait for them with a time limit, and return the job's exit code:
+    0 only if EVERY rank exited 0 and rank 0 printed a JSON line, which is then forwarded to `out` as the job's only
+    stdout line.  When a rank fails the others get `grace_s` to fail on their own (they usually notice through the
+    rendezvous) and are then killed by process group; the same at the time limit.  Never execs: children are new
+    processes, each in its own session, so a kill reaches exactly the processes started here."""
+    out = out or sys.stdout
+    err = err or sys.stderr
+    port = free_port()
+    procs = []
+    r0_lines = []
+    for rank in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "OSC_BENCH_LAUNCHED_BY": str(os.getpid())})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this stack
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen(child_argv, env=env, stdout=subprocess.PIPE, stderr=None, text=True,
+                                      start_new_session=True))
+
+    def pump(rank, p):  # rank 0's stdout is the job's stdout (collected); the other ranks' stdout goes to stderr
+        for line in p.stdout:
+            if rank == 0:
+                r0_lines.append(line)
+            else:
+                err.write(f"[rank {rank}] {line}")
+                err.flush()
+
+    threads = [threading.Thread(target=pump, args=(r, p), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+
+    killed = set()  # ranks this launcher ended itself: their signal codes say nothing about the job
+
+    def kill_all(sig):
+        for r, p in enumerate(procs):
+            if p.poll() is None:
+                killed.add(r)
+                try:
+                    os.killpg(p.pid, sig)  # (own session: pgid == pid)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    t0 = time.time()
+    first_fail = None
+    reason = None
+    while any(p.poll() is None for p in procs):
+        now = time.time()
+        if first_fail is None and any(p.poll() not in (None, 0) for p in procs):
+            first_fail = now
+        if first_fail is not None and now - first_fail > grace_s:
+            reason = "a rank failed and the others did not exit by themselves"
+            break
+        if now - t0 > timeout_s:
+            reason = f"time limit of {timeout_s:.0f} s reached"
+            break
+        time.sleep(0.05)
+    if reason:
+        err.write(f"bench.py launcher: {reason}; killing the remaining ranks\n")
+        kill_all(signal.SIGTERM)
+        t1 = time.time()
+        while any(p.poll() is None for p in procs) and time.time() - t1 < 10.0:
+            time.sleep(0.05)
+        kill_all(signal.SIGKILL)
+    for p in procs:
+        p.wait()
+    for t in threads:
+        t.join(5.0)
+    codes = [p.returncode if p.returncode >= 0 else 128 - p.returncode for p in procs]  # (killed by signal s: 128 + s)
+    worst = max([c for r, c in enumerate(codes) if r not in killed] or [0])  # the worst of the ranks that ended by themselves
+    if reason and worst == 0:
+        worst = 124  # nobody failed, somebody never finished
+    if worst != 0:
+        err.write(f"bench.py launcher: rank exit codes {codes} -> exit {worst}; no result line\n")
+        err.flush()
+        return worst
+    lines = [ln for ln in r0_lines if ln.lstrip().startswith("{")]
+    try:
+        json.loads(lines[-1])
+    except (IndexError, ValueError):
+        err.write("bench.py launcher: every rank exited 0 but rank 0 printed no JSON line\n")
+        return 4
+    for ln in r0_lines:  # anything else rank 0 printed is not part of the one-line contract
+        if ln is not lines[-1] and ln.strip():
+            err.write(f"[rank 0] {ln}")
+    out.write(lines[-1] if lines[-1].endswith("\n") else lines[-1] + "\n")
+    out.flush()
+    return 0
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) with no launcher around it."""
+    n = args.gpus
+    have = visible_device_count()
+    one_device = bool(os.environ.get("OSC_BENCH_ONE_DEVICE"))
+    if have < n and not (one_device and have >= 1):
+        print(f"bench.py: --gpus {n} but {have} HIP device(s) visible here; refusing to report replicas or oversubscribed "
+              f"devices as a {n}-GPU run (nothing was built or started)", file=sys.stderr, flush=True)
+        return EXIT_REFUSED
+    from oscillink_amd import _build  # hipcc only: compiles, does not load the library
+
+    _build.build()  # before the ranks start, so that N children never race one stale library
+    child = [sys.executable, os.path.abspath(__file__), *sys.argv[1:]]
+    return launch_ranks(n, child, timeout_s=args.launch_timeout)
+
+
+def pctl(xs, q):
+    return float(np.percentile(np.asarray(xs, dtype=np.float64), q))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +290,11 @@ def main():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--tol", type=float, default=1e-3)
     ap.add_argument("--max-iters", type=int, default=12)
+    ap.add_argument("--seeds", type=str, default=None,
+                    help="comma-separated anchor seeds, each timed for --steps steps (default: 0,1,2 on one GPU -- "
+                         "BASELINE.md section 2 --, 0 under a communicator)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="self-launcher: seconds the ranks get before they are killed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the build / U* / receipt timings after the timed region")
     ap.add_argument("--extras", action="store_true",
@@ -132,6 +304,12 @@ def main():
                     help="multi-GPU CG partitioning: column slabs (one all-reduce(max) per iteration, default) or "
                          "row blocks (halo exchange of p + all-reduces of D-vectors, the north-star wording)")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        raise SystemExit("bench.py: need --gpus >= 1, --steps >= 1, --warmup >= 0")
+
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        raise SystemExit(self_launch(args))
 
     os.environ["OSC_SHARD"] = args.shard
     rank = int(os.environ.get("RANK", "0"))
@@ -139,104 +317,161 @@ def main():
     if os.environ.get("OSC_BENCH_ONE_DEVICE"):  # rehearsal on a one-GPU box: every rank on device 0 (RCCL then refuses
         local_rank = 0                          # the communicator and the run must fail, see below)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     # (rehearsal on a one-GPU box: OSC_BENCH_FORCE_COMM=1 takes the multi-GPU code path -- rendezvous, the library's RCCL
     # communicator, the sharded solve with its second stream, barriers -- with the one rank RCCL allows there)
     launched = world > 1 or bool(os.environ.get("OSC_BENCH_FORCE_COMM"))
+    seeds = [int(x) for x in (args.seeds or ("0" if launched else "0,1,2")).split(",") if x.strip() != ""]
+    if not seeds:
+        raise SystemExit("bench.py: --seeds is empty")
 
     from oscillink_amd import Oscillink
     from oscillink_amd import _native as nat
     from oscillink_amd.sharding import rccl_unique_id
 
+    if nat.device_count() <= local_rank:  # fail before any work: this rank has no device of its own
+        print(f"bench.py: rank {rank}: device {local_rank} does not exist ({nat.device_count()} visible); refusing to "
+              "report replicas or shared devices as a sharded run", file=sys.stderr, flush=True)
+        raise SystemExit(EXIT_REFUSED)
     N, D, k = args.N, args.D, args.k
-    rng = np.random.default_rng(0)
-    Y = rng.standard_normal((N, D)).astype(np.float32)
-    psi = Y[:32].mean(axis=0)
-    psi = (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
-
     rdzv = FileRendezvous(rank, world) if launched else None
-    comm = None
-    comm_error = None
-    if launched:  # bootstrap the library's own RCCL communicator: rank 0 makes the id, the directory carries it
-        try:
-            if rank == 0:
-                rdzv.put("uid", rccl_unique_id())
-            comm = (rdzv.get("uid"), rank, world)
-        except Exception as e:  # noqa: BLE001
-            comm_error = f"{type(e).__name__}: {e}"
 
-    t0 = time.time()
-    lat = None
-    if comm is not None:
-        try:
-            with StdoutToStderr():
-                lat = Oscillink(Y, kneighbors=k, deterministic_k=False, device=local_rank, comm=comm)
-        except Exception as e:  # noqa: BLE001 -- reported by every rank below
-            comm_error = f"{type(e).__name__}: {e}"
-            lat = None
-    if launched:  # every rank learns whether ALL ranks joined; if not, the job fails as a whole
-        flags = rdzv.gather("comm_ok", (comm_error or "").encode())
-        bad = [f.decode() for f in flags if f]
-        if bad:
-            if lat is not None:
-                lat.close()
-            rdzv.close()
-            print(f"bench.py: rank {rank}: the {world}-rank communicator could not be set up ({comm_error or bad[0]}); "
-                  "refusing to report independent replicas as a sharded run", file=sys.stderr, flush=True)
-            raise SystemExit(3)
-    if lat is None:
-        lat = Oscillink(Y, kneighbors=k, deterministic_k=False, device=local_rank)
-    # what the library's communicator itself says (kind "rccl" / "loopback" / "none", ranks it spans)
-    c_rank, c_world, c_mode, c_kind = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.create_string_buffer(32)
-    lat._call("osc_comm_info", C.byref(c_rank), C.byref(c_world), C.byref(c_mode), c_kind, 32)
-    comm_info = {"kind": c_kind.value.decode(), "world": int(c_world.value), "rank": int(c_rank.value),
-                 "shard": "row" if c_mode.value == 1 else "column"}
-    ov = os.environ.get("OSC_COMM_OVERLAP")  # where the stop test's all-reduce runs (library default: by world size)
-    comm_info["stop_test"] = ("none" if comm_info["kind"] == "none" else
-                              "second stream" if (ov not in (None, "0") or (ov is None and comm_info["world"] >= 4)) else "solve's stream")
-    if launched and (comm_info["kind"] != "rccl" or comm_info["world"] != world):
-        print(f"bench.py: rank {rank}: communicator reports {comm_info}, expected rccl over {world} ranks", file=sys.stderr,
-              flush=True)
-        raise SystemExit(3)
-    lattice_create_ms = 1000.0 * (time.time() - t0)
-    nnz, max_deg, dev_build_ms = lat.graph_stats()
-    lat.set_query(psi)
+    def make_inputs(seed):
+        rng = np.random.default_rng(seed)
+        Y = rng.standard_normal((N, D)).astype(np.float32)
+        psi = Y[:32].mean(axis=0)
+        return Y, (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
 
-    def sync_all():
+    def make_lattice(Y, tag):
+        """One lattice, under the job's communicator when there is one.  Every rank learns whether ALL ranks joined; if
+        not, the job fails as a whole."""
+        comm = None
+        comm_error = None
+        if launched:  # bootstrap the library's own RCCL communicator: rank 0 makes the id, the directory carries it
+            try:
+                if rank == 0:
+                    rdzv.put(f"uid.{tag}", rccl_unique_id())
+                comm = (rdzv.get(f"uid.{tag}"), rank, world)
+            except Exception as e:  # noqa: BLE001
+                comm_error = f"{type(e).__name__}: {e}"
+        lat = None
+        if comm is not None:
+            try:
+                with StdoutToStderr():
+                    lat = Oscillink(Y, kneighbors=k, deterministic_k=False, device=local_rank, comm=comm)
+            except Exception as e:  # noqa: BLE001 -- reported by every rank below
+                comm_error = f"{type(e).__name__}: {e}"
+                lat = None
+        if launched:
+            flags = rdzv.gather(f"comm_ok.{tag}", (comm_error or "").encode())
+            bad = [f.decode() for f in flags if f]
+            if bad:
+                if lat is not None:
+                    lat.close()
+                rdzv.close()
+                print(f"bench.py: rank {rank}: the {world}-rank communicator could not be set up ({comm_error or bad[0]}); "
+                      "refusing to report independent replicas as a sharded run", file=sys.stderr, flush=True)
+                raise SystemExit(EXIT_REFUSED)
+        if lat is None:
+            lat = Oscillink(Y, kneighbors=k, deterministic_k=False, device=local_rank)
+        return lat
+
+    def comm_info_of(lat):
+        """what the library's communicator itself says (kind "rccl" / "loopback" / "none", ranks it spans)"""
+        c_rank, c_world, c_mode, c_kind = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.create_string_buffer(32)
+        lat._call("osc_comm_info", C.byref(c_rank), C.byref(c_world), C.byref(c_mode), c_kind, 32)
+        info = {"kind": c_kind.value.decode(), "world": int(c_world.value), "rank": int(c_rank.value),
+                "shard": "row" if c_mode.value == 1 else "column"}
+        ov = os.environ.get("OSC_COMM_OVERLAP")  # where the stop test's all-reduce runs (DESIGN.md section 6; default: by world size)
+        info["stop_test"] = ("none" if info["kind"] == "none" else
+                             "second stream" if (ov not in (None, "0") or (ov is None and info["world"] >= 4)) else "solve's stream")
+        ver = C.c_int32(0)
+        nat.lib().osc_comm_backend_version(C.byref(ver))
+        info["rccl_version"] = int(ver.value)
+        if launched and (info["kind"] != "rccl" or info["world"] != world):
+            print(f"bench.py: rank {rank}: communicator reports {info}, expected rccl over {world} ranks", file=sys.stderr,
+                  flush=True)
+            raise SystemExit(EXIT_REFUSED)
+        return info
+
+    def sync_all(lat):
         """barrier + device drain on every rank"""
         nat.lib().osc_device_synchronize(local_rank)
         if launched:
             lat._call("osc_comm_allreduce_f64", None, 0, 0)  # drains the stream, then a barrier over the communicator
         nat.lib().osc_device_synchronize(local_rank)
 
-    def max_over_ranks(x: float) -> float:
+    def over_ranks(lat, x: float, op: str = "max") -> float:
         if not launched:
             return x
-        v = (C.c_double * 1)(x)
+        v = (C.c_double * 1)(-x if op == "min" else x)
         lat._call("osc_comm_allreduce_f64", v, 1, 1)
-        return float(v[0])
+        return float(-v[0] if op == "min" else v[0])
 
-    def step():
-        lat.reset_U(wait=False)  # (ordered by the handle's stream; the settle below starts behind it)
-        return lat.settle(dt=1.0, max_iters=args.max_iters, tol=args.tol)
+    def time_seed(seed, first):
+        """W warm-up steps, then EXACTLY K timed steps between barrier + drain; each step also timed by itself."""
+        t_in = time.time()
+        Y, psi = make_inputs(seed)
+        t_c = time.time()
+        lat = make_lattice(Y, f"s{seed}")
+        info = comm_info_of(lat)
+        create_ms = 1000.0 * (time.time() - t_c)
+        nnz, max_deg, dev_build_ms = lat.graph_stats()
+        lat.set_query(psi)
 
-    for _ in range(args.warmup):
-        last = step()
-    lat._call("osc_profile_enable", 1)
-    lat._call("osc_profile_reset")
-    sync_all()
-    t0 = time.perf_counter()
-    iters_total = 0
-    for _ in range(args.steps):
-        last = step()
-        iters_total += last["iters"]
-    sync_all()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+        def step():
+            lat.reset_U(wait=False)  # (ordered by the handle's stream; the settle below starts behind it)
+            return lat.settle(dt=1.0, max_iters=args.max_iters, tol=args.tol)
 
-    launches, total_ms = C.c_int64(0), C.c_double(0.0)
-    lat._call("osc_profile_get", 0, C.byref(launches), C.byref(total_ms))
-    lat._call("osc_profile_enable", 0)
+        for _ in range(args.warmup):
+            last = step()
+        lat._call("osc_profile_enable", 1)
+        lat._call("osc_profile_reset")
+        sync_all(lat)
+        per_step = []
+        iters_total = 0
+        t0 = time.perf_counter()
+        ta = t0
+        for _ in range(args.steps):
+            last = step()
+            tb = time.perf_counter()
+            per_step.append(1000.0 * (tb - ta))
+            ta = tb
+            iters_total += last["iters"]
+        sync_all(lat)
+        elapsed = time.perf_counter() - t0
+        launches, total_ms = C.c_int64(0), C.c_double(0.0)
+        lat._call("osc_profile_get", 0, C.byref(launches), C.byref(total_ms))
+        lat._call("osc_profile_enable", 0)
+        return {"seed": seed, "lat": lat, "Y": Y, "psi": psi, "comm": info, "create_ms": create_ms,
+                "inputs_ms": 1000.0 * (t_c - t_in), "nnz": nnz, "max_deg": max_deg, "dev_build_ms": dev_build_ms,
+                "per_step_ms": per_step, "elapsed_s": elapsed, "iters_total": iters_total, "last": last,
+                "apply_launches": int(launches.value), "apply_total_ms": float(total_ms.value), "first": first, "step": step}
+
+    runs = []
+    for i, seed in enumerate(seeds):
+        r = time_seed(seed, i == 0)
+        if i > 0:  # only the first seed's lattice is kept for the numbers beside the timed region
+            sync_all(r["lat"])
+            r["lat"].close()
+            r["lat"] = r["Y"] = r["step"] = None
+        runs.append(r)
+    main_run = runs[0]
+    lat, Y, psi = main_run["lat"], main_run["Y"], main_run["psi"]
+    comm_info = main_run["comm"]
+    nnz, max_deg = main_run["nnz"], main_run["max_deg"]
+
+    all_steps = [t for r in runs for t in r["per_step_ms"]]
+    med_local = pctl(all_steps, 50)
+    ms_median = over_ranks(lat, med_local)                     # max over the ranks of the per-rank medians
+    ms_p10, ms_p90 = over_ranks(lat, pctl(all_steps, 10)), over_ranks(lat, pctl(all_steps, 90))
+    mean_local = 1000.0 * sum(r["elapsed_s"] for r in runs) / (args.steps * len(runs))
+    ms_mean = over_ranks(lat, mean_local)                      # bracketed regions: barrier + drain on both sides
+    ms_mean_min = over_ranks(lat, mean_local, "min")
+    ms_median_min = over_ranks(lat, med_local, "min")
+    iters_mean = sum(r["iters_total"] for r in runs) / (args.steps * len(runs))
+
     c0, c1 = C.c_int32(0), C.c_int32(0)
     lat._call("osc_comm_shard", C.byref(c0), C.byref(c1))
     d_local = int(c1.value - c0.value)
@@ -251,16 +486,24 @@ def main():
     spmm_kernel = ("k_apply_blocked<" if plan.get("apply_src_blocks") else  # (template arguments: matched by prefix)
                    "k_spmm<8, 1, 0>" if plan["apply_xs_workgroups"] else None)
     bytes_apply = 8.0 * n_local * d_local + (8.0 * nnz + 12.0 * N) * (n_local / N)
-    apply_ms = total_ms.value / max(1, launches.value)
+    apply_ms = sum(r["apply_total_ms"] for r in runs) / max(1, sum(r["apply_launches"] for r in runs))
     bytes_mv = bytes_apply / slabs
     mv_ms = apply_ms / slabs
     achieved = bytes_mv / (mv_ms * 1e-3) / 1e9 if mv_ms > 0 else 0.0
     traffic, traffic_src = pmc_traffic(N, D, k, world, spmm_kernel)
-    ms_per_step = 1000.0 * elapsed / args.steps
-    iters_mean = iters_total / args.steps
     # whole settle, algorithmic: (20 + 44 I) N D + 8 nnz (I + 1) bytes, all ranks together
     bytes_settle = (20.0 + 44.0 * iters_mean) * N * D + 8.0 * nnz * (iters_mean + 1.0)
-    settle_gbs = bytes_settle / (ms_per_step * 1e-3) / 1e9  # all GPUs together (they settle ONE lattice)
+    settle_gbs = bytes_settle / (ms_median * 1e-3) / 1e9  # all GPUs together (they settle ONE lattice)
+
+    # every rank's window apply against its own algorithmic bytes (the shapes a scaling run really times)
+    mine = {"rank": rank, "columns": d_local, "rows": n_local, "apply_ms": apply_ms, "launches_per_apply": slabs,
+            "algorithmic_bytes_per_apply": bytes_apply,
+            "achieved_GBs": bytes_apply / (apply_ms * 1e-3) / 1e9 if apply_ms > 0 else 0.0,
+            "ms_per_step_median": med_local, "ms_per_step_mean": mean_local,
+            "kernel": "k_apply_blocked" if plan.get("apply_src_blocks") else "k_spmm",
+            "src_blocks": plan.get("apply_src_blocks", 0)}
+    mine["frac"] = mine["achieved_GBs"] / HBM_PEAK_GBS
+    per_rank = [mine] if not launched else [json.loads(b.decode()) for b in rdzv.gather("rank_stats", json.dumps(mine).encode())]
 
     # The same launch against the bound that applies to a gather (profiles/r02_gather_bench.txt):
     # a CU retires one random 128-byte row per N clocks depending on the footprint an XCD gathers from -- measured with
@@ -284,24 +527,38 @@ def main():
 
     out = {
         "metric": "settles/sec",
-        "value": args.steps / elapsed,  # all ranks settle ONE lattice together
+        "value": 1000.0 / ms_median,  # all ranks settle ONE lattice together
         "unit": "settles/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
+        "ms_per_step": ms_median,
+        "ms_per_step_p10": ms_p10,
+        "ms_per_step_p90": ms_p90,
+        "ms_per_step_mean": ms_mean,
+        "ms_per_step_over_ranks": {"median_min": ms_median_min, "median_max": ms_median, "mean_min": ms_mean_min,
+                                   "mean_max": ms_mean},
+        "steps_timed_total": args.steps * len(runs),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"config3: N={N} D={D} k={k} fp32 settle(dt=1,max_iters={args.max_iters},tol={args.tol})",
+        "config": {"workload": f"config3: N={N} D={D} k={k} fp32; one step = reset_U (U <- Y, device copy, inside the "
+                               f"timed step) + settle(dt=1,max_iters={args.max_iters},tol={args.tol})",
                    "N": N, "D": D, "k": k, "nnz": nnz, "max_degree": max_deg,
                    "parallelism": "single" if not launched else f"{args.shard}-sharded CG x{world}",
-                   "cg_iters_per_settle": iters_mean, "residual": last["res"]},
+                   "cg_iters_per_settle": iters_mean, "residual": main_run["last"]["res"],
+                   "seeds": seeds,
+                   "per_seed": [{"seed": r["seed"], "ms_per_step_median": pctl(r["per_step_ms"], 50),
+                                 "ms_per_step_mean": 1000.0 * r["elapsed_s"] / args.steps, "nnz": r["nnz"],
+                                 "cg_iters_per_settle": r["iters_total"] / args.steps,
+                                 "graph_build_device_ms": r["dev_build_ms"]} for r in runs],
+                   "statistic": "value = 1000 / median over all timed steps (max over ranks of the per-rank medians); "
+                                "ms_per_step_mean = the barrier-bracketed regions / steps (max over ranks)"},
         "comm": comm_info,
-        "lattice_create_ms": lattice_create_ms,  # first call in the process: HIP context + code objects + upload + build
-        "graph_build_device_ms": dev_build_ms,
+        "lattice_create_ms": main_run["create_ms"],  # first call in the process: HIP context + code objects + upload + build
+        "graph_build_device_ms": main_run["dev_build_ms"],
         "roofline": {"bound": "hbm",
                      "kernel": (f"k_apply_blocked (operator apply / CG matvec; one launch, XCD-affine 32-column slabs, "
                                 f"source rows walked in {plan['apply_src_blocks']} blocks)" if plan.get("apply_src_blocks") else
@@ -311,14 +568,18 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_mv, "mean_launch_ms": mv_ms,
-                     "launches_per_apply": slabs, "apply_ms": apply_ms, "applies_timed": int(launches.value),
+                     "launches_per_apply": slabs, "apply_ms": apply_ms,
+                     "applies_timed": sum(r["apply_launches"] for r in runs),
                      "achieved_traffic_GBs": (traffic / (mv_ms * 1e-3) / 1e9) if (traffic and mv_ms > 0) else None,
                      "request_rate": request_rate,
+                     "per_rank": per_rank,
                      "settle": {"algorithmic_bytes": bytes_settle, "achieved": settle_gbs,
                                 "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                                 "frac": settle_gbs / (HBM_PEAK_GBS * world)}},
     }
 
+    if not launched and not args.no_extras:
+        out.update(cold_and_mispredicted(lat, Y, psi, args, k, local_rank, main_run["step"]))
     if not args.no_extras and (not launched or args.extras):
         out.update(extras(lat, N, D, args, launched))
     elif launched:
@@ -328,9 +589,67 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if launched:
-        sync_all()
+        sync_all(lat)
         lat.close()
         rdzv.close()
+
+
+def cold_and_mispredicted(lat, Y, psi, args, k, device, step):
+    """Two numbers the steady-state loop hides (run_cg predicts its last iteration from the handle's previous solve of
+    the same kind, osc_api.hip: predicted_iters): (1) the first settle of a FRESH handle -- no prediction, first-use
+    scratch and block-major graph copy; (2) a settle whose iteration count the handle guesses wrong, both ways: guessed
+    one short (the host reads a residual it expected to be the last, re-enqueues: one round trip + the r update
+    redone) and one long (a needless speculative iteration's gated-off launches).  Device-synchronised wall times of
+    reset_U + settle, like a timed step; medians of 7."""
+    from oscillink_amd import Oscillink
+    from oscillink_amd import _native as nat
+
+    def timed(fn):
+        nat.lib().osc_device_synchronize(device)
+        t0 = time.perf_counter()
+        r = fn()
+        nat.lib().osc_device_synchronize(device)
+        return 1000.0 * (time.perf_counter() - t0), r
+
+    fresh = Oscillink(Y, kneighbors=k, deterministic_k=False, device=device)
+    fresh.set_query(psi)
+
+    def fstep():
+        fresh.reset_U(wait=False)
+        return fresh.settle(dt=1.0, max_iters=args.max_iters, tol=args.tol)
+
+    first_ms, st = timed(fstep)
+    second_ms, _ = timed(fstep)
+    fresh.close()
+    hist = lat.residual_history()
+    iters = st["iters"]
+    res = {"first_settle_ms": first_ms, "second_settle_ms": second_ms}
+    steady, low, high = [], [], []
+    tol_short = None  # a tolerance the solve meets one iteration earlier: between the residuals of iterations iters-1 and iters-2
+    if iters >= 3 and len(hist) >= iters and hist[iters - 2] > args.tol and hist[iters - 3] > hist[iters - 2]:
+        tol_short = float(math.sqrt(hist[iters - 2] * hist[iters - 3]))
+    for _ in range(7):
+        steady.append(timed(step)[0])
+        if tol_short is not None:
+            lat.reset_U(wait=False)
+            s0 = lat.settle(dt=1.0, max_iters=args.max_iters, tol=tol_short)   # leaves the handle guessing iters - 1
+            if s0["iters"] == iters - 1:
+                t, s1 = timed(step)
+                if s1["iters"] == iters:
+                    low.append(t)
+        if iters + 1 <= args.max_iters:
+            lat.reset_U(wait=False)
+            lat.settle(dt=1.0, max_iters=iters + 1, tol=0.0)                   # leaves it guessing iters + 1
+            t, s1 = timed(step)
+            if s1["iters"] == iters:
+                high.append(t)
+        step()  # back to the right guess
+    res["mispredict_settle_ms"] = {"steady": float(np.median(steady)),
+                                   "guessed_one_short": float(np.median(low)) if low else None,
+                                   "guessed_one_long": float(np.median(high)) if high else None,
+                                   "note": "device-synchronised reset_U + settle, median of 7; steady = the same call with "
+                                           "the right guess"}
+    return res
 
 
 def extras(lat, N, D, args, sharded):

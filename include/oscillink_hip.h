@@ -221,6 +221,9 @@ int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* tota
  * all-reduce(max) of the stop-test residual.  id is an ncclUniqueId (128 bytes) made by rank 0
  * with osc_comm_unique_id and distributed by the caller. */
 int osc_comm_unique_id(char id_out[128]);
+/* version code of the RCCL this library is linked against (ncclGetVersion, e.g. 22203 = 2.22.3); touches no device.
+ * A bench line carries it so that a scaling record says which collective library produced it. */
+int osc_comm_backend_version(int32_t* version);
 /* An id for the in-process LOOPBACK backend instead: the ranks are threads of ONE process, each with its own handle on
  * the same GPU, and every collective is device-to-device copies between host barriers.  It runs the multi-rank code
  * paths (unequal column slabs, row-block / halo exchanges, the sharded kNN list all-gather, speculative iterations

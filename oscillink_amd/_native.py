@@ -74,6 +74,7 @@ SIGNATURES = {
     "osc_get_blocked_copy": (C.c_int, [Handle, C.c_int32, c_i32p, c_f32p, c_i32p, c_i32p, c_i32p, c_f32p, C.c_int32]),
     "osc_comm_unique_id": (C.c_int, [C.c_char_p]),
     "osc_comm_loopback_id": (C.c_int, [C.c_char_p]),
+    "osc_comm_backend_version": (C.c_int, [c_i32p]),
     "osc_comm_init": (C.c_int, [Handle, C.c_char_p, C.c_int32, C.c_int32]),
     "osc_comm_info": (C.c_int, [Handle, c_i32p, c_i32p, c_i32p, C.c_char_p, C.c_int32]),
     "osc_halo_info": (C.c_int, [Handle, c_i64p, c_i64p, c_i64p, c_i64p, c_i32p]),

@@ -218,6 +218,11 @@ void comm_rccl_id(char id_out[128]) {
   std::memcpy(id_out, &id, 128);
 }
 
+int comm_rccl_version() {
+  int v = 0;
+  return ncclGetVersion(&v) == ncclSuccess ? v : 0;
+}
+
 void comm_loopback_id(char id_out[128]) {
   std::memset(id_out, 0, 128);
   std::memcpy(id_out, kLoopMagic, 8);

@@ -42,6 +42,7 @@ class Comm {
 
 void comm_rccl_id(char id_out[128]);      // throws CommError
 void comm_loopback_id(char id_out[128]);  // process-local group key
+int comm_rccl_version();                  // ncclGetVersion's code (e.g. 22105), 0 if the call fails
 std::unique_ptr<Comm> comm_create(const char id[128], int rank, int world, int device);
 
 }  // namespace osc

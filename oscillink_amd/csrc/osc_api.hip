@@ -3026,6 +3026,12 @@ int osc_comm_unique_id(char id_out[128]) {
   return OSC_OK;
 }
 
+int osc_comm_backend_version(int32_t* version) {
+  if (!version) return OSC_E_INVALID;
+  *version = comm_rccl_version();
+  return OSC_OK;
+}
+
 int osc_comm_loopback_id(char id_out[128]) {
   comm_loopback_id(id_out);
   return OSC_OK;

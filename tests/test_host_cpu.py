@@ -203,3 +203,83 @@ def test_product_signed_receipts_were_accepted_by_the_reference_verifier():
                      "tampered": False}
         assert verify_receipt(rec, fx["secret"])
         assert rec["meta"]["signature"]["payload"]["mode"] == mode
+
+
+# ---- bench.py's own launcher (`python bench.py --gpus N` without torch.distributed.run) ---------------------------------
+_STUB = r'''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"]
+mode = os.environ.get("STUB_MODE", "ok")
+if mode == "fail1" and rank == 1:
+    print("rank 1 gives up", file=sys.stderr)
+    sys.exit(3)
+if mode == "fail1" and rank != 1:
+    time.sleep(60)            # a rank that would wait for ever for its peer: the launcher must kill it
+if mode == "hang":
+    time.sleep(60)
+if mode == "nojson":
+    sys.exit(0)
+print("RCCL banner that is not JSON" if rank == 0 else f"noise from rank {rank}")
+if rank == 0:
+    print(json.dumps({"metric": "settles/sec", "n_gpus": world, "value": 1.0}))
+'''
+
+
+def _launch(tmp_path, world, mode, **kw):
+    import io
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB)
+    out, err = io.StringIO(), io.StringIO()
+    rc = bench.launch_ranks(world, [sys.executable, str(stub)], env_extra={"STUB_MODE": mode}, out=out, err=err, **kw)
+    return rc, out.getvalue(), err.getvalue()
+
+
+def test_bench_launcher_forwards_rank0s_one_json_line(tmp_path):
+    import json
+
+    rc, out, err = _launch(tmp_path, 4, "ok", timeout_s=120)
+    assert rc == 0
+    assert len(out.strip().splitlines()) == 1 and json.loads(out)["n_gpus"] == 4
+    assert "noise from rank 2" in err and "RCCL banner" in err  # everything else goes to stderr
+
+
+def test_bench_launcher_fails_as_a_whole_and_kills_stragglers(tmp_path):
+    import time
+
+    t0 = time.time()
+    rc, out, err = _launch(tmp_path, 3, "fail1", timeout_s=120, grace_s=1.0)
+    assert rc == 3 and out == "" and "killing the remaining ranks" in err
+    assert time.time() - t0 < 30  # did not wait for the sleeping ranks
+    rc, out, err = _launch(tmp_path, 2, "hang", timeout_s=1.5, grace_s=1.0)
+    assert rc != 0 and out == "" and "time limit" in err
+    rc, out, err = _launch(tmp_path, 2, "nojson", timeout_s=60)
+    assert rc == 4 and out == ""
+
+
+def test_bench_refuses_more_gpus_than_devices_before_any_build():
+    """`python bench.py --gpus 8` on a box with fewer devices: exit code 3, a message, no JSON line, nothing built or
+    started (this container has no GPU at all; the parent counts devices through a short-lived child)."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    import bench
+
+    if bench.visible_device_count() < 8:
+        assert r.returncode == 3, r.stderr
+        assert r.stdout.strip() == ""
+        assert "refusing to report" in r.stderr and "--gpus 8" in r.stderr
+    # a launcher's environment that disagrees with --gpus is refused as well (no silent 1-rank run labelled as 8)
+    env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env2, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "WORLD_SIZE=2" in r.stderr
