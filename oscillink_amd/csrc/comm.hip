@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -18,11 +19,25 @@ void nccl_ok(ncclResult_t r, const char* what) {
   if (r != ncclSuccess) throw CommError(std::string(what) + " failed: " + ncclGetErrorString(r));
 }
 
+// Measurement stand-in (OSC_RCCL_PROXY=1, one-rank communicators only): at world 1 ncclAllReduce launches nothing, so the
+// one GPU a round gets cannot show what the stop test's all-reduce KERNEL costs beside a resident operator apply.  This
+// kernel has the launch shape of RCCL 2.27's ncclDevKernel_Generic on gfx950 as its code object declares it (one
+// workgroup of 256 threads, 248 VGPRs, 37 664 bytes of LDS, 696 bytes of scratch per lane: `llvm-readelf --notes` of the
+// gfx950 bundle of librccl.so.1.0.70200) and touches one word; the communicator then reports kind "rccl+proxy".
+__global__ void __launch_bounds__(256) k_rccl_shape_proxy(uint32_t* __restrict__ word) {
+  __shared__ uint32_t lds[37664 / 4];
+  asm volatile("v_mov_b32 v247, 0" ::: "v247");  // raises the kernel's VGPR count to RCCL's 248
+  lds[threadIdx.x] = threadIdx.x == 0 ? word[0] : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) word[0] = lds[0];
+}
+
 class RcclComm final : public Comm {
  public:
   RcclComm(const char id[128], int rank, int world) {
     rank_ = rank;
     world_ = world;
+    if (const char* e = getenv("OSC_RCCL_PROXY")) proxy_ = world == 1 && atoi(e) != 0;
     ncclUniqueId uid;
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
     std::memcpy(&uid, id, 128);
@@ -31,8 +46,12 @@ class RcclComm final : public Comm {
   ~RcclComm() override {
     if (comm_) (void)ncclCommDestroy(comm_);
   }
-  const char* kind() const override { return "rccl"; }
+  const char* kind() const override { return proxy_ ? "rccl+proxy" : "rccl"; }
   void allreduce(void* buf, size_t n, CommDType t, CommOp op, hipStream_t s) override {
+    if (proxy_ && n > 0) {
+      hipLaunchKernelGGL(k_rccl_shape_proxy, dim3(1), dim3(256), 0, s, static_cast<uint32_t*>(buf));
+      HIP_CHECK(hipGetLastError());
+    }
     const ncclDataType_t dt = t == COMM_F32 ? ncclFloat : t == COMM_F64 ? ncclDouble : ncclInt32;
     nccl_ok(ncclAllReduce(buf, buf, n, dt, op == COMM_SUM ? ncclSum : ncclMax, comm_, s), "ncclAllReduce");
   }
@@ -57,6 +76,7 @@ class RcclComm final : public Comm {
 
  private:
   ncclComm_t comm_ = nullptr;
+  bool proxy_ = false;
 };
 
 // ---- loopback -----------------------------------------------------------------------------------------------------
@@ -121,6 +141,9 @@ class LoopbackComm final : public Comm {
     }
     g_->barrier();
     HIP_CHECK(hipMemcpyAsync(buf, tmp_.p, n * esz, hipMemcpyDeviceToDevice, s));
+    // tmp_ is shared by every stream this rank runs collectives on (the solve's and the stop test's second stream): the
+    // copy out of it must have finished before another collective may refill it
+    HIP_CHECK(hipStreamSynchronize(s));
   }
   void allgather(void* buf, size_t chunk_bytes, hipStream_t s) override {
     enter(buf, nullptr, s);

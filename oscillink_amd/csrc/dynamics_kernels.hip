@@ -57,17 +57,22 @@ __global__ __launch_bounds__(256) void k_top_select(const float* v, const int32_
   for (int r = 0; r < K; ++r) {
     float bv = 0.f;
     int64_t bk = -1, bi = -1;
+    bool bk_known = false;  // the (API row, API column) key costs a division and two dependent gathers: only ties need it
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
       const float x = v[i];
-      if (!(x > 0.f)) continue;
-      const int64_t k = key_of(i);
-      if (!before(pv, pk, x, k)) continue;  // not after the previous pick
-      if (bi < 0 || before(x, k, bv, bk)) {
+      if (!(x > 0.f) || x > pv) continue;
+      if (x == pv && !(pk < key_of(i))) continue;  // not after the previous pick
+      if (bi < 0 || x > bv) {
         bv = x;
-        bk = k;
         bi = i;
+        bk_known = false;
+      } else if (x == bv) {
+        if (!bk_known) bk = key_of(bi), bk_known = true;
+        const int64_t k = key_of(i);
+        if (k < bk) bk = k, bi = i;
       }
     }
+    if (bi >= 0 && !bk_known) bk = key_of(bi);
     sv[threadIdx.x] = bv;
     sk[threadIdx.x] = bk;
     si[threadIdx.x] = bi;

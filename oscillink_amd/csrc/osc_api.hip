@@ -230,6 +230,7 @@ struct osc_lattice {
   size_t ctrl_seg = 0;   // words per segment
   int ctrl_next = 0;     // next free segment
   bool small_path = true;             // OSC_SMALL_PATH=0 disables the one-launch CG for small lattices
+  bool fake_window = false;  // OSC_FAKE_COL_SHARD under a one-rank communicator (measurement hook; reported by osc_comm_info)
   int predicted_iters[3] = {0, 0, 0};  // iterations the last general-path solve of each kind (CgBuffers::kind) took (0 = unknown)
   bool x_defer = true;                // the x update rides in the next iteration's p update (run_cg; OSC_X_DEFER=0: beside the r update)
   bool x_last_form = true;            // ... and the expected last iteration finishes x itself without storing r (OSC_X_DEFER=2: off)
@@ -3044,6 +3045,7 @@ int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world)
     l.comm.reset();
     l.rank = rank;
     l.world = world;
+    l.fake_window = false;
     std::tie(l.c0, l.c1) = host::column_shard(l.dcols, rank, world);  // slabs in units of 4 floats, as even as possible
     if (l.shard_mode == 1) {  // row-sharded CG: every rank works on all columns of its row block
       l.c0 = 0;
@@ -3052,7 +3054,10 @@ int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world)
     if (world == 1 && l.shard_mode == 0)  // measurement hook (osc_create): one rank's window of a wider solve, now WITH the
       if (const char* e = getenv("OSC_FAKE_COL_SHARD")) {  // communicator machinery of a sharded solve around it
         int r = 0, w = 1;
-        if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) std::tie(l.c0, l.c1) = host::column_shard(l.dcols, r, w);
+        if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) {
+          std::tie(l.c0, l.c1) = host::column_shard(l.dcols, r, w);
+          l.fake_window = w > 1;  // osc_comm_info then says so: this handle solves ONE window's columns only
+        }
       }
     if (l.c1 <= l.c0) throw Invalid("osc_comm_init: more ranks than 4-column groups");
     l.comm = comm_create(id, rank, world, l.device);
@@ -3089,7 +3094,8 @@ int osc_comm_info(osc_handle h, int32_t* rank, int32_t* world, int32_t* shard_mo
     if (rank) *rank = l.comm ? l.rank : 0;
     if (world) *world = l.comm ? l.world : 1;
     if (shard_mode) *shard_mode = l.shard_mode;
-    if (kind_out && cap > 0) snprintf(kind_out, (size_t)cap, "%s", l.comm ? l.comm->kind() : "none");
+    if (kind_out && cap > 0)
+      snprintf(kind_out, (size_t)cap, "%s%s", l.comm ? l.comm->kind() : "none", l.comm && l.fake_window ? "+fake-window" : "");
   });
 }
 

@@ -71,7 +71,14 @@ def compute_diffusion_gates(
         lat._call("osc_cg_single_rhs", float(gamma), nat.f32(s), cg_tol, cg_iters, nat.f32(h), C.byref(iters),
                   C.byref(res))
         if not np.all(np.isfinite(h)):
-            h = np.ones(N, dtype=np.float32)  # a solve that broke down numerically: the reference's uniform fallback
+            # a solve that broke down numerically: the reference's cg path hands back whatever cg_solve produced
+            # (diffusion.py:138-151; only exceptions become uniform gates), so the non-finite gates go to the caller --
+            # with a warning that names the breakdown instead of hiding it
+            import warnings
+
+            warnings.warn(f"compute_diffusion_gates: the screened-diffusion solve produced non-finite values "
+                          f"(iters={int(iters.value)}, res={float(res.value)!r}); returned as computed, like the reference's "
+                          "cg path", RuntimeWarning, stacklevel=2)
     finally:
         if own:
             lat.close()

@@ -275,9 +275,21 @@ class OscillinkLattice:
         # ("Injected graphs").
         if np.any(np.diagonal(A) != 0) or not np.array_equal(A, A.T):
             A = A.copy()
+            diag_nonzero = int(np.count_nonzero(np.diagonal(A)))
             np.fill_diagonal(A, 0.0)
             both = (A > 0) & (A.T > 0)
+            dropped = int(np.count_nonzero((A > 0) & ~both))       # one-directional edges: not in the repaired graph
+            drift = float(np.max(np.abs(A - A.T), where=both, initial=0.0))
             A = np.where(both, 0.5 * (A + A.T), 0.0).astype(np.float32)
+            # the repair is never silent: a state whose graph changed on the way in says so (logger event + warning)
+            info = {"diagonal_entries_dropped": diag_nonzero, "one_directional_edges_dropped": dropped,
+                    "max_abs_asymmetry_averaged": drift}
+            self._log("adjacency_repaired", info)
+            if dropped or diag_nonzero or drift > 1e-6:
+                import warnings
+
+                warnings.warn(f"Oscillink: injected adjacency was brought to the graph contract ({info}); the reference "
+                              "would have used it as given (lattice.py:709-713)", RuntimeWarning, stacklevel=2)
         r, c = np.nonzero(A > 0)
         rowptr = np.zeros(self.N + 1, dtype=np.int64)
         np.add.at(rowptr, r + 1, 1)

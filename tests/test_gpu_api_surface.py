@@ -419,3 +419,76 @@ def test_iteration_count_prediction_is_invisible(amd, monkeypatch):
         it, hist, U = fresh(tol, max_iters)
         assert st["iters"] == it and lat.residual_history() == hist
         assert np.array_equal(lat.U, U)
+
+
+def test_dense_adjacency_of_a_reference_state_loads_and_any_repair_is_reported(amd):
+    """`lat.A = A` (from_state, lattice.py:709-713).  The reference's own row-capped adjacency (fixture c1: the dense A
+    its state export carries) loads as the SAME graph -- no repair, no warning, the fixture's solves reproduced.  An
+    adjacency the device graph contract cannot take as given (float drift between A_ij and A_ji, a one-directional
+    edge, a diagonal entry) is repaired, and the repair is never silent: logger event `adjacency_repaired` with the
+    counts, plus a RuntimeWarning when an edge or a diagonal entry was dropped or the drift is beyond float noise."""
+    import warnings
+
+    from tests._cases import load_case, make_inputs
+
+    case = load_case("c1_n80_d128_k8")
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    N = rc["N"]
+    A = np.zeros((N, N), dtype=np.float32)
+    indptr, indices = case["indptr"], case["indices"]
+    for i in range(N):
+        A[i, indices[indptr[i]:indptr[i + 1]]] = case["A_data"][indptr[i]:indptr[i + 1]]
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
+    events = []
+    lat.set_logger(lambda ev, payload: events.append((ev, payload)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # the reference's own capped state: taken as given
+        lat.A = A
+    assert not [e for e in events if e[0] == "adjacency_repaired"]
+    assert np.allclose(lat.sqrt_deg, case["sqrt_deg"], rtol=2e-6)
+    lat.set_query(psi)
+    st = lat.settle(max_iters=rc.get("settle_max_iters", 6), tol=rc.get("settle_tol", 1e-3))
+    assert st["iters"] == int(case["settle_iters"])
+
+    # float drift only (what a row cap that promises approximate symmetry may leave): logged, averaged, no warning
+    B = A.copy()
+    i, j = np.argwhere(A > 0)[0]
+    B[i, j] *= np.float32(1.0 + 2e-7)
+    events.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        lat.A = B
+    (ev, info), = [e for e in events if e[0] == "adjacency_repaired"]
+    assert info["one_directional_edges_dropped"] == 0 and info["diagonal_entries_dropped"] == 0
+    assert 0 < info["max_abs_asymmetry_averaged"] < 1e-6
+    assert lat.A[i, j] == lat.A[j, i]
+
+    # a one-directional edge and a diagonal entry: dropped, counted, warned about
+    Cc = A.copy()
+    free = np.argwhere((A == 0) & (A.T == 0) & ~np.eye(N, dtype=bool))[0]
+    Cc[free[0], free[1]] = 0.25
+    Cc[3, 3] = 1.0
+    events.clear()
+    with pytest.warns(RuntimeWarning, match="graph contract"):
+        lat.A = Cc
+    (ev, info), = [e for e in events if e[0] == "adjacency_repaired"]
+    assert info["one_directional_edges_dropped"] == 1 and info["diagonal_entries_dropped"] == 1
+    assert lat.A[free[0], free[1]] == 0 and lat.A[3, 3] == 0
+    assert np.array_equal(lat.A > 0, A > 0)
+
+
+def test_diffusion_gates_that_broke_down_come_back_as_computed(amd):
+    """The reference's cg path returns whatever cg_solve produced (diffusion.py:138-151): a solve that went non-finite
+    yields non-finite gates, not uniform ones.  Here the anchors carry a NaN row, so the cosine sources are NaN."""
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal((64, 12)).astype(np.float32)
+    psi = Y[0].copy()
+    lat = amd.Oscillink(Y, kneighbors=5)
+    bad = psi.copy()
+    bad[2] = np.nan
+    with pytest.warns(RuntimeWarning, match="non-finite"):
+        h = amd.compute_diffusion_gates(Y, bad, kneighbors=5, method="cg", lattice=lat)
+    assert h.shape == (64,) and not np.isfinite(h).all()
+    h_ok = amd.compute_diffusion_gates(Y, psi, kneighbors=5, method="cg", lattice=lat)
+    assert np.isfinite(h_ok).all() and 0.0 <= h_ok.min() and h_ok.max() <= 1.0
