@@ -60,6 +60,24 @@ constexpr unsigned STAGE_BYTES = 16384;  // one K step of a column tile: 128 row
 constexpr int HB_CAP = 1792;  // entries of 8 bytes per wave: 4 x 14 KB behind the ring
 constexpr size_t PANEL_LDS = (size_t)RING * STAGE_BYTES + 2048;
 constexpr size_t PANEL_LDS_HITS = PANEL_LDS + (size_t)4 * HB_CAP * 8;
+// Symmetric half sweep (SYM, single-process builds): S = Yh Yh^T is symmetric bit for bit (every product a_ik b_jk is
+// formed once per pair and the MFMA sums k in the same order whichever operand a row arrives as), so row block I only
+// visits column tiles J >= I and tests every accumulator against BOTH thresholds -- tau of its row (the entry is a
+// candidate of row i: "row side") and tau of its column (a candidate of row j: "column side", J > I only).  That halves
+// the MFMA, LDS-fragment and LDS-DMA work of the sweep for about twice the hit test per visited tile.  The column
+// thresholds of an item's tiles wait in LDS (the per-lane tau[column] would otherwise be a vector load per tile on the
+// vmcnt queue the DMA ring is counted on): the same 56 KB behind the ring hold TC_TILES x 512 B of thresholds and four
+// hit lists of HB_CAP_SYM entries.  An entry carries two flags (bit 26: row side, bit 25: column side).  At the end of
+// an item a wave delivers its entries to global BUCKETS, one per group of 32 receiving rows (= one (row block, wave) of
+// the select): the row-side ones to its own bucket behind one reservation, the column-side ones to the buckets of
+// their columns -- counted per bucket in LDS first (the item's tiles span at most 4 TC_TILES buckets), one returning
+// atomic per touched bucket, 64 buckets per wave instruction.  (A first version sent the column-side hits through one
+// global pool and counting-sorted it afterwards: 9.6 M same-address atomics made those two passes cost 2.7 ms at
+// config 3 -- more than the sweep saved at N = 20 000.)
+constexpr int TC_TILES = 44;
+constexpr int HB_CAP_SYM = 1056;
+static_assert((size_t)4 * HB_CAP_SYM * 8 + (size_t)TC_TILES * 512 <= (size_t)4 * HB_CAP * 8, "SYM layout must fit the hit area");
+constexpr unsigned ROW_SIDE = 1u << 26, COL_SIDE = 1u << 25, COL_MASK = (1u << 25) - 1u;
 
 struct PanelArgs {
   const _Float16* A;   // query image, npad rows
@@ -71,8 +89,14 @@ struct PanelArgs {
   const float* tau;    // MODE 1: [npad]
   uint2* hit_list;     // MODE 1: [(list * 4 + wave) * hit_cap + e] = {local row << 27 | column, score bits}; list = split * rb_count + (row block - rb_begin)
   int32_t* hit_cnt;    // MODE 1: [list * 4 + wave] hits of that wave in that list (may exceed hit_cap: overflow)
-  int32_t hit_cap;     // entries per list: HB_CAP / row groups per wave
+  int32_t hit_cap;     // entries per list: HB_CAP (SYM: HB_CAP_SYM) / row groups per wave
   unsigned* queue;
+  // SYM: column chunks of T tiles, walked from the last to the first; chunk c is swept by the row blocks I < min(nrb, (c + 1) T)
+  int32_t T, nchunks;
+  uint2* bucket_ent;     // [npad / 32][bucket_cap] entries {local row << 27 | ROW_SIDE | candidate, score bits} per group of 32 receiving rows
+  int32_t* bucket_cnt;   // [npad / 32] entries delivered (may exceed bucket_cap: overflow); zeroed by the caller
+  int32_t bucket_cap;
+  int32_t* flags;        // [c]: an LDS list of chunk c overflowed (hits of its tiles' rows were lost); zeroed by the caller
 };
 
 // LDS-DMA of one 1 KiB piece: M0 = LDS destination - K offset, the K offset rides in the immediate
@@ -86,14 +110,15 @@ struct PanelArgs {
                  : "memory");                                                                                        \
   } while (0)
 
-template <int NKT, int MODE, int NRG>
+template <int NKT, int MODE, int NRG, bool SYM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_panel(const PanelArgs a) {
   static_assert(NKT % RING == 0, "a tile's K steps must be whole laps of the ring (compile-time stage indices)");
   static_assert(NRG == 1 || NRG == 2, "row groups per wave");
+  static_assert(!SYM || MODE == 1, "the half sweep is a form of the main sweep");
   constexpr int NK16 = NKT * 4;
-  constexpr int HCAP = HB_CAP / NRG;  // entries of one (row group, wave) hit list
+  constexpr int HCAP = (SYM ? HB_CAP_SYM : HB_CAP) / NRG;  // entries of one (row group, wave) hit list
   extern __shared__ __attribute__((aligned(1024))) float lds[];  // RING stages x [128 rows][32 float slots] (+2 KB lead)
-  __shared__ int s_item;
+  __shared__ int s_item, s_chunk, s_first;
   __shared__ __attribute__((aligned(16))) float s_tau[4][NRG][2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -106,18 +131,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int s = 0; s < 4; ++s) rd[s] = (unsigned)(l31 * 128 + (((2 * s + h) ^ swz) * 16));
   const char* ldsc = reinterpret_cast<const char*>(lds) + 2048;
   const int nsets = (a.rb_count + NRG - 1) / NRG;  // work item = (column split, set of NRG consecutive row blocks)
-  const int nitems = nsets * a.S;
+  // SYM: chunk c (T tiles) is swept by the row blocks I < min(nrb, (c + 1) T), i.e. by all nrb of them in the last chunk
+  // and by (c + 1) T in the others, so the item and list tables have closed forms (host copies: knn_panel_sym_tables):
+  // lists before chunk c: T c (c + 1) / 2; the queue walks the chunks from the last to the first
+  auto chunk_sets = [&](int c) { return (min(a.ntileB, (c + 1) * a.T) + NRG - 1) / NRG; };
+  int nitems = nsets * a.S;
+  if constexpr (SYM) {
+    nitems = 0;
+    for (int c = 0; c < a.nchunks; ++c) nitems += chunk_sets(c);
+  }
   const size_t ldh = (size_t)a.ldh;
   const size_t tile_stride = (size_t)128 * ldh;  // halfs between column tiles
+  float* const s_tc = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + PANEL_LDS + (size_t)4 * HB_CAP_SYM * 8);  // SYM: [tile of the item][lane 0..31][subtile 0..3]
   for (;;) {
-    if (tid == 0) s_item = (int)atomicAdd(a.queue, 1u);
+    if (tid == 0) {
+      const int it = (int)atomicAdd(a.queue, 1u);
+      s_item = it;
+      if constexpr (SYM) {  // chunks are queued from the last (every row block sweeps it) to the first (T row blocks): the
+        int c = a.nchunks - 1, first = 0;  // short diagonal items come last and fill the tail of the persistent grid
+        if (it < nitems)
+          while (it >= first + chunk_sets(c)) first += chunk_sets(c), --c;
+        s_chunk = c;
+        s_first = first;
+      }
+    }
     __syncthreads();
     const int item = s_item;
+    const int chunk = SYM ? s_chunk : 0;
+    const int first_item = SYM ? s_first : 0;
     __syncthreads();
     if (item >= nitems) break;
-    // items of one split are consecutive: the workgroups that start together sweep the same column tiles together
-    const int split = item / nsets, rbi0 = (item - split * nsets) * NRG;  // first row block of the set, relative to rb_begin
-    const int t0 = split * a.tiles_per_split, t1 = min(a.ntileB, t0 + a.tiles_per_split);
+    // items of one split (chunk) are consecutive: the workgroups that start together sweep the same column tiles together
+    int split, rbi0, t0, t1;
+    if constexpr (SYM) {
+      split = chunk;
+      rbi0 = (item - first_item) * NRG;
+      t1 = min(a.ntileB, (chunk + 1) * a.T);
+      t0 = max(chunk * a.T, rbi0);  // row group 0's diagonal tile or the chunk's first tile
+    } else {
+      split = item / nsets;
+      rbi0 = (item - split * nsets) * NRG;  // first row block of the set, relative to rb_begin
+      t0 = split * a.tiles_per_split;
+      t1 = min(a.ntileB, t0 + a.tiles_per_split);
+    }
     int rbv[NRG];     // row block of row group r (the last set of an odd count repeats its first block: computed, not kept)
     bool rok[NRG];
 #pragma unroll
@@ -125,13 +181,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       rok[r] = rbi0 + r < a.rb_count;
       rbv[r] = a.rb_begin + (rok[r] ? rbi0 + r : rbi0);
     }
+    // list of (this item's split / chunk, row block rbi0 + r): SYM packs the chunks' lists (chunk c has min(nrb, (c + 1) T) of them)
+    auto list_of = [&](int r) -> size_t {
+      return SYM ? (size_t)a.T * chunk * (chunk + 1) / 2 + rbi0 + r : (size_t)split * a.rb_count + rbi0 + r;
+    };
     if (t0 >= t1) {  // an empty column split (the planner never makes one; OSC_KNN_MODE=panel can): no hits, but say so
       if (MODE == 1 && lane == 0) {
 #pragma unroll
         for (int r = 0; r < NRG; ++r)
-          if (rok[r]) a.hit_cnt[((size_t)split * a.rb_count + rbi0 + r) * 4 + wave] = 0;
+          if (rok[r]) a.hit_cnt[list_of(r) * 4 + wave] = 0;
       }
       continue;
+    }
+    if constexpr (SYM) {  // the column thresholds of the item's tiles -> LDS, [tile][lane][subtile]; +inf beyond N: no receiver
+      const int nq = (t1 - t0) * 32;  // quads of consecutive columns (tau has npad entries: whole quads)
+      constexpr int QPT = (TC_TILES * 32 + 255) / 256;
+      v4f tq[QPT];
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {  // all loads first, then the LDS stores
+        const int q = tid + 256 * j;
+        tq[j] = q < nq ? *reinterpret_cast<const v4f*>(a.tau + (size_t)t0 * 128 + 4 * q) : v4f{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        const int q = tid + 256 * j;
+        if (q < nq) {
+          const int e = 4 * q, tl = e >> 7, sub = (e >> 5) & 3, l5 = e & 31;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) s_tc[tl * 128 + (l5 + u) * 4 + sub] = (t0 * 128 + e + u) < a.N ? tq[j][u] : 3.0e38f;
+        }
+      }
     }
     half8 areg[NRG][NK16];
 #pragma unroll
@@ -150,7 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int r = 0; r < NRG; ++r) {
       wcnt[r] = 0;
-      hitbuf[r] = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds) + PANEL_LDS) + (wave * NRG + r) * HCAP;
+      hitbuf[r] = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds) + PANEL_LDS) + (wave * NRG + r) * HCAP;  // (SYM: the shorter lists leave the tail of the area to s_tc)
       const int grow0 = rbv[r] * 128 + 32 * wave + 4 * h;
       if constexpr (MODE == 0) {
 #pragma unroll
@@ -179,21 +258,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // instruction issue (32 MFMAs, 32 fragment reads, 8 DMA pieces of ~5 instructions per pair), not by the matrix pipe,
     // so VALU work placed there is not hidden.
     f32x16 acc[NRG][4];
-    auto row_mask = [&](auto GC, const f32x16(&pa)[4], const float(&tg)[16]) -> unsigned long long {
+    // tc[t]: SYM, the threshold of this lane's column of subtile t (+inf where the column side does not apply: the
+    // diagonal tile, whose pairs are all met on the row side, and columns beyond N)
+    auto row_mask = [&](auto GC, const f32x16(&pa)[4], const float(&tg)[16], const float(&tc)[4]) -> unsigned long long {
       constexpr int g = decltype(GC)::value;
-      return __ballot(fmaxf(fmaxf(pa[0][g], pa[1][g]), fmaxf(pa[2][g], pa[3][g])) > tg[g]);
+      bool any = fmaxf(fmaxf(pa[0][g], pa[1][g]), fmaxf(pa[2][g], pa[3][g])) > tg[g];
+      if constexpr (SYM)  // (bitwise or: both sides are plain compares, no lane-divergent branch wanted here)
+        any = any | (fmaxf(fmaxf(pa[0][g] - tc[0], pa[1][g] - tc[1]), fmaxf(pa[2][g] - tc[2], pa[3][g] - tc[3])) > 0.f);
+      return __ballot(any);
     };
-    auto hit_rows = [&](auto GC, const f32x16(&pa)[4], const float(&tg)[16], int pct, int rb, uint2* hb, int& wc) {  // query-row register g of the tile pct has a hit
+    auto hit_rows = [&](auto GC, const f32x16(&pa)[4], const float(&tg)[16], const float(&tc)[4], int pct, int rb, uint2* hb, int& wc) {  // query-row register g of the tile pct has a hit
       constexpr int g = decltype(GC)::value;
       const int rl = (g & 3) + 8 * (g >> 2) + 4 * h;  // local row of the wave's 32
       const int grow = rb * 128 + 32 * wave + rl;
       const int cbase = pct * 128 + l31;
       const bool special = pct == rb || (pct + 1) * 128 > a.N;  // the tile holds the diagonal or the ragged tail
       unsigned long long mk[4];
+      unsigned side[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         bool pred = pa[t][g] > tg[g];
         if (special) pred = pred && (cbase + 32 * t) != grow && (cbase + 32 * t) < a.N;  // graph.py:37: no self-similarity
+        side[t] = pred ? ROW_SIDE : 0u;
+        if constexpr (SYM) {
+          const bool cp = pa[t][g] > tc[t];
+          side[t] |= cp ? COL_SIDE : 0u;
+          pred = pred | cp;
+        }
         mk[t] = __ballot(pred);
       }
 #pragma unroll
@@ -202,15 +293,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool pred = (mk[t] >> lane) & 1ull;
         const int pos = wc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[t] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[t], 0u));
         if (pred && pos < HCAP)
-          hb[pos] = make_uint2(((unsigned)rl << 27) | (unsigned)(cbase + 32 * t), __float_as_uint(pa[t][g]));
+          hb[pos] = make_uint2(((unsigned)rl << 27) | side[t] | (unsigned)(cbase + 32 * t), __float_as_uint(pa[t][g]));
         wc += __popcll(mk[t]);
       }
     };
-    auto hit_test_tile = [&](const f32x16(&pa)[4], const float(&tg)[16], int pct, int rb, uint2* hb, int& wc) {  // all 16 registers, compares batched ahead of the branches
+    auto hit_test_tile = [&](const f32x16(&pa)[4], const float(&tg)[16], const float(&tc)[4], int pct, int rb, uint2* hb, int& wc) {  // all 16 registers, compares batched ahead of the branches
       unsigned long long fm[16];
-      static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, pa, tg); });
+      static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, pa, tg, tc); });
       static_for<0, 16>([&](auto GC) {
-        if (fm[decltype(GC)::value] != 0ull) hit_rows(GC, pa, tg, pct, rb, hb, wc);
+        if (fm[decltype(GC)::value] != 0ull) hit_rows(GC, pa, tg, tc, pct, rb, hb, wc);
       });
     };
     auto k_loop = [&](int ct) {
@@ -282,13 +373,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int r = 0; r < NRG; ++r) {
           if (!rok[r]) continue;
+          if (SYM && ct < rbv[r]) continue;  // (second row group of a set: the tile below its diagonal belongs to the first)
           float tg[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][r][h][4 * q]);
             tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
           }
-          hit_test_tile(acc[r], tg, ct, rbv[r], hitbuf[r], wcnt[r]);
+          float tc[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+          if constexpr (SYM) {
+            if (ct > rbv[r]) {
+              const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(ct - t0) * 128 + l31 * 4]);
+              tc[0] = c4[0], tc[1] = c4[1], tc[2] = c4[2], tc[3] = c4[3];
+            }
+          }
+          hit_test_tile(acc[r], tg, tc, ct, rbv[r], hitbuf[r], wcnt[r]);
         }
       }
     } else {
@@ -316,15 +415,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
     }
-    if constexpr (MODE == 1) {  // flush the wave's hit lists (coalesced 8-byte stores) and their counts
+    if constexpr (MODE == 1 && !SYM) {  // flush the wave's hit lists (coalesced 8-byte stores) and their counts
 #pragma unroll
       for (int r = 0; r < NRG; ++r) {
         if (!rok[r]) continue;
-        const size_t li = ((size_t)split * a.rb_count + rbi0 + r) * 4 + wave;
+        const size_t li = list_of(r) * 4 + wave;
         const int n = min(wcnt[r], HCAP);
         uint2* out = a.hit_list + li * (size_t)a.hit_cap;
         for (int e = lane; e < n; e += 64) out[e] = hitbuf[r][e];
         if (lane == 0) a.hit_cnt[li] = wcnt[r];
+      }
+    }
+    if constexpr (SYM) {  // deliver the wave's entries to the buckets of their receiving rows
+      __syncthreads();    // every wave has finished its last tile: the threshold window becomes the waves' bucket counters
+      const int nbl = (t1 - t0) * 4;  // buckets the item's column tiles span: (t0 * 4 + b), b < nbl <= 4 TC_TILES
+      int* const s_cnt = reinterpret_cast<int*>(s_tc) + wave * (8 * TC_TILES);  // [2][4 TC_TILES]: counts / cursors, bases
+      int* const s_base = s_cnt + 4 * TC_TILES;
+#pragma unroll
+      for (int r = 0; r < NRG; ++r) {
+        if (!rok[r]) continue;
+        const int n = min(wcnt[r], HCAP);
+        const int own = rbv[r] * 4 + wave;  // bucket of this wave's 32 rows
+        if (wcnt[r] > HCAP && lane == 0) {  // dropped hits: row-side ones of these rows, column-side ones of any row of the chunk
+          a.flags[chunk] = 1;
+          atomicAdd(&a.bucket_cnt[own], a.bucket_cap + 1);
+        }
+        for (int b = lane; b < nbl; b += 64) s_cnt[b] = 0;
+        int nrow = 0;
+        for (int e0 = 0; e0 < n; e0 += 64) {  // (a wave's LDS accesses complete in order: no barrier between these passes)
+          const int e = e0 + lane;
+          const unsigned x = e < n ? hitbuf[r][e].x : 0u;
+          if (x & COL_SIDE) atomicAdd(&s_cnt[(int)((x & COL_MASK) >> 5) - t0 * 4], 1);
+          nrow += __popcll(__ballot((x & ROW_SIDE) != 0u));
+        }
+        int rbase = 0;
+        if (lane == 0 && nrow > 0) rbase = atomicAdd(&a.bucket_cnt[own], nrow);
+        for (int b = lane; b < nbl; b += 64) {
+          const int c = s_cnt[b];
+          s_base[b] = c > 0 ? atomicAdd(&a.bucket_cnt[t0 * 4 + b], c) : 0;
+          s_cnt[b] = 0;
+        }
+        rbase = __builtin_amdgcn_readfirstlane(rbase);
+        const unsigned irow0 = (unsigned)(rbv[r] * 128 + 32 * wave);
+        for (int e0 = 0; e0 < n; e0 += 64) {
+          const int e = e0 + lane;
+          const uint2 v = e < n ? hitbuf[r][e] : make_uint2(0u, 0u);
+          const bool rs = (v.x & ROW_SIDE) != 0u, cs = (v.x & COL_SIDE) != 0u;
+          const unsigned long long m = __ballot(rs);
+          const int rpos = rbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (rs && rpos < a.bucket_cap)
+            a.bucket_ent[(size_t)own * a.bucket_cap + rpos] = make_uint2((v.x & ~COL_SIDE), v.y);
+          rbase += __popcll(m);
+          if (cs) {
+            const unsigned col = v.x & COL_MASK;
+            const int b = (int)(col >> 5) - t0 * 4;
+            const int cpos = s_base[b] + atomicAdd(&s_cnt[b], 1);
+            if (cpos < a.bucket_cap)
+              a.bucket_ent[(size_t)(col >> 5) * a.bucket_cap + cpos] = make_uint2(((col & 31u) << 27) | ROW_SIDE | (irow0 + (v.x >> 27)), v.y);
+          }
+        }
       }
     }
     __syncthreads();  // every wave is done with the ring before the next item refills it
@@ -399,10 +548,18 @@ __device__ __forceinline__ unsigned order_key(unsigned bits) {  // ascending flo
 // sorted: the re-scoring ranks by exact score.
 constexpr int SEL_CAP = 1024;    // candidates of one row the select can hold (expected: ~5 keep)
 constexpr int SORT_CAP = 2560;   // entries one workgroup sorts (20 KB of LDS: several workgroups per CU)
+// Half-sweep builds (sym): every candidate of the 32 rows of (row block, wave) sits in ONE bucket (k_panel's flush).
+struct SelectSym {
+  int32_t on, T;
+  const uint2* bucket_ent;
+  const int32_t* bucket_cnt;
+  int32_t bucket_cap;
+  const int32_t* flags;
+};
 __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, const int32_t* hit_cnt, int32_t hit_cap, int32_t S,
                                                       int32_t rb_begin, int32_t rb_count, int32_t nsub, int32_t keep,
                                                       int32_t N, int32_t scatter, float* cval, int32_t* cidx, int32_t* fail_rows,
-                                                      int32_t* fail_count) {
+                                                      int32_t* fail_count, const SelectSym sy) {
   __shared__ uint2 sorted[SORT_CAP];
   __shared__ int hist[32], start[33], cursor[32], s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -410,18 +567,32 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
   const int rows_here = 32 / nsub, rl0 = sub * rows_here;  // local rows [rl0, rl0 + rows_here) of the wave's 32
   const int row_base = (rb_begin + rbi) * 128 + 32 * w;
   if (tid < 32) hist[tid] = 0;
-  if (tid == 0) s_bad = 0;
+  if (tid == 0) s_bad = sy.on && sy.flags[rbi / sy.T] != 0;  // lost column-side hits of this row block's rows
   __syncthreads();
+  // the segments that hold this (row block, wave)'s entries: (list, entries, raw count)
+  const int seg0 = 0;
+  const int nseg = sy.on ? 1 : S;
+  auto segment = [&](int sg, int& n, int& raw) -> const uint2* {
+    if (sy.on) {
+      const int b = rbi * 4 + w;
+      raw = sy.bucket_cnt[b];
+      n = min(raw, sy.bucket_cap);
+      return sy.bucket_ent + (size_t)b * sy.bucket_cap;
+    }
+    const size_t li = ((size_t)sg * rb_count + rbi) * 4 + w;
+    raw = hit_cnt[li];
+    n = min(raw, hit_cap);
+    return hit_list + li * (size_t)hit_cap;
+  };
   // pass 1: entries per row
-  for (int s = 0; s < S; ++s) {
-    const size_t li = ((size_t)s * rb_count + rbi) * 4 + w;
-    const int c = hit_cnt[li];
-    if (c > hit_cap && tid == 0) s_bad = 1;  // the list overflowed: hits were dropped
-    const int n = min(c, hit_cap);
-    const uint2* list = hit_list + li * (size_t)hit_cap;
+  for (int s = seg0; s < nseg; ++s) {
+    int n, c;
+    const uint2* list = segment(s, n, c);
+    if (c > n && tid == 0) s_bad = 1;  // the list overflowed: hits were dropped
     for (int e = tid; e < n; e += 256) {
-      const int rl = (int)(list[e].x >> 27);
-      if (rl >= rl0 && rl < rl0 + rows_here) atomicAdd(&hist[rl], 1);
+      const unsigned x = list[e].x;
+      const int rl = (int)(x >> 27);
+      if ((x & ROW_SIDE) && rl >= rl0 && rl < rl0 + rows_here) atomicAdd(&hist[rl], 1);
     }
   }
   __syncthreads();
@@ -439,14 +610,14 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
   const bool bad = s_bad != 0;
   // pass 2: scatter into row order
   if (!bad) {
-    for (int s = 0; s < S; ++s) {
-      const size_t li = ((size_t)s * rb_count + rbi) * 4 + w;
-      const int n = min(hit_cnt[li], hit_cap);
-      const uint2* list = hit_list + li * (size_t)hit_cap;
+    for (int s = seg0; s < nseg; ++s) {
+      int n, c;
+      const uint2* list = segment(s, n, c);
       for (int e = tid; e < n; e += 256) {
         const uint2 v = list[e];
         const int rl = (int)(v.x >> 27);
-        if (rl >= rl0 && rl < rl0 + rows_here) sorted[atomicAdd(&cursor[rl], 1)] = make_uint2(v.x & 0x07FFFFFFu, v.y);
+        if ((v.x & ROW_SIDE) && rl >= rl0 && rl < rl0 + rows_here)
+          sorted[atomicAdd(&cursor[rl], 1)] = make_uint2(v.x & COL_MASK, v.y);
       }
     }
   }
@@ -516,17 +687,27 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
 }
 
 template <int MODE>
-void launch_panel(const PanelArgs& a, int nkt, int nrg, int grid, hipStream_t s) {
-#define OSC_PANEL(NKT, NRG)                                                                                         \
+void launch_panel(const PanelArgs& a, int nkt, int nrg, bool sym, int grid, hipStream_t s) {
+#define OSC_PANEL(NKT, NRG, SYM)                                                                                    \
   do {                                                                                                              \
     constexpr size_t lds_bytes = MODE == 1 ? PANEL_LDS_HITS : PANEL_LDS;                                            \
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NKT, MODE, NRG>),                         \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NKT, MODE, NRG, SYM>),                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                     \
-    hipLaunchKernelGGL((k_panel<NKT, MODE, NRG>), dim3(grid), dim3(256), lds_bytes, s, a);                         \
+    hipLaunchKernelGGL((k_panel<NKT, MODE, NRG, SYM>), dim3(grid), dim3(256), lds_bytes, s, a);                    \
   } while (0)
-  if (nkt == 6 && nrg == 2) OSC_PANEL(6, 2);
-  else if (nkt == 6 && nrg == 1) OSC_PANEL(6, 1);
-  else if (nkt == 12 && nrg == 1) OSC_PANEL(12, 1);
+  if constexpr (MODE == 1) {
+    if (sym) {
+      if (nkt == 6 && nrg == 2) OSC_PANEL(6, 2, true);
+      else if (nkt == 6 && nrg == 1) OSC_PANEL(6, 1, true);
+      else if (nkt == 12 && nrg == 1) OSC_PANEL(12, 1, true);
+      else throw std::runtime_error("launch_panel: unsupported K depth / row groups");
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
+  if (nkt == 6 && nrg == 2) OSC_PANEL(6, 2, false);
+  else if (nkt == 6 && nrg == 1) OSC_PANEL(6, 1, false);
+  else if (nkt == 12 && nrg == 1) OSC_PANEL(12, 1, false);
   else throw std::runtime_error("launch_panel: unsupported K depth / row groups");
 #undef OSC_PANEL
   HIP_CHECK(hipGetLastError());
@@ -536,8 +717,9 @@ void launch_panel(const PanelArgs& a, int nkt, int nrg, int grid, hipStream_t s)
 
 int knn_panel_nkt(int32_t D) { return D <= 384 ? 6 : D <= 768 ? 12 : 0; }
 
-KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows) {
+KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows, bool sym) {
   KnnPanelPlan p{};
+  p.sym = sym;
   p.scatter = 1;
   if (scatter_rows && N > 2) {  // ~ N / golden ratio, made coprime to N: consecutive image rows are far-apart lattice rows
     auto gcd = [](int64_t a, int64_t b) {
@@ -598,6 +780,23 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
     }
   }
   p.tiles_per_split = (p.nrb + p.S - 1) / p.S;
+  if (sym) {
+    // half sweep: column chunks of T tiles; a (wave, item) list takes the row-side AND the column-side hits of its tiles,
+    // 2 x 32 rows x bound / nrb per tile, and should stay within ~2/3 of its LDS list; the item's column thresholds must
+    // fit their LDS window (TC_TILES); T even where a set holds two row blocks (both then meet their diagonal in one chunk)
+    p.hit_cap = HB_CAP_SYM / p.nrg;
+    const double bound = std::max(5.0 * keep, 20.0 * rho);
+    int T = (int)std::floor(0.66 * p.hit_cap * p.nrb / (64.0 * bound));
+    T = std::max(2, std::min(TC_TILES, T));
+    if (const char* e = getenv("OSC_KNN_PANEL_T")) T = std::max(2, std::min(TC_TILES, atoi(e)));  // (A/B: tiles per chunk)
+    if (p.nrg == 2) T &= ~1;
+    p.T = T;
+    p.S = (p.nrb + T - 1) / T;  // chunks
+    p.tiles_per_split = T;
+    p.bucket_cap = (int32_t)(32.0 * bound);  // a group of 32 rows may receive all its candidates here (the last rows: all column-side)
+    p.nitems = 0;
+    for (int c = 0; c < p.S; ++c) p.nitems += (std::min(p.nrb, (c + 1) * T) + p.nrg - 1) / p.nrg;
+  }
   // phase A: splits of whole tile groups, again for the tail of the persistent grid
   best = 1e30;
   p.SA = 1;
@@ -646,7 +845,7 @@ void launch_panel_tilemax(const void* Yh, const void* Ys, const KnnPanelPlan& p,
   a.tmax = tmax;
   a.queue = queue;
   HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
-  launch_panel<0>(a, p.nkt, p.nrg, grid, s);
+  launch_panel<0>(a, p.nkt, p.nrg, false, grid, s);
 }
 
 void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float* tau, hipStream_t s) {
@@ -657,9 +856,18 @@ void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float
 }
 
 void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count, const float* tau,
-                         void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s) {
+                         void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s, const KnnPanelSymDev* sd) {
   if (rb_count <= 0) return;
   PanelArgs a{};
+  if (p.sym) {
+    if (!sd || rb_begin != 0 || rb_count != p.nrb) throw std::runtime_error("launch_panel_filter: the half sweep covers all row blocks");
+    a.T = p.T;
+    a.nchunks = p.S;
+    a.bucket_ent = static_cast<uint2*>(sd->bucket_ent);
+    a.bucket_cnt = sd->bucket_cnt;
+    a.bucket_cap = p.bucket_cap;
+    a.flags = sd->flags;
+  }
   a.A = static_cast<const _Float16*>(Yh);
   a.B = a.A;
   a.ldh = p.ldh;
@@ -675,19 +883,28 @@ void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int r
   a.hit_cap = p.hit_cap;
   a.queue = queue;
   HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
-  launch_panel<1>(a, p.nkt, p.nrg, grid, s);
+  launch_panel<1>(a, p.nkt, p.nrg, p.sym, grid, s);
 }
 
 void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int32_t N, const void* hit_list,
                          const int32_t* hit_cnt, float* cval, int32_t* cidx, int32_t* fail_rows, int32_t* fail_count,
-                         hipStream_t s) {
+                         hipStream_t s, const KnnPanelSymDev* sd) {
   if (rb_count <= 0) return;
+  SelectSym sy{};
+  if (p.sym) {
+    sy.on = 1;
+    sy.T = p.T;
+    sy.bucket_ent = static_cast<const uint2*>(sd->bucket_ent);
+    sy.bucket_cnt = sd->bucket_cnt;
+    sy.bucket_cap = p.bucket_cap;
+    sy.flags = sd->flags;
+  }
   // rows of one wave-of-32 a workgroup sorts: as many as keeps ~5 keep entries per row within 3/4 of its LDS array
   int nsub = 1;
   while (nsub < 8 && 5.0 * p.keep * (32 / nsub) > 0.75 * SORT_CAP) nsub *= 2;
   hipLaunchKernelGGL(k_panel_select, dim3((unsigned)(rb_count * 4 * nsub)), dim3(256), 0, s,
                      static_cast<const uint2*>(hit_list), hit_cnt, p.hit_cap, p.S, rb_begin, rb_count, nsub, p.keep, N, p.scatter, cval, cidx,
-                     fail_rows, fail_count);
+                     fail_rows, fail_count, sy);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -1,5 +1,7 @@
 // Prefilter route "panel": fp16 similarity GEMM with the query panel register-resident (knn_gemm.hip).
 #pragma once
+#include <vector>
+
 #include "common.hpp"
 
 namespace osc {
@@ -24,6 +26,15 @@ struct KnnPanelPlan {
   int32_t sample_tiles_per_split;
   int32_t hit_cap;     // entries of one hit list (one per work item and wave)
   int32_t keep;        // candidates handed to the exact re-scoring
+  // Half sweep (single-process builds): the similarity matrix is symmetric bit for bit, so row block I visits only the
+  // column tiles J >= I and every accumulator is tested against its row's AND its column's threshold.  The sweep is cut
+  // into S column CHUNKS of T tiles (S, tiles_per_split = T above); chunk c is swept by the row blocks I < min(nrb,
+  // (c + 1) T): nitems work items in all.  All hits are delivered to buckets of bucket_cap entries, one per group of 32
+  // receiving rows (npad / 32 of them), which is all the select reads.
+  bool sym;
+  int32_t T;
+  int32_t nitems;
+  int32_t bucket_cap;
   // Row scatter of the fp16 images: image row r (r < N) holds lattice row (r * scatter) mod N -- a bijection (scatter is
   // coprime to N; 1 = identity).  Anchors often arrive grouped (documents, clusters): then the 32 rows of a wave all
   // have their ~cluster-size best columns in the same one or two column tiles, one (work item, wave) hit list takes
@@ -38,7 +49,13 @@ struct KnnPanelPlan {
 inline int32_t knn_panel_row(const KnnPanelPlan& p, int32_t N, int32_t r) {
   return r < N ? (int32_t)(((int64_t)r * p.scatter) % N) : r;
 }
-KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows = false);
+KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows = false, bool sym = false);
+// half sweep: the device arrays the sweep and the select share
+struct KnnPanelSymDev {
+  void* bucket_ent;      // uint2 [npad / 32][bucket_cap]
+  int32_t* bucket_cnt;   // [npad / 32], zeroed by the caller
+  int32_t* flags;        // [S], zeroed by the caller
+};
 
 // fp32 unit rows -> fp16 image of 16 * Yn with pitch plan.ldh, rows [N, npad) zero
 void launch_panel_image(const float* Yn, int32_t ldn, void* Yh, const KnnPanelPlan& p, int32_t N, int32_t D, hipStream_t s);
@@ -54,12 +71,13 @@ void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float
 // (column split, row block, wave): hit_list [(list * 4 + wave) * hit_cap + e] = 8-byte entries {local row << 27 | column,
 // score bits}, hit_cnt [list * 4 + wave] (may exceed hit_cap: overflow); list = split * rb_count + (row block - rb_begin)
 void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count, const float* tau,
-                         void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s);
+                         void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s,
+                         const KnnPanelSymDev* sd = nullptr);
 // per row: `keep` candidates holding the keep best fp16 scores (unsorted, the minimum in the last slot) -> cval / cidx
 // [N][keep]; rows whose candidate set is incomplete (a list overflowed) or too small (< keep) are appended to fail_rows
 // and get an empty list
 void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int32_t N, const void* hit_list,
                          const int32_t* hit_cnt, float* cval, int32_t* cidx, int32_t* fail_rows, int32_t* fail_count,
-                         hipStream_t s);
+                         hipStream_t s, const KnnPanelSymDev* sd = nullptr);
 
 }  // namespace osc

@@ -7,6 +7,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/oscillink_hip.h"
@@ -401,20 +402,117 @@ void upload_rows(L& h, float* dst, const float* src) {  // N x D host -> N x ld 
   HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)h.ld * 4, src, (size_t)h.D * 4, (size_t)h.D * 4, (size_t)h.N,
                              hipMemcpyHostToDevice, h.stream));
 }
+// ---- large device -> host transfers: pinned staging, chunked, the DMA of chunk c + 1 beside the host copy of chunk c ----
+// A device-to-host copy into PAGEABLE memory (what a caller's NumPy array is) runs at 6-10 GB/s through the runtime's own
+// staging: reading the 307 MB state of config 3 back took 30-50 ms for a 5 ms solve.  Two pinned buffers per process and
+// device (parked like the streams; 2 x 32 MiB) take the DMA at PCIe rate while a few host threads copy the previous chunk
+// into the caller's array -- whose pages are usually untouched, so the copy is also what faults them in, and that is what
+// the threads are for.  OSC_PINNED_DL=0 keeps the plain copy.
+constexpr size_t kStageBytes = (size_t)32 << 20;
+struct StagePair {
+  void* buf[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+std::map<int, std::vector<StagePair>> g_stage_pool;  // guarded by g_pool_mu
+
+StagePair acquire_stage(int device) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto& v = g_stage_pool[device];
+    if (!v.empty()) {
+      StagePair sp = v.back();
+      v.pop_back();
+      return sp;
+    }
+  }
+  StagePair sp;
+  for (int i = 0; i < 2; ++i) {
+    HIP_CHECK(hipHostMalloc(&sp.buf[i], kStageBytes, hipHostMallocDefault));
+    HIP_CHECK(hipEventCreateWithFlags(&sp.ev[i], hipEventDisableTiming));
+  }
+  return sp;
+}
+void release_stage(int device, const StagePair& sp) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto& v = g_stage_pool[device];
+  if (v.size() < 4) {
+    v.push_back(sp);
+    return;
+  }
+  for (int i = 0; i < 2; ++i) {
+    (void)hipHostFree(sp.buf[i]);
+    (void)hipEventDestroy(sp.ev[i]);
+  }
+}
+
+void parallel_copy(char* dst, const char* src, size_t bytes, int threads) {
+  if (threads <= 1 || bytes < ((size_t)4 << 20)) {
+    std::memcpy(dst, src, bytes);
+    return;
+  }
+  const size_t per = ((bytes / (size_t)threads) + 4095) & ~(size_t)4095;
+  std::vector<std::thread> ts;
+  for (int t = 1; t < threads; ++t) {
+    const size_t off = per * (size_t)t;
+    if (off >= bytes) break;
+    ts.emplace_back([=] { std::memcpy(dst + off, src + off, std::min(per, bytes - off)); });
+  }
+  std::memcpy(dst, src, std::min(per, bytes));
+  for (auto& t : ts) t.join();
+}
+
+// contiguous device array -> host array, returns when the host array is complete
+void download_contiguous(L& h, char* dst, const char* src, size_t bytes) {
+  static const bool pinned = [] { const char* e = getenv("OSC_PINNED_DL"); return !(e && atoi(e) == 0); }();
+  if (!pinned || bytes < 2 * kStageBytes) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h.stream));
+    sync(h);
+    return;
+  }
+  static const int threads = [] {
+    const char* e = getenv("OSC_COPY_THREADS");
+    const int hw = (int)std::thread::hardware_concurrency();
+    return e ? std::max(1, atoi(e)) : std::max(1, std::min(8, hw / 2));
+  }();
+  const StagePair sp = acquire_stage(h.device);
+  try {
+    const size_t nchunks = (bytes + kStageBytes - 1) / kStageBytes;
+    auto issue = [&](size_t c) {
+      const size_t off = c * kStageBytes;
+      HIP_CHECK(hipMemcpyAsync(sp.buf[c & 1], src + off, std::min(kStageBytes, bytes - off), hipMemcpyDeviceToHost, h.stream));
+      HIP_CHECK(hipEventRecord(sp.ev[c & 1], h.stream));
+    };
+    issue(0);
+    for (size_t c = 0; c < nchunks; ++c) {
+      if (c + 1 < nchunks) issue(c + 1);  // (its buffer was emptied by the host copy of chunk c - 1)
+      HIP_CHECK(hipEventSynchronize(sp.ev[c & 1]));
+      const size_t off = c * kStageBytes;
+      parallel_copy(dst + off, static_cast<const char*>(sp.buf[c & 1]), std::min(kStageBytes, bytes - off), threads);
+    }
+  } catch (...) {
+    (void)hipStreamSynchronize(h.stream);
+    release_stage(h.device, sp);
+    throw;
+  }
+  release_stage(h.device, sp);
+}
+
+// N x ld device array -> N x D host array; returns when the host array is complete
 void download_rows(L& h, float* dst, const float* src) {
   if (h.ld == h.D) {
-    HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)h.N * h.D * 4, hipMemcpyDeviceToHost, h.stream));
+    download_contiguous(h, reinterpret_cast<char*>(dst), reinterpret_cast<const char*>(src), (size_t)h.N * h.D * 4);
     return;
   }
   float* stage = (src == h.R.p) ? h.P.p : h.R.p;
   if ((int64_t)h.N * h.D >= ((int64_t)1 << 20) && stage != nullptr && stage != src) {
     HIP_CHECK(hipMemcpy2DAsync(stage, (size_t)h.D * 4, src, (size_t)h.ld * 4, (size_t)h.D * 4, (size_t)h.N,
                                hipMemcpyDeviceToDevice, h.stream));
-    HIP_CHECK(hipMemcpyAsync(dst, stage, (size_t)h.N * h.D * 4, hipMemcpyDeviceToHost, h.stream));
+    download_contiguous(h, reinterpret_cast<char*>(dst), reinterpret_cast<const char*>(stage), (size_t)h.N * h.D * 4);
     return;
   }
   HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)h.D * 4, src, (size_t)h.ld * 4, (size_t)h.D * 4, (size_t)h.N,
                              hipMemcpyDeviceToHost, h.stream));
+  sync(h);
 }
 
 // per-row host vector that came back in device row order -> API row order (in place)
@@ -789,8 +887,8 @@ void build_graph(L& h) {
   // sample, hits appended -- D <= 768 and enough row blocks for the sample) and the older 128 x 128 tile with
   // register-resident sorted lists (k_knn_pref), which serves everything else.
   static const int panel_min = [] { const char* e = getenv("OSC_KNN_PANEL_MIN"); return e ? std::max(6144, atoi(e)) : 16384; }();
-  // (a hit entry packs the column index into 27 bits)
-  bool panel = prefilter && knn_panel_nkt(h.D) != 0 && N >= panel_min && N < (1 << 27) &&
+  // (a hit entry packs the column index into 25 bits, next to its two side flags)
+  bool panel = prefilter && knn_panel_nkt(h.D) != 0 && N >= panel_min && N < (1 << 25) &&
                knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount).ok;
   if (const char* e = getenv("OSC_KNN_MODE")) {
     if (!strcmp(e, "panel")) panel = prefilter = (keep_f >= k + 8) && !any_k && knn_panel_nkt(h.D) != 0 && N >= 6144;
@@ -808,11 +906,16 @@ void build_graph(L& h) {
   DevBuf<unsigned long long> p_hits;
   DevBuf<int32_t> p_hcnt;
   DevBuf<unsigned> p_queue;
+  KnnPanelSymDev sym_dev{};
   if (panel) {
     // (image rows scattered over the lattice rows in single-process builds: knn_gemm.hpp, KnnPanelPlan::scatter)
     const char* sc_env = getenv("OSC_KNN_PANEL_SCATTER");
     const bool scatter_on = !(sc_env && atoi(sc_env) == 0);
-    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, scatter_on && parts == 1);
+    // single-process builds sweep only the column tiles J >= I of every row block (knn_gemm.hip: symmetric half sweep);
+    // a sharded build's ranks own row blocks and would have to exchange the column-side hits, so they keep the full sweep
+    const char* sym_e = getenv("OSC_KNN_PANEL_SYM");  // 0: full sweep (A/B, tests)
+    const bool sym_env = !(sym_e && atoi(sym_e) == 0);
+    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, scatter_on && parts == 1, sym_env && parts == 1);
     p_img.alloc((size_t)pp.npad * pp.ldh / 2);
     p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
     p_tmax.alloc((size_t)pp.npad * pp.sample_groups);
@@ -861,12 +964,24 @@ void build_graph(L& h) {
         launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
                              std::max(1, std::min(prop.multiProcessorCount, nsets * pp.SA)), h.stream);
         launch_panel_tau(p_tmax.p, pp, N, p_tau.p, h.stream);
-        p_hits.alloc((size_t)rb_count * pp.S * 4 * pp.hit_cap);  // one list per (work item, wave)
-        p_hcnt.alloc((size_t)rb_count * pp.S * 4);
-        launch_panel_filter(p_img.p, pp, N, rb_begin, rb_count, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, grid, h.stream);
+        if (pp.sym) {
+          const size_t nb = (size_t)pp.npad / 32;
+          p_hits.alloc(nb * pp.bucket_cap);  // one bucket per group of 32 receiving rows
+          p_hcnt.alloc(nb + (size_t)pp.S);   // [bucket counts | chunk flags]
+          HIP_CHECK(hipMemsetAsync(p_hcnt.p, 0, (nb + (size_t)pp.S) * 4, h.stream));
+          sym_dev.bucket_ent = p_hits.p;
+          sym_dev.bucket_cnt = p_hcnt.p;
+          sym_dev.flags = p_hcnt.p + nb;
+          const int sgrid = std::max(1, std::min(prop.multiProcessorCount, pp.nitems));
+          launch_panel_filter(p_img.p, pp, N, rb_begin, rb_count, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, sgrid, h.stream, &sym_dev);
+        } else {
+          p_hits.alloc((size_t)rb_count * pp.S * 4 * pp.hit_cap);  // one list per (work item, wave)
+          p_hcnt.alloc((size_t)rb_count * pp.S * 4);
+          launch_panel_filter(p_img.p, pp, N, rb_begin, rb_count, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, grid, h.stream);
+        }
       }
       launch_panel_select(pp, rb_begin, rb_count, N, p_hits.p, p_hcnt.p, cval.p, cidx.p, fail_rows.p, fail_count.p,
-                          h.stream);
+                          h.stream, pp.sym ? &sym_dev : nullptr);
       launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
                          fail_count.p, h.stream);
     } else if (prefilter) {

@@ -855,16 +855,22 @@ def test_panel_prefilter_route_gives_the_exact_lists(amd, N, D, k, kind, monkeyp
         base = rng.standard_normal((N // 40 + 1, D), dtype=np.float32)
         Y = base[np.arange(N) % base.shape[0]].copy()
     lists, info = {}, {}
-    for mode in ("panel", "prefilter", "exact"):
-        monkeypatch.setenv("OSC_KNN_MODE", mode)
+    # "panel" is the default form of a single-process build: the symmetric half sweep (row block I visits the column tiles
+    # J >= I only, every score tested against its row's and its column's threshold); "panel_full" the full sweep a sharded
+    # build's ranks run (OSC_KNN_PANEL_SYM=0)
+    for mode in ("panel", "panel_full", "prefilter", "exact"):
+        monkeypatch.setenv("OSC_KNN_MODE", mode.split("_")[0])
+        monkeypatch.setenv("OSC_KNN_PANEL_SYM", "0" if mode == "panel_full" else "1")
         lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
         info[mode] = lat.build_info()
         lists[mode] = (_knn_sets(lat, N, k), lat.graph_csr())
         lat.close()
     assert info["panel"]["prefilter"] == 2 and info["prefilter"]["prefilter"] == 1 and info["exact"]["prefilter"] == 0
+    assert info["panel_full"]["prefilter"] == 2
     if kind == "dups":  # ties are broken by index in every route: the lattice must be identical
-        assert np.array_equal(lists["panel"][1][0], lists["exact"][1][0])
-        assert np.array_equal(lists["panel"][1][1], lists["exact"][1][1])
+        for mode in ("panel", "panel_full"):
+            assert np.array_equal(lists[mode][1][0], lists["exact"][1][0])
+            assert np.array_equal(lists[mode][1][1], lists["exact"][1][1])
         return
     # In tight clusters the k-th and (k+1)-th neighbours are often within fp32 summation noise of each other.  Every row that
     # differs between two routes is recomputed in float64 and must be such a near-tie: the similarities of the members the
@@ -883,15 +889,17 @@ def test_panel_prefilter_route_gives_the_exact_lists(amd, N, D, k, kind, monkeyp
             assert gap < gap_tol, (what, int(r), members, gap)
         return int(rows.size)
 
-    for mode in ("panel", "prefilter"):
+    for mode in ("panel", "panel_full", "prefilter"):
         differ = prove(mode, "exact", mode)
         assert differ <= allowed, (mode, differ)
+    differ = prove("panel", "panel_full", "half sweep vs full sweep")
+    assert differ <= (allowed if kind == "clustered" else max(4, N // 4000)), differ
     # the two prefilter routes re-score with the same arithmetic; which rows they can prove (and which go to the exact
     # kernel instead) may differ in tight clusters
     differ = prove("panel", "prefilter", "panel vs prefilter")
     assert differ <= (allowed if kind == "clustered" else max(4, N // 4000)), differ
     if kind == "iid":
-        assert info["panel"]["fallback_rows"] <= 8
+        assert info["panel"]["fallback_rows"] <= 8 and info["panel_full"]["fallback_rows"] <= 8
 
 
 def test_panel_prefilter_on_anchors_that_arrive_grouped(amd, monkeypatch):
