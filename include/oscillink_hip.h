@@ -48,6 +48,13 @@ int osc_device_name(int32_t device, char* out, int32_t cap);
 int osc_device_synchronize(int32_t device);
 const char* osc_last_error(osc_handle h);               /* h may be NULL: error of the last failed osc_create on this thread */
 
+/* Pinned host memory for result arrays (what the reference allocates with NumPy for `U`, `Y`, `U*`: lattice.py:54-56,
+ * 206, 262-271): a read-back (osc_get_U / osc_get_Y / osc_get_ustar / osc_solve_ustar) into such an array is one DMA at
+ * PCIe rate; into ordinary pageable memory it goes through two pinned staging buffers and a threaded host copy.  Freed
+ * blocks are parked and reused (pinning is slow).  Needs a HIP runtime, no device context of its own. */
+int osc_host_alloc(int64_t bytes, void** out);
+int osc_host_free(void* p);
+
 /* ---- construction: OscillinkLattice.__init__ (lattice.py:33-110) ---------------------------- */
 /* Copies Y (N x D) to the device, sets U = Y, B = 1, psi = 0, lams = (1.0, 0.5, 4.0).
  * build_graph != 0: builds the mutual-kNN graph on the device -- graph.py:8-66 (mutual_knn_adj),

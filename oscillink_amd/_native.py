@@ -29,6 +29,8 @@ SIGNATURES = {
     "osc_device_name": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
     "osc_device_synchronize": (C.c_int, [C.c_int32]),
     "osc_last_error": (C.c_char_p, [Handle]),
+    "osc_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "osc_host_free": (C.c_int, [C.c_void_p]),
     "osc_create": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int64, C.c_int32,
                              C.c_int32, C.POINTER(Handle)]),
     "osc_destroy": (C.c_int, [Handle]),
@@ -114,6 +116,26 @@ def device_count() -> int:
     n = C.c_int32(0)
     lib().osc_device_count(C.byref(n))
     return int(n.value)
+
+
+_PINNED_MIN_BYTES = 8 << 20
+
+
+def result_array(shape) -> np.ndarray:
+    """An uninitialised float32 array for a device read-back.  Large ones live in pinned host memory from the library's
+    pool (osc_host_alloc), so the read-back is one DMA with no host copy behind it; the block returns to the pool when
+    the array (and every view of it) is gone.  Small ones, and any failure to pin, give a plain `np.empty`."""
+    import weakref
+
+    n = int(np.prod(shape))
+    if n * 4 < _PINNED_MIN_BYTES or os.environ.get("OSC_PINNED_RESULTS", "1") == "0":
+        return np.empty(shape, dtype=np.float32)
+    p = C.c_void_p()
+    if lib().osc_host_alloc(n * 4, C.byref(p)) != OSC_OK or not p.value:
+        return np.empty(shape, dtype=np.float32)
+    buf = (C.c_float * n).from_address(p.value)
+    weakref.finalize(buf, lib().osc_host_free, C.c_void_p(p.value))  # runs when numpy drops its last reference to buf
+    return np.frombuffer(buf, dtype=np.float32).reshape(shape)
 
 
 def f32(a: np.ndarray):

@@ -445,6 +445,67 @@ void release_stage(int device, const StagePair& sp) {
   }
 }
 
+// Pinned host arrays for results (osc_host_alloc): the Python layer hands them out as the NumPy arrays `lat.U`, `lat.Y` and
+// solve_Ustar() return, so a read-back is ONE DMA at PCIe rate with no host copy and no page faults behind it.  Pinning
+// is slow (tens of ms for 300 MB), so freed arrays are parked per size class and handed out again; at most kHostParkBytes
+// stay parked.
+constexpr size_t kHostParkBytes = (size_t)2 << 30;
+struct HostBlock {
+  void* p;
+  size_t bytes;
+};
+std::vector<HostBlock> g_host_parked;       // guarded by g_pool_mu
+std::map<void*, size_t> g_host_live;        // blocks handed out (pointer -> capacity)
+size_t g_host_parked_bytes = 0;
+
+void* host_pool_alloc(size_t bytes) {
+  const size_t cap = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_host_parked.size(); ++i)
+      if (g_host_parked[i].bytes >= cap && g_host_parked[i].bytes <= cap + cap / 8) {
+        const HostBlock b = g_host_parked[i];
+        g_host_parked.erase(g_host_parked.begin() + (long)i);
+        g_host_parked_bytes -= b.bytes;
+        g_host_live[b.p] = b.bytes;
+        return b.p;
+      }
+  }
+  void* p = nullptr;
+  if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_host_live[p] = cap;
+  return p;
+}
+bool host_pool_free(void* p) {
+  size_t cap = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_host_live.find(p);
+    if (it == g_host_live.end()) return false;
+    cap = it->second;
+    g_host_live.erase(it);
+    if (g_host_parked_bytes + cap <= kHostParkBytes) {
+      g_host_parked.push_back(HostBlock{p, cap});
+      g_host_parked_bytes += cap;
+      return true;
+    }
+  }
+  (void)hipHostFree(p);
+  return true;
+}
+bool host_pool_owns(const void* p, size_t bytes) {  // [p, p + bytes) lies inside a block this pool handed out
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_host_live.upper_bound(const_cast<void*>(p));
+  if (it == g_host_live.begin()) return false;
+  --it;
+  const char* b = static_cast<const char*>(it->first);
+  return static_cast<const char*>(p) >= b && static_cast<const char*>(p) + bytes <= b + it->second;
+}
+
 void parallel_copy(char* dst, const char* src, size_t bytes, int threads) {
   if (threads <= 1 || bytes < ((size_t)4 << 20)) {
     std::memcpy(dst, src, bytes);
@@ -464,7 +525,7 @@ void parallel_copy(char* dst, const char* src, size_t bytes, int threads) {
 // contiguous device array -> host array, returns when the host array is complete
 void download_contiguous(L& h, char* dst, const char* src, size_t bytes) {
   static const bool pinned = [] { const char* e = getenv("OSC_PINNED_DL"); return !(e && atoi(e) == 0); }();
-  if (!pinned || bytes < 2 * kStageBytes) {
+  if (!pinned || bytes < 2 * kStageBytes || host_pool_owns(dst, bytes)) {  // (a pinned destination takes the DMA directly)
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h.stream));
     sync(h);
     return;
@@ -2176,6 +2237,17 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
   }
   *out = h.release();
   return OSC_OK;
+}
+
+int osc_host_alloc(int64_t bytes, void** out) {
+  if (!out || bytes <= 0) return OSC_E_INVALID;
+  *out = host_pool_alloc((size_t)bytes);
+  return *out ? OSC_OK : OSC_E_HIP;
+}
+
+int osc_host_free(void* p) {
+  if (!p) return OSC_OK;
+  return host_pool_free(p) ? OSC_OK : OSC_E_INVALID;
 }
 
 int osc_destroy(osc_handle h) {

@@ -140,7 +140,7 @@ class OscillinkLattice:
     @property
     def Y(self) -> np.ndarray:
         if self._Y_host is None:
-            out = np.empty((self.N, self.D), dtype=np.float32)
+            out = nat.result_array((self.N, self.D))
             self._call("osc_get_Y", nat.f32(out))
             self._Y_host = out
         return self._Y_host
@@ -148,7 +148,7 @@ class OscillinkLattice:
     @property
     def U(self) -> np.ndarray:
         if self._U_host is None:
-            out = np.empty((self.N, self.D), dtype=np.float32)
+            out = nat.result_array((self.N, self.D))
             self._call("osc_get_U", nat.f32(out))
             self._U_host = out
         return self._U_host
@@ -453,7 +453,7 @@ class OscillinkLattice:
         return out
 
     def _download_ustar(self) -> np.ndarray:
-        out = np.empty((self.N, self.D), dtype=np.float32)
+        out = nat.result_array((self.N, self.D))
         self._call("osc_get_ustar", nat.f32(out))
         return out
 

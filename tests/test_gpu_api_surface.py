@@ -492,3 +492,44 @@ def test_diffusion_gates_that_broke_down_come_back_as_computed(amd):
     assert h.shape == (64,) and not np.isfinite(h).all()
     h_ok = amd.compute_diffusion_gates(Y, psi, kneighbors=5, method="cg", lattice=lat)
     assert np.isfinite(h_ok).all() and 0.0 <= h_ok.min() and h_ok.max() <= 1.0
+
+
+def test_large_read_backs_pinned_and_staged_agree(amd, monkeypatch):
+    """`lat.U` / `lat.Y` / solve_Ustar() of a large lattice come back in pinned host memory from the library's pool (one
+    DMA); with OSC_PINNED_RESULTS=0 they go into an ordinary NumPy array through the chunked, double-buffered staging path
+    (>= 64 MB).  Same bytes either way and as the row-wise reads; the arrays outlive the lattice; a freed block is handed
+    out again."""
+    import ctypes as C
+    import gc
+
+    from oscillink_amd import _native as nat
+
+    rng = np.random.default_rng(3)
+    N, D = 70_000, 256  # 71.7 MB per array
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    lat = amd.Oscillink(Y, kneighbors=8)
+    lat.set_query(Y[0] / np.linalg.norm(Y[0]))
+    lat.settle(max_iters=6, tol=1e-3)
+    U_pinned = lat.U
+    Us_pinned = lat.solve_Ustar()
+    assert np.array_equal(lat.Y, Y)
+    rows = np.array([0, 1, N // 2, N - 1], dtype=np.int32)
+    assert np.array_equal(lat._fetch_rows(1, rows), U_pinned[rows])
+    monkeypatch.setenv("OSC_PINNED_RESULTS", "0")
+    lat._U_host = None
+    U_staged = lat.U
+    Us_staged = lat._download_ustar()
+    assert U_staged is not U_pinned and np.array_equal(U_staged, U_pinned) and np.array_equal(Us_staged, Us_pinned)
+    monkeypatch.delenv("OSC_PINNED_RESULTS")
+    lat.close()
+    view = U_pinned[5:9]  # a view keeps the pinned block alive
+    del U_pinned
+    gc.collect()
+    assert np.array_equal(view, U_staged[5:9])
+    # the pool: a freed block of this size class comes back
+    p, q = C.c_void_p(), C.c_void_p()
+    assert nat.lib().osc_host_alloc(N * D * 4, C.byref(p)) == 0 and p.value
+    assert nat.lib().osc_host_free(p) == 0
+    assert nat.lib().osc_host_alloc(N * D * 4, C.byref(q)) == 0 and q.value == p.value
+    assert nat.lib().osc_host_free(q) == 0
+    assert nat.lib().osc_host_free(C.c_void_p(12345)) == nat.OSC_E_INVALID  # not a block of the pool
