@@ -14,14 +14,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import oscillink_amd as amd  # noqa: E402
 from oscillink_amd.sharding import run_loopback_ranks  # noqa: E402
 
-seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-rng = np.random.default_rng(seed)
-os.environ["OSC_SMALL_PATH"] = "0"
-os.environ.pop("OSC_SHARD", None)
-bad = 0
-for t in range(count):
-    N = int(rng.integers(600, 40000))
+
+
+def run_cases(seed, count, n_max=40000, log=print):
+    """`count` random cases from `seed`; returns the number of mismatching cases (tests/test_gpu_multirank_fullsize.py
+    runs a slice of this inside `pytest -m gpu`)."""
+    rng = np.random.default_rng(seed)
+    saved = {k: os.environ.get(k) for k in ("OSC_SMALL_PATH", "OSC_SHARD", "OSC_COMM_OVERLAP")}
+    os.environ["OSC_SMALL_PATH"] = "0"
+    os.environ.pop("OSC_SHARD", None)
+    bad = 0
+    try:
+        for t in range(count):
+            bad += not _one_case(rng, t, n_max, log)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return bad
+
+
+def _one_case(rng, t, n_max, log):
+    N = int(rng.integers(600, n_max))
     D = int(rng.choice([32, 50, 64, 96, 128, 200, 256]))
     k = int(rng.integers(4, 25))
     world = int(rng.choice([2, 3, 4, 5, 8]))
@@ -69,9 +85,14 @@ for t in range(count):
             ok &= gi == wi and len(gh) == len(wh) and bool(np.allclose(gh, wh, rtol=1e-6, atol=1e-12)) and err < 2e-6
         for a, b in zip(g, got[0]):
             ok &= bool(np.array_equal(a[2], b[2]))
-    bad += not ok
-    print(f"case {t}: N={N} D={D} k={k} world={world} overlap={overlap} gates={gates is not None} chain={bool(chain)} "
-          f"iters={[x[0] for x in want]} {'ok' if ok else 'MISMATCH'}", flush=True)
+    log(f"case {t}: N={N} D={D} k={k} world={world} overlap={overlap} gates={gates is not None} chain={bool(chain)} "
+        f"iters={[x[0] for x in want]} {'ok' if ok else 'MISMATCH'}")
     lat0.close()
-print("mismatches:", bad)
-sys.exit(1 if bad else 0)
+    return ok
+
+
+if __name__ == "__main__":
+    bad = run_cases(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 16,
+                    log=lambda m: print(m, flush=True))
+    print("mismatches:", bad)
+    sys.exit(1 if bad else 0)
