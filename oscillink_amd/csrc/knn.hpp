@@ -19,7 +19,7 @@ struct KnnPlan {
 };
 
 // keep <= 128 (exact) / <= 96 (f16).  slots = resident blocks on the device (load balance of the split count)
-KnnPlan knn_plan(int32_t N, int32_t keep, int32_t slots, int rb_begin, int rb_count, bool f16);
+KnnPlan knn_plan(int32_t N, int32_t keep, int32_t slots, int rb_begin, int rb_count, bool f16, int splits_override = 0);  // (override: OSC_KNN_SPLITS, read by the caller)
 void launch_normalize_rows(const float* Y, int32_t ldy, float* Yn, int32_t ldn, int64_t N, int32_t D, hipStream_t s);
 void launch_rows_dot(const float* Yn, int32_t ldn, const float* q, float* out, int64_t N, int32_t D, hipStream_t s);
 void launch_rows_cosine(const float* A, int32_t ld, const float* q, float* out, int64_t N, int32_t D, hipStream_t s);

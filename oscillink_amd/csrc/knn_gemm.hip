@@ -717,7 +717,8 @@ void launch_panel(const PanelArgs& a, int nkt, int nrg, bool sym, int grid, hipS
 
 int knn_panel_nkt(int32_t D) { return D <= 384 ? 6 : D <= 768 ? 12 : 0; }
 
-KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows, bool sym) {
+KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows, bool sym,
+                            const KnnPanelTune& tune) {
   KnnPanelPlan p{};
   p.sym = sym;
   p.scatter = 1;
@@ -737,8 +738,7 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
   p.nkt = knn_panel_nkt(D);
   p.ldh = 64 * p.nkt;
   // row groups per wave: two where the panel is small enough (D <= 384: 2 x 96 registers), see the file header
-  static const int nrg_env = [] { const char* e = getenv("OSC_KNN_PANEL_NRG"); return e ? atoi(e) : 0; }();
-  p.nrg = (p.nkt == 6 && nrg_env != 1) ? 2 : 1;
+  p.nrg = (p.nkt == 6 && tune.nrg != 1) ? 2 : 1;
   p.npad = ((N + 127) / 128) * 128;
   p.nrb = p.npad / 128;
   p.keep = keep;
@@ -746,7 +746,7 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
   // score, so about rho * 16 columns of the full sweep beat it (gamma-distributed: 0.1 % of the rows see fewer than
   // rho * 6 or more than rho * 32).  rho = keep / 4 puts `keep` at the low tail and 8 keep slots above the high one;
   // OSC_KNN_PANEL_RHO overrides it.
-  static const double rho_env = [] { const char* e = getenv("OSC_KNN_PANEL_RHO"); return e ? atof(e) : 0.0; }();
+  const double rho_env = tune.rho;
   // (round 3, config 4's shape, keep = 24: rho 6 / 8 / 12 / 16 -> build 798 / 790 / 775 / 784 ms with 6 / 1 / 1 / 129 rows sent
   // to the exact kernel; from 24 on the folded group maxima put tau so low that every hit list overflows.  Config 3,
   // keep = 48: 8 / 12 / 16 -> 26.5 / 22.2 / 26.8 ms.  Hence at least 12.)
@@ -788,7 +788,7 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
     const double bound = std::max(5.0 * keep, 20.0 * rho);
     int T = (int)std::floor(0.66 * p.hit_cap * p.nrb / (64.0 * bound));
     T = std::max(2, std::min(TC_TILES, T));
-    if (const char* e = getenv("OSC_KNN_PANEL_T")) T = std::max(2, std::min(TC_TILES, atoi(e)));  // (A/B: tiles per chunk)
+    if (tune.T > 0) T = std::max(2, std::min(TC_TILES, tune.T));  // (A/B: tiles per chunk)
     if (p.nrg == 2) T &= ~1;
     p.T = T;
     p.S = (p.nrb + T - 1) / T;  // chunks

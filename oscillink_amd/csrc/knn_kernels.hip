@@ -1126,7 +1126,7 @@ void launch_rows_dot(const float* Yn, int32_t ldn, const float* q, float* out, i
   HIP_CHECK(hipGetLastError());
 }
 
-KnnPlan knn_plan(int32_t N, int32_t keep, int32_t slots, int rb_begin, int rb_count, bool f16) {
+KnnPlan knn_plan(int32_t N, int32_t keep, int32_t slots, int rb_begin, int rb_count, bool f16, int splits_override) {
   KnnPlan p{};
   p.keep = keep;
   p.E = (keep + 31) / 32;
@@ -1160,7 +1160,7 @@ KnnPlan knn_plan(int32_t N, int32_t keep, int32_t slots, int rb_begin, int rb_co
       best_S = S;
     }
   }
-  if (const char* e = getenv("OSC_KNN_SPLITS")) best_S = std::max(1, std::min(col_tiles, atoi(e)));
+  if (splits_override > 0) best_S = std::max(1, std::min(col_tiles, splits_override));
   p.S = best_S;
   p.cols_per_split = ((col_tiles + p.S - 1) / p.S) * BN;
   return p;
@@ -1181,25 +1181,11 @@ void launch_knn_topk(const KnnPlan& p, const float* Yop, int32_t ld, int32_t N, 
   if (p.f16) {
     if (p.qrows) throw std::runtime_error("the prefilter kernel has no row-list variant");
     if (p.E > 3) throw std::runtime_error("f16 prefilter supports at most 96 kept candidates");
-    static const bool wide = [] { const char* e = getenv("OSC_KNN_PREF_WG"); return e && atoi(e) == 8; }();
-    if (!wide) {
-      constexpr size_t lds = (size_t)2 * (128 + 128) * BK * 4;
-      if (p.E == 1) hipLaunchKernelGGL((k_knn_pref<1, 4, 2>), grid, block, lds, s, OSC_KNN_PREF_ARGS);
-      else if (p.E == 2) hipLaunchKernelGGL((k_knn_pref<2, 4, 2>), grid, block, lds, s, OSC_KNN_PREF_ARGS);
-      else if (p.E == 3) hipLaunchKernelGGL((k_knn_pref<3, 4, 2>), grid, block, lds, s, OSC_KNN_PREF_ARGS);
-    } else {  // 256-row workgroups, three stages
-      constexpr size_t lds = (size_t)3 * (256 + 128) * BK * 4;
-      const dim3 grid8((unsigned)(8 * ((((p.rb_count + 1) / 2) + 7) / 8) * p.S)), block8(512);
-      static std::once_flag once;
-      std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_pref<1, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_pref<2, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_pref<3, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      });
-      if (p.E == 1) hipLaunchKernelGGL((k_knn_pref<1, 8, 3>), grid8, block8, lds, s, OSC_KNN_PREF_ARGS);
-      else if (p.E == 2) hipLaunchKernelGGL((k_knn_pref<2, 8, 3>), grid8, block8, lds, s, OSC_KNN_PREF_ARGS);
-      else if (p.E == 3) hipLaunchKernelGGL((k_knn_pref<3, 8, 3>), grid8, block8, lds, s, OSC_KNN_PREF_ARGS);
-    }
+    // (a 256-row, 8-wave, three-stage form of the same body was measured at 32.0 vs 31.0 ms at config 3 and removed)
+    constexpr size_t lds = (size_t)2 * (128 + 128) * BK * 4;
+    if (p.E == 1) hipLaunchKernelGGL((k_knn_pref<1, 4, 2>), grid, block, lds, s, OSC_KNN_PREF_ARGS);
+    else if (p.E == 2) hipLaunchKernelGGL((k_knn_pref<2, 4, 2>), grid, block, lds, s, OSC_KNN_PREF_ARGS);
+    else if (p.E == 3) hipLaunchKernelGGL((k_knn_pref<3, 4, 2>), grid, block, lds, s, OSC_KNN_PREF_ARGS);
   } else if (p.qrows) {
     if (p.E == 1) hipLaunchKernelGGL((k_knn_topk<1, false, true>), grid, block, 0, s, OSC_KNN_ARGS);
     else if (p.E == 2) hipLaunchKernelGGL((k_knn_topk<2, false, true>), grid, block, 0, s, OSC_KNN_ARGS);

@@ -216,11 +216,11 @@ struct osc_lattice {
   bool p_blocked = true;   // slab-major search direction in xs mode (OSC_P_BLOCKED=0 keeps it row-major)
   int xs_nb = 0;           // workgroups per XCD in that mode; 0 = automatic (OSC_XS_NB)
   int xs_groups_cap = 8;   // upper bound on the slab groups (= slabs in flight) of that mode (OSC_XS_GROUPS)
-  int xs_min_cols = 32;    // narrowest column window the mode is used for (OSC_XS_MIN_COLS; 96 until round 3 -- with the
+  int xs_min_cols = 32;    // narrowest column window the mode is used for (96 until round 3 -- with the
                            // blocked matvec under it, one- and two-slab windows win too: 100k x 64 k 16 0.505 -> 0.425 ms per
                            // settle, 100k x 32 0.352 -> 0.309, 200k x 64 k 32 1.43 -> 0.97, 60k x 64 k 32 0.438 -> 0.387)
-  int xs_min_rows = 6144, xs_min_rows_narrow = 0;  // smallest lattice the mode is used for: windows of >= 256 columns / narrower ones (0: by width, xs_plan) (OSC_XS_MIN_ROWS="a,b")
-  int xs_groups_min = 2;   // fewest slab groups the mode is kept for when the natural count had to be reduced (OSC_XS_MIN_GROUPS)
+  int xs_min_rows = 6144, xs_min_rows_narrow = 0;  // smallest lattice the mode is used for: windows of >= 256 columns / narrower ones (0: by width, xs_plan)
+  int xs_groups_min = 2;   // fewest slab groups the mode is kept for when the natural count had to be reduced
   DevBuf<float> part0, part1, alpha, beta;
   DevBuf<double> rz, colsum;
   DevBuf<uint32_t> res_bits;  // residual slots of the row-sharded solve
@@ -232,6 +232,16 @@ struct osc_lattice {
   int ctrl_next = 0;     // next free segment
   bool small_path = true;             // OSC_SMALL_PATH=0 disables the one-launch CG for small lattices
   bool fake_window = false;  // OSC_FAKE_COL_SHARD under a one-rank communicator (measurement hook; reported by osc_comm_info)
+  // build-route switches (read_env): every OSC_* variable the library reads per handle is read in ONE place, at
+  // osc_create and again at osc_rebuild_graph (INTEGRATION.md has the table)
+  int knn_mode = 0;            // OSC_KNN_MODE: 0 automatic, 1 exact, 2 tile prefilter, 3 panel prefilter
+  int knn_fake_shards = 0;     // OSC_KNN_FAKE_SHARDS
+  int knn_splits = 0;          // OSC_KNN_SPLITS (tile / exact routes: column splits)
+  bool knn_scatter = true;     // OSC_KNN_PANEL_SCATTER
+  bool knn_sym = true;         // OSC_KNN_PANEL_SYM
+  KnnPanelTune knn_tune{};     // OSC_KNN_PANEL_NRG / _RHO / _T
+  int halo_force = 0;          // OSC_HALO: 1 full, 2 lists
+  int fake_col_r = 0, fake_col_w = 0;  // OSC_FAKE_COL_SHARD "r/w"
   int predicted_iters[3] = {0, 0, 0};  // iterations the last general-path solve of each kind (CgBuffers::kind) took (0 = unknown)
   bool x_defer = true;                // the x update rides in the next iteration's p update (run_cg; OSC_X_DEFER=0: beside the r update)
   bool x_last_form = true;            // ... and the expected last iteration finishes x itself without storing r (OSC_X_DEFER=2: off)
@@ -242,11 +252,11 @@ struct osc_lattice {
   DevBuf<int2> blk_slots, blk_rest, blk_over;
   int blk_nb = 0;          // blocks of the copy held (0 = none / stale)
   int spmm_blocked = -1;   // -1 by lattice size, 0 off, > 0 = that many source blocks (OSC_SPMM_BLOCKED)
-  double blk_mb = 2.0;     // smallest slab (N x 128 B, MiB) the blocked apply is chosen for (OSC_BLK_MB)
-  double blk_edges = 0.0;  // edges of a row per source block the block count aims at; 0 = by lattice size: 3.3 / 2.5 (OSC_BLK_EDGES)
+  double blk_mb = 2.0;     // smallest slab (N x 128 B, MiB) the blocked apply is chosen for
+  double blk_edges = 0.0;  // edges of a row per source block the block count aims at; 0 = by lattice size: 3.3 / 2.5
   int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
   int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
-  double temporal_mb = 200.0;  // largest solve (5 arrays x N x window) whose update kernels use ordinary instead of nontemporal accesses (OSC_TEMPORAL_MB)
+  double temporal_mb = 200.0;  // largest solve (5 arrays x N x window) whose update kernels use ordinary instead of nontemporal accesses
   bool spmm_deep = true;   // re-ordered lattices: the operator apply with 8 gathers in flight per row (OSC_SPMM_DEEP=0: the usual 2)
   bool blk_init = true;    // the initial residual goes through the blocked matvec as well (OSC_BLK_INIT=0: plain INIT apply)
   bool blk_init_fused = true;  // ... and is formed in that launch's epilogue where it can be (OSC_BLK_INIT=2: separate finish pass)
@@ -255,7 +265,7 @@ struct osc_lattice {
   float* res_host = nullptr;  // pinned, host-mapped mirror of res_bits for the per-iteration read-back
   float* res_host_dev = nullptr;  // the device's address of it
   size_t res_host_n = 0;
-  bool mapped_residual = true;  // OSC_MAPPED_RES=0: copy + event per iteration instead
+  bool mapped_residual = true;  // residuals published into host-mapped memory (false: copy + event per iteration)
   std::vector<hipEvent_t> iter_events;
   // sharded solves: the stop test's all-reduce runs on a second stream beside the next iteration's p update and matvec
   // (run_cg); step_events[it] = "iteration it's local residual is out" (OSC_COMM_OVERLAP=0: all-reduce in the solve's stream)
@@ -917,8 +927,7 @@ void build_graph(L& h) {
   // columns, then one all-gather of the (idx, sim) lists; mutual test / cap / Laplacian weights run on every rank.
   const int all_rb = (N + 127) / 128;
   // OSC_KNN_FAKE_SHARDS=G (test hook): run the G per-rank passes of a sharded build one after another on this GPU
-  int fake = 0;
-  if (const char* e = getenv("OSC_KNN_FAKE_SHARDS")) fake = std::max(0, atoi(e));
+  const int fake = h.knn_fake_shards;
   const bool sharded = h.comm != nullptr && h.world > 1;
   const int parts = sharded ? h.world : (fake > 1 ? fake : 1);
   const int rb_per = (all_rb + parts - 1) / parts;
@@ -935,26 +944,23 @@ void build_graph(L& h) {
   //              to its top-k, otherwise the row is redone by the exact kernel.
   // kept candidates per row: k plus a margin; rows whose margin turns out too thin are redone exactly
   const int keep_f = std::min(96, k + std::max(12, k / 2));
-  static const bool dense_small = [] { const char* e = getenv("OSC_KNN_DENSE"); return !(e && atoi(e) == 0); }();
-  static const int dense_max = [] { const char* e = getenv("OSC_KNN_DENSE_MAX"); return e ? std::max(0, std::min(8192, atoi(e))) : 8192; }();
+  constexpr bool dense_small = true;
+  constexpr int dense_max = 8192;
   // small lattices go through the dense similarity matrix (below); beyond that the fp16 prefilter pays
   bool prefilter = (keep_f >= k + 8) && N >= 4096 && !(dense_small && parts == 1 && N <= dense_max);
-  if (const char* e = getenv("OSC_KNN_MODE")) {  // "exact" | "prefilter": force one path (tests, A/B)
-    if (!strcmp(e, "exact")) prefilter = false;
-    if (!strcmp(e, "prefilter")) prefilter = (keep_f >= k + 8);
-  }
+  // OSC_KNN_MODE = exact | prefilter | panel: force one route (tests, A/B)
+  if (h.knn_mode == 1) prefilter = false;
+  if (h.knn_mode == 2) prefilter = (keep_f >= k + 8);
   if (any_k) prefilter = false;
   // The prefilter's GEMM has two shapes: "panel" (knn_gemm.hip: query panel in registers, thresholds from a column
   // sample, hits appended -- D <= 768 and enough row blocks for the sample) and the older 128 x 128 tile with
   // register-resident sorted lists (k_knn_pref), which serves everything else.
-  static const int panel_min = [] { const char* e = getenv("OSC_KNN_PANEL_MIN"); return e ? std::max(6144, atoi(e)) : 16384; }();
+  constexpr int panel_min = 16384;
   // (a hit entry packs the column index into 25 bits, next to its two side flags)
   bool panel = prefilter && knn_panel_nkt(h.D) != 0 && N >= panel_min && N < (1 << 25) &&
-               knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount).ok;
-  if (const char* e = getenv("OSC_KNN_MODE")) {
-    if (!strcmp(e, "panel")) panel = prefilter = (keep_f >= k + 8) && !any_k && knn_panel_nkt(h.D) != 0 && N >= 6144;
-    if (!strcmp(e, "prefilter")) panel = false;
-  }
+               knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, false, false, h.knn_tune).ok;
+  if (h.knn_mode == 3) panel = prefilter = (keep_f >= k + 8) && !any_k && knn_panel_nkt(h.D) != 0 && N >= 6144 && N < (1 << 25);
+  if (h.knn_mode == 2) panel = false;
   h.knn_panel = panel;
   DevBuf<float> cand_val, cval;
   DevBuf<int32_t> cand_idx, cidx, fail_rows, fail_count;
@@ -970,13 +976,10 @@ void build_graph(L& h) {
   KnnPanelSymDev sym_dev{};
   if (panel) {
     // (image rows scattered over the lattice rows in single-process builds: knn_gemm.hpp, KnnPanelPlan::scatter)
-    const char* sc_env = getenv("OSC_KNN_PANEL_SCATTER");
-    const bool scatter_on = !(sc_env && atoi(sc_env) == 0);
     // single-process builds sweep only the column tiles J >= I of every row block (knn_gemm.hip: symmetric half sweep);
     // a sharded build's ranks own row blocks and would have to exchange the column-side hits, so they keep the full sweep
-    const char* sym_e = getenv("OSC_KNN_PANEL_SYM");  // 0: full sweep (A/B, tests)
-    const bool sym_env = !(sym_e && atoi(sym_e) == 0);
-    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, scatter_on && parts == 1, sym_env && parts == 1);
+    // (OSC_KNN_PANEL_SCATTER=0 / OSC_KNN_PANEL_SYM=0: A/B and tests)
+    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, h.knn_scatter && parts == 1, h.knn_sym && parts == 1, h.knn_tune);
     p_img.alloc((size_t)pp.npad * pp.ldh / 2);
     p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
     p_tmax.alloc((size_t)pp.npad * pp.sample_groups);
@@ -1017,7 +1020,7 @@ void build_graph(L& h) {
         sync(h);  // Sm goes back to the pool at scope exit
       }
     } else if (panel) {
-      const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true);  // row range + keep for the re-scoring
+      const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true, h.knn_splits);  // row range + keep for the re-scoring
       const int nsets = (rb_count + pp.nrg - 1) / pp.nrg;  // work items per column split (knn_gemm.hip)
       const int grid = std::max(1, std::min(prop.multiProcessorCount, nsets * pp.S));
       {
@@ -1046,7 +1049,7 @@ void build_graph(L& h) {
       launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
                          fail_count.p, h.stream);
     } else if (prefilter) {
-      const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true);
+      const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true, h.knn_splits);
       const size_t ncand = (size_t)h.N * plan.S * plan.KC;
       cand_val.alloc(ncand);
       cand_idx.alloc(ncand);
@@ -1067,7 +1070,7 @@ void build_graph(L& h) {
       launch_knn_dense(Yn.p, ldn, N, k, Sm.p, ldS, h.knn_val.p, h.knn_idx.p, h.stream);
       sync(h);  // Sm goes back to the pool at scope exit
     } else {
-      const KnnPlan plan = knn_plan(N, k, slots, rb_begin, rb_count, false);
+      const KnnPlan plan = knn_plan(N, k, slots, rb_begin, rb_count, false, h.knn_splits);
       const size_t ncand = (size_t)h.N * plan.S * plan.KC;
       cand_val.alloc(ncand);
       cand_idx.alloc(ncand);
@@ -1092,7 +1095,7 @@ void build_graph(L& h) {
       if (few_done) sync(h);  // Sm goes back to the pool at scope exit
     }
     if (nfail > 0 && !few_done) {  // redo the unproven rows with the exact kernel (ties / dense clusters of near-equal scores)
-      KnnPlan plan = knn_plan(N, k, slots, 0, (nfail + 127) / 128, false);
+      KnnPlan plan = knn_plan(N, k, slots, 0, (nfail + 127) / 128, false, h.knn_splits);
       plan.qrows = fail_rows.p;
       plan.nq = nfail;
       const size_t ncand = (size_t)h.N * plan.S * plan.KC;
@@ -1188,7 +1191,13 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   const int nb = std::max(1, std::min(grid / 8, h.xs_nb > 0 ? h.xs_nb : 96));
   if (h.spmm_xs == 0) return 0;
   if (h.spmm_xs == 1) return nb;
-  if (h.spmm_slab != 0 || h.reordered || (h.ld & 31) != 0 || (h.c0 & 31) != 0) return 0;
+  if (h.spmm_slab != 0 || (h.ld & 31) != 0 || (h.c0 & 31) != 0) return 0;
+  // A lattice stored in BFS order gathers from its XCD's L2 on the general path already, so the slab
+  // mode is off for it -- except large narrow ones, where the source-blocked matvec on top of the local order wins
+  // (round 4, scripts/exp/r04_bfs_blocked_sweep.py, clustered anchors, per settle: 300k x 128 k 16 2.17 -> 1.95 ms, 300k x
+  // 256 k 32 6.15 -> 5.0-5.3, 400k x 256 6.35 -> 5.35, 600k x 128 4.79 -> 3.92, 1M x 128 8.15 -> 6.72; at 384 columns a tie
+  // (400k 8.06 / 7.98, 1M 20.4 / 20.7), at 200k rows a loss (128 columns: 1.25 -> 1.32)).
+  if (h.reordered) return (h.N >= 300000 && ncols <= 256 && blocked_plan(h, false) > 0) ? nb : 0;
   // from N = 32768 on, and from 6144 (16384 until round 3) for windows of >= 256 columns (N = 20000, D = 256: apply 43.5 -> 31.4 us)
   // narrower windows: 32768 rows, but 12288 where the window is whole groups of four slabs (every XCD pair a slab of its
   // own) and 24576 for other windows of >= 128 columns (scripts/exp/xs_narrow_sweep.py, k = 16, per settle: 20000 x 128
@@ -1217,10 +1226,11 @@ int blocked_plan(const L& h, bool with_path) {
       (int64_t)h.N * h.ld * 4 >= ((int64_t)1 << 32))
     return 0;
   if (h.spmm_blocked > 0) return std::min(h.spmm_blocked, OSC_MAX_SRC_BLOCKS);
-  // block count from the mean degree and the lattice size (host_logic.hpp: blocked_edges_per_block); OSC_BLK_EDGES
+  // block count from the mean degree and the lattice size (host_logic.hpp: blocked_edges_per_block)
   // overrides the edges a row should have per block
   const double mean_deg = h.N > 0 ? (double)h.nnz / (double)h.N : 0.0;
-  const double e = h.blk_edges > 0.0 ? h.blk_edges : host::blocked_edges_per_block(h.N);
+  // (a lattice in BFS order: 2.2 edges per block -- x4 of x2 / x3 / x4 / x6 / x8 at mean degree 8.3, x8 of x6 / x8 / x12 at 20.2)
+  const double e = h.blk_edges > 0.0 ? h.blk_edges : h.reordered ? 2.2 : host::blocked_edges_per_block(h.N);
   const int nb = host::blocked_block_count(mean_deg, e, OSC_MAX_SRC_BLOCKS);
   if (h.spmm_blocked == -2) return nb;  // "whenever possible" (experiments)
   // ... and wherever the XCD-affine slab mode itself runs from a 2 MiB slab (N = 16384) on.  Measured against the plain
@@ -1230,6 +1240,9 @@ int blocked_plan(const L& h, bool with_path) {
   // (k 64: -46 %), 260k x 768 -22 % (k 64: -37 %).
   const double slab = (double)h.N * 128.0;
   if (slab < h.blk_mb * 1024.0 * 1024.0) return 0;
+  // narrow windows of small lattices: the plain slab apply is ahead (round 4 shape sweep: 16384 x 128 k 16 0.205 vs 0.221 ms per
+  // settle; from 20000 rows on a tie or a win)
+  if (h.N < 20000 && h.c1 - h.c0 <= 128) return 0;
   return nb;
 }
 
@@ -1345,7 +1358,7 @@ bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, 
   ensure_ctrl(h, nctl);
   uint32_t* ctl = ctrl_segment(h, nctl);
   // the kernel's last workgroup publishes residuals + a "done" word into host-mapped memory and the host polls that
-  // word (OSC_MAPPED_RES=0: copy of the control words + stream wait, as before)
+  // word
   const bool polled = h.mapped_residual;
   constexpr uint32_t kPending = 0xFFFFFFFFu;
   volatile uint32_t* host_words = reinterpret_cast<volatile uint32_t*>(h.res_host);
@@ -1435,7 +1448,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   uint32_t* done_ctr = res_slots + nslots;
   // Single GPU: the last workgroup of each iteration's beta reduction writes the residual into host-mapped memory and
   // the host polls that word (no 4-byte copy, event record and event wait per iteration).  Under a communicator the
-  // residual first goes through the all-reduce (below; OSC_COMM_OVERLAP=0 or OSC_MAPPED_RES=0: in the solve's stream,
+  // residual first goes through the all-reduce (below; OSC_COMM_OVERLAP=0: in the solve's stream,
   // read back by copy + event).
   const bool mapped = h.comm == nullptr && h.mapped_residual;
   // Sharded (column windows): the stop test needs max over the ranks of the residual -- a 4-byte all-reduce per iteration,
@@ -1890,8 +1903,7 @@ void build_halo_plan(L& h) {
   if (!dec.consistent) throw CommError("halo plan: need / give counts of a rank pair differ (asymmetric lattice graph?)");
   hp.need_rows_max = dec.need_rows_max;
   bool full = dec.full;
-  const char* fe = getenv("OSC_HALO");  // "full" | "lists": force one exchange form (tests, A/B); same on every rank
-  const int force = fe ? (!strcmp(fe, "full") ? 1 : !strcmp(fe, "lists") ? 2 : 0) : 0;
+  const int force = h.halo_force;  // OSC_HALO = full | lists: force one exchange form (tests, A/B); same on every rank
   if (force == 1) full = true;
   if (force == 2) full = false;
   hp.full = full;
@@ -2055,6 +2067,59 @@ CgResult run_cg_rows(L& h, const OpParams& op, const CgBuffers& b, bool with_pat
 
 bool row_mode(const L& h) { return h.shard_mode == 1 && (h.comm != nullptr || h.fake_row_shards > 1); }
 
+// The ONE place the per-handle OSC_* switches are read (osc_create, osc_rebuild_graph).  Process-wide ones are read where
+// the process-wide object is made: OSC_POOL_MB (device memory pool), OSC_PINNED_DL / OSC_COPY_THREADS (read-back staging),
+// OSC_LOOPBACK_TIMEOUT_S / OSC_RCCL_PROXY (communicator backends, comm.hip), OSC_LD (osc_create, before the arrays are sized).
+void read_env(L& h) {
+  auto num = [](const char* name, int& out) {
+    const char* e = getenv(name);
+    if (e) out = atoi(e);
+    return e != nullptr;
+  };
+  int v = 0;
+  if (num("OSC_SPMM_SLAB", v)) h.spmm_slab = v < 0 ? -1 : (v / 4) * 4;
+  if (num("OSC_SPMM_XS", v)) h.spmm_xs = v != 0 ? 1 : 0;
+  if (num("OSC_XS_NB", v)) h.xs_nb = std::max(1, v);
+  if (num("OSC_XS_GROUPS", v)) h.xs_groups_cap = v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : 1;
+  if (num("OSC_P_BLOCKED", v)) h.p_blocked = v != 0;
+  if (num("OSC_SPMM_BLOCKED", v)) h.spmm_blocked = v;
+  if (num("OSC_BLK_INIT", v)) {
+    h.blk_init = v != 0;
+    h.blk_init_fused = v == 1;
+  }
+  if (num("OSC_SPMM_DEEP", v)) h.spmm_deep = v != 0;
+  if (num("OSC_COMM_OVERLAP", v)) h.comm_overlap = v != 0 ? 1 : 0;
+  if (num("OSC_X_DEFER", v)) {
+    h.x_defer = v != 0;
+    h.x_last_form = v == 1;
+  }
+  if (num("OSC_SMALL_PATH", v)) h.small_path = v != 0;
+  if (num("OSC_REORDER", v)) h.reorder = v != 0 ? 1 : 0;
+  else h.reorder = -1;
+  if (const char* e = getenv("OSC_SHARD")) h.shard_mode = !strcmp(e, "row") ? 1 : 0;
+  if (num("OSC_ROW_FAKE_SHARDS", v)) h.fake_row_shards = std::max(0, v);
+  h.fake_col_w = 0;
+  if (const char* e = getenv("OSC_FAKE_COL_SHARD")) {  // "r/w"
+    int r = 0, w = 1;
+    if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) h.fake_col_r = r, h.fake_col_w = w;
+  }
+  // the lattice build
+  h.knn_mode = 0;
+  if (const char* e = getenv("OSC_KNN_MODE")) h.knn_mode = !strcmp(e, "exact") ? 1 : !strcmp(e, "prefilter") ? 2 : !strcmp(e, "panel") ? 3 : 0;
+  h.knn_fake_shards = 0;
+  if (num("OSC_KNN_FAKE_SHARDS", v)) h.knn_fake_shards = std::max(0, v);
+  h.knn_splits = 0;
+  if (num("OSC_KNN_SPLITS", v)) h.knn_splits = std::max(1, v);
+  h.knn_scatter = !(num("OSC_KNN_PANEL_SCATTER", v) && v == 0);
+  h.knn_sym = !(num("OSC_KNN_PANEL_SYM", v) && v == 0);
+  h.knn_tune = KnnPanelTune{};
+  if (num("OSC_KNN_PANEL_NRG", v)) h.knn_tune.nrg = v;
+  if (const char* e = getenv("OSC_KNN_PANEL_RHO")) h.knn_tune.rho = atof(e);
+  if (num("OSC_KNN_PANEL_T", v)) h.knn_tune.T = v;
+  h.halo_force = 0;
+  if (const char* e = getenv("OSC_HALO")) h.halo_force = !strcmp(e, "full") ? 1 : !strcmp(e, "lists") ? 2 : 0;
+}
+
 void require_graph(L& h) {
   if (!h.have_graph) throw StateError("no lattice graph: build it (osc_create build_graph=1) or inject one (osc_set_csr)");
 }
@@ -2164,7 +2229,7 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
       h->ld = ((D + 31) / 32) * 32;
       if ((h->ld * 4) % 4096 == 0) h->ld += 32;
     }
-    if (const char* e = getenv("OSC_LD")) {
+    if (const char* e = getenv("OSC_LD")) {  // (row pitch override: needed before the arrays are sized, hence not in read_env)
       const int v = atoi(e);
       if (v >= h->dcols && v % 4 == 0) h->ld = v;
     }
@@ -2174,46 +2239,10 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     h->row_cap = row_cap;
     h->deterministic = deterministic;
     h->seed = seed;
-    if (const char* e = getenv("OSC_SPMM_SLAB")) h->spmm_slab = atoi(e) < 0 ? -1 : (atoi(e) / 4) * 4;
-    if (const char* e = getenv("OSC_GRID_CAP")) h->grid_cap = std::max(1, atoi(e));
-    if (const char* e = getenv("OSC_SPMM_XS")) h->spmm_xs = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("OSC_XS_NB")) h->xs_nb = std::max(1, atoi(e));
-    if (const char* e = getenv("OSC_XS_MIN_COLS")) h->xs_min_cols = std::max(32, atoi(e));
-    if (const char* e = getenv("OSC_XS_MIN_ROWS")) {
-      int a = 0, b = 0;
-      if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) h->xs_min_rows = a, h->xs_min_rows_narrow = b;
-    }
-    if (const char* e = getenv("OSC_XS_MIN_GROUPS")) h->xs_groups_min = std::max(1, std::min(8, atoi(e)));
-    if (const char* e = getenv("OSC_XS_GROUPS")) {
-      const int g = atoi(e);
-      h->xs_groups_cap = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;
-    }
-    if (const char* e = getenv("OSC_P_BLOCKED")) h->p_blocked = atoi(e) != 0;
-    if (const char* e = getenv("OSC_SPMM_BLOCKED")) h->spmm_blocked = atoi(e);
-    if (const char* e = getenv("OSC_BLK_MB")) h->blk_mb = std::max(0.0, atof(e));
-    if (const char* e = getenv("OSC_BLK_EDGES")) h->blk_edges = std::max(0.5, atof(e));
-    if (const char* e = getenv("OSC_BLK_INIT")) {
-      h->blk_init = atoi(e) != 0;
-      h->blk_init_fused = atoi(e) == 1;
-    }
-    if (const char* e = getenv("OSC_SPMM_DEEP")) h->spmm_deep = atoi(e) != 0;
-    if (const char* e = getenv("OSC_TEMPORAL_MB")) h->temporal_mb = std::max(0.0, atof(e));
-    if (const char* e = getenv("OSC_MAPPED_RES")) h->mapped_residual = atoi(e) != 0;
-    if (const char* e = getenv("OSC_COMM_OVERLAP")) h->comm_overlap = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("OSC_X_DEFER")) {
-      h->x_defer = atoi(e) != 0;
-      h->x_last_form = atoi(e) == 1;
-    }
-    if (const char* e = getenv("OSC_SMALL_PATH")) h->small_path = atoi(e) != 0;
-    if (const char* e = getenv("OSC_REORDER")) h->reorder = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("OSC_SHARD")) h->shard_mode = !strcmp(e, "row") ? 1 : 0;
-    if (const char* e = getenv("OSC_ROW_FAKE_SHARDS")) h->fake_row_shards = std::max(0, atoi(e));
-    if (const char* e = getenv("OSC_FAKE_COL_SHARD")) {  // "r/w": work on rank r's column slab of w, no communicator
-      int r = 0, w = 1;                                   // (measurement hook: one rank's share of a column-sharded solve)
-      if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) {
-        std::tie(h->c0, h->c1) = host::column_shard(h->dcols, r, w);
-        if (h->c1 <= h->c0) throw Invalid("OSC_FAKE_COL_SHARD: more ranks than 4-column groups");
-      }
+    read_env(*h);
+    if (h->fake_col_w > 0) {  // measurement hook: work on rank r's column slab of w, no communicator
+      std::tie(h->c0, h->c1) = host::column_shard(h->dcols, h->fake_col_r, h->fake_col_w);
+      if (h->c1 <= h->c0) throw Invalid("OSC_FAKE_COL_SHARD: more ranks than 4-column groups");
     }
     const size_t n = (size_t)N * h->ld;
     for (DevBuf<float>* b : {&h->Y, &h->U, &h->X, &h->R, &h->P, &h->AP, &h->Ustar}) b->alloc(n);
@@ -2262,6 +2291,7 @@ int osc_destroy(osc_handle h) {
 int osc_rebuild_graph(osc_handle h, int32_t k, float row_cap, int32_t deterministic, int64_t seed) {
   return guarded(h, [&](L& l) {
     if (k < 1) throw Invalid("kneighbors must be >= 1");
+    read_env(l);
     l.k_eff = (int32_t)std::min<int64_t>(k, std::max<int64_t>(1, l.N - 1));
     l.row_cap = row_cap;
     l.deterministic = deterministic;
@@ -3238,14 +3268,10 @@ int osc_comm_init(osc_handle h, const char id[128], int32_t rank, int32_t world)
       l.c0 = 0;
       l.c1 = l.dcols;
     }
-    if (world == 1 && l.shard_mode == 0)  // measurement hook (osc_create): one rank's window of a wider solve, now WITH the
-      if (const char* e = getenv("OSC_FAKE_COL_SHARD")) {  // communicator machinery of a sharded solve around it
-        int r = 0, w = 1;
-        if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) {
-          std::tie(l.c0, l.c1) = host::column_shard(l.dcols, r, w);
-          l.fake_window = w > 1;  // osc_comm_info then says so: this handle solves ONE window's columns only
-        }
-      }
+    if (world == 1 && l.shard_mode == 0 && l.fake_col_w > 0) {  // measurement hook (OSC_FAKE_COL_SHARD, read at osc_create): one
+      std::tie(l.c0, l.c1) = host::column_shard(l.dcols, l.fake_col_r, l.fake_col_w);  // rank's window of a wider solve, now WITH
+      l.fake_window = l.fake_col_w > 1;  // the communicator machinery around it; osc_comm_info says so
+    }
     if (l.c1 <= l.c0) throw Invalid("osc_comm_init: more ranks than 4-column groups");
     l.comm = comm_create(id, rank, world, l.device);
     ++l.graph_epoch;

@@ -1363,3 +1363,52 @@ def test_deferred_x_update_leaves_the_same_state_at_every_stop_point(amd, path, 
         for (ia, ha, Ua), (ib, hb, Ub) in zip(a, run(other)):
             assert ia == ib and ha == hb
             assert np.array_equal(Ua, Ub)
+
+
+def test_panel_planner_overrides_give_the_same_lattice(amd, monkeypatch):
+    """OSC_KNN_PANEL_T / _RHO / _NRG move the half sweep's chunk length, the sample density of the thresholds and the row
+    groups per wave; the lattice is the one of the planner's own choice (and of the exact route) whatever they say."""
+    rng = np.random.default_rng(5)
+    N, D, k = 18000, 320, 16
+    Y = rng.standard_normal((N, D), dtype=np.float32)
+    monkeypatch.setenv("OSC_KNN_MODE", "panel")
+    want = None
+    for env in ({}, {"OSC_KNN_PANEL_T": "4"}, {"OSC_KNN_PANEL_RHO": "16"}, {"OSC_KNN_PANEL_NRG": "1"},
+                {"OSC_KNN_PANEL_NRG": "1", "OSC_KNN_PANEL_T": "9", "OSC_KNN_PANEL_SYM": "0"}):
+        for v in ("OSC_KNN_PANEL_T", "OSC_KNN_PANEL_RHO", "OSC_KNN_PANEL_NRG", "OSC_KNN_PANEL_SYM"):
+            monkeypatch.delenv(v, raising=False)
+        for v, val in env.items():
+            monkeypatch.setenv(v, val)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        assert lat.build_info()["prefilter"] == 2 and lat.build_info()["fallback_rows"] <= 8
+        g = lat.graph_csr()[:3]
+        lat.close()
+        if want is None:
+            want = g
+        else:
+            assert np.array_equal(g[0], want[0]) and np.array_equal(g[1], want[1]) and np.array_equal(g[2], want[2]), env
+
+
+def test_pool_off_and_planner_overrides():
+    """OSC_POOL_MB=0 (process-wide: plain hipMalloc / hipFree per block) in a process of its own: create / settle / destroy
+    twice, same results as with the pool."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import numpy as np, sys\n"
+            "from oscillink_amd import Oscillink\n"
+            "Y = np.random.default_rng(0).standard_normal((3000, 64)).astype(np.float32)\n"
+            "out = []\n"
+            "for _ in range(2):\n"
+            "    lat = Oscillink(Y, kneighbors=8, deterministic_k=True); lat.set_query(Y[0]); st = lat.settle(); out.append((st['iters'], float(lat.U.sum()))); lat.close()\n"
+            "assert out[0] == out[1], out\n"
+            "print(out[0][0], repr(out[0][1]))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mb in ("0", "16384"):
+        r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "OSC_POOL_MB": mb, "PYTHONPATH": root},
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        res[mb] = r.stdout.strip()
+    assert res["0"] == res["16384"]
