@@ -480,6 +480,272 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// ---- the same thresholds-and-hits prefilter on a GEMM core that takes ANY depth: D > 768 ------------------------------
+// A 32-row panel of more than 768 halfs does not fit a wave's registers, so here BOTH operands go through LDS: the
+// 128 x 128 tile of the tile prefilter (knn_kernels.hip: k_knn_pref -- A tile + B tile of one 64-half K step per stage by
+// LDS-DMA, two stages, one barrier per K step, the flat (column tile, K step) loop that keeps the next tile's first step
+// in flight during the epilogue, two workgroups per CU), with k_panel's epilogues instead of the sorted register lists:
+// MODE 0 tile-group maxima of the sample sweep, MODE 1 the symmetric half sweep -- threshold test of every accumulator
+// against its row's and its column's tau, hits appended to per-wave LDS lists, delivered to the 32-row buckets at the
+// end of the item.  Config 5's build (200k x 1536, k 64) spent 227 of its 257 ms in the list-maintaining full sweep of
+// k_knn_pref; this sweep visits half the tiles and inserts nothing.  LDS: 64 KB of stages + 4 x TH_CAP entries + a
+// threshold window of TT_TILES tiles = 78 KB, two workgroups per CU.
+constexpr int TH_CAP = 320;
+constexpr int TT_TILES = 8;
+constexpr unsigned TILE_STAGE = (128 + 128) * 128;  // bytes of one stage: A tile, then B tile
+constexpr size_t TILE_LDS = (size_t)2 * TILE_STAGE;
+constexpr size_t TILE_LDS_HITS = TILE_LDS + (size_t)4 * TH_CAP * 8 + (size_t)TT_TILES * 512;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_tile_thr(const PanelArgs a, const int nkt) {
+  extern __shared__ __attribute__((aligned(1024))) float lds[];
+  __shared__ int s_item, s_chunk, s_first;
+  __shared__ __attribute__((aligned(16))) float s_tau[4][2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int frow = lane >> 3;
+  const int swz = (l31 >> 1) & 7;
+  const unsigned lds_base = (unsigned)(size_t)lds;
+  const char* ldsc = reinterpret_cast<const char*>(lds);
+  uint2* const hitbuf = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds) + TILE_LDS) + wave * TH_CAP;
+  float* const s_tc = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + TILE_LDS + (size_t)4 * TH_CAP * 8);
+  const size_t ldh = (size_t)a.ldh;
+  auto chunk_sets = [&](int c) { return min(a.ntileB, (c + 1) * a.T); };
+  int nitems = a.rb_count * a.S;
+  if constexpr (MODE == 1) {
+    nitems = 0;
+    for (int c = 0; c < a.nchunks; ++c) nitems += chunk_sets(c);
+  }
+  auto glds16 = [&](const _Float16* src, unsigned dst_bytes) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst_bytes)
+                 : "memory");
+  };
+  for (;;) {
+    if (tid == 0) {
+      const int it = (int)atomicAdd(a.queue, 1u);
+      s_item = it;
+      if constexpr (MODE == 1) {
+        int c = a.nchunks - 1, first = 0;
+        if (it < nitems)
+          while (it >= first + chunk_sets(c)) first += chunk_sets(c), --c;
+        s_chunk = c;
+        s_first = first;
+      }
+    }
+    __syncthreads();
+    const int item = s_item;
+    const int chunk = MODE == 1 ? s_chunk : 0;
+    const int first_item = MODE == 1 ? s_first : 0;
+    __syncthreads();
+    if (item >= nitems) break;
+    int split, rbi, t0, t1;
+    if constexpr (MODE == 1) {
+      split = chunk;
+      rbi = item - first_item;
+      t1 = min(a.ntileB, (chunk + 1) * a.T);
+      t0 = max(chunk * a.T, rbi);
+    } else {
+      split = item / a.rb_count;
+      rbi = item - split * a.rb_count;
+      t0 = split * a.tiles_per_split;
+      t1 = min(a.ntileB, t0 + a.tiles_per_split);
+    }
+    const int rb = a.rb_begin + rbi;
+    if (t0 >= t1) continue;
+    float taug[16];
+    int wcnt = 0;
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) taug[g] = -3.0e38f;
+    } else {
+      if (l31 < 16) s_tau[wave][h][l31] = a.tau[rb * 128 + 32 * wave + 4 * h + (l31 & 3) + 8 * (l31 >> 2)];
+      for (int e = tid; e < (t1 - t0) * 128; e += 256) {  // the chunk's column thresholds: [tile][lane][subtile]
+        const int col = t0 * 128 + e;
+        s_tc[(e >> 7) * 128 + (e & 31) * 4 + ((e >> 5) & 3)] = col < a.N ? a.tau[col] : 3.0e38f;
+      }
+    }
+    // LDS-DMA sources of this wave's pieces: rows 32 wave + 8 q + frow of the A and of the B tile, swizzled chunk
+    const _Float16* a_src[4];
+    const _Float16* b_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t off = (size_t)(32 * wave + 8 * q + frow) * ldh + ((lane & 7) ^ (((q & 1) << 2) | (frow >> 1))) * 8;
+      a_src[q] = a.A + (size_t)rb * 128 * ldh + off;
+      b_src[q] = a.B + off;
+    }
+    auto issue = [&](int stage, int ct, int kt) {
+      const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)stage * TILE_STAGE + (unsigned)(32 * wave) * 128u);
+      const unsigned b_dst = a_dst + 128u * 128u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds16(a_src[q] + kt * 64, a_dst + (unsigned)(8 * q) * 128u);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds16(b_src[q] + (size_t)ct * 128 * ldh + kt * 64, b_dst + (unsigned)(8 * q) * 128u);
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+    // ---- k_panel's hit test (one row group, both sides) -----------------------------------------------------------------
+    auto row_mask = [&](auto GC, const float(&tg)[16], const float(&tc)[4]) -> unsigned long long {
+      constexpr int g = decltype(GC)::value;
+      bool any = fmaxf(fmaxf(acc[0][g], acc[1][g]), fmaxf(acc[2][g], acc[3][g])) > tg[g];
+      any = any | (fmaxf(fmaxf(acc[0][g] - tc[0], acc[1][g] - tc[1]), fmaxf(acc[2][g] - tc[2], acc[3][g] - tc[3])) > 0.f);
+      return __ballot(any);
+    };
+    auto hit_rows = [&](auto GC, const float(&tg)[16], const float(&tc)[4], int pct) {
+      constexpr int g = decltype(GC)::value;
+      const int rl = (g & 3) + 8 * (g >> 2) + 4 * h;
+      const int grow = rb * 128 + 32 * wave + rl;
+      const int cbase = pct * 128 + l31;
+      const bool special = pct == rb || (pct + 1) * 128 > a.N;
+      unsigned long long mk[4];
+      unsigned side[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bool pred = acc[t][g] > tg[g];
+        if (special) pred = pred && (cbase + 32 * t) != grow && (cbase + 32 * t) < a.N;
+        const bool cp = acc[t][g] > tc[t];
+        side[t] = (pred ? ROW_SIDE : 0u) | (cp ? COL_SIDE : 0u);
+        mk[t] = __ballot(pred | cp);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (mk[t] == 0ull) continue;
+        const bool pred = (mk[t] >> lane) & 1ull;
+        const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[t] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[t], 0u));
+        if (pred && pos < TH_CAP)
+          hitbuf[pos] = make_uint2(((unsigned)rl << 27) | side[t] | (unsigned)(cbase + 32 * t), __float_as_uint(acc[t][g]));
+        wcnt += __popcll(mk[t]);
+      }
+    };
+    // ---- flat (column tile, K step) pipeline: step s computes from stage s & 1 while step s + 1 lands in the other ------
+    const int total = (t1 - t0) * nkt;
+    int ct = t0, kt = 0, ict = t0, ikt = 0, issued = 0;
+    auto issue_next = [&]() {
+      issue(issued & 1, ict, ikt);
+      ++issued;
+      if (++ikt == nkt) {
+        ikt = 0;
+        ++ict;
+      }
+    };
+    issue_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int step = 0; step < total; ++step) {
+      const int stage = step & 1;
+      if (issued < total) issue_next();
+      const char* Asw = ldsc + (size_t)stage * TILE_STAGE + (size_t)(32 * wave + l31) * 128;
+      const char* Bsw = ldsc + (size_t)stage * TILE_STAGE + 128 * 128 + (size_t)l31 * 128;
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        const int co = ((2 * sl + h) ^ swz) * 16;
+        const half8 av = *reinterpret_cast<const half8*>(Asw + co);
+        half8 bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const half8*>(Bsw + (size_t)t * 32 * 128 + co);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[t], acc[t], 0, 0, 0);
+      }
+      if (kt == nkt - 1) {  // ---- the tile's accumulators are complete ----
+        if constexpr (MODE == 0) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g)
+            taug[g] = fmaxf(taug[g], fmaxf(fmaxf(acc[0][g], acc[1][g]), fmaxf(acc[2][g], acc[3][g])));
+          if ((ct + 1) % a.group_tiles == 0 || ct + 1 == t1) {
+            const int grp = ct / a.group_tiles;
+            const int grow0 = rb * 128 + 32 * wave + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              float m = taug[g];
+#pragma unroll
+              for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+              if (l31 == 0) a.tmax[(size_t)(grow0 + (g & 3) + 8 * (g >> 2)) * a.ngroups + grp] = m;
+              taug[g] = -3.0e38f;
+            }
+          }
+        } else {
+          float tg[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][h][4 * q]);
+            tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
+          }
+          float tc[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+          if (ct > rb) {
+            const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(ct - t0) * 128 + l31 * 4]);
+            tc[0] = c4[0], tc[1] = c4[1], tc[2] = c4[2], tc[3] = c4[3];
+          }
+          unsigned long long fm[16];
+          static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, tg, tc); });
+          static_for<0, 16>([&](auto GC) {
+            if (fm[decltype(GC)::value] != 0ull) hit_rows(GC, tg, tc, ct);
+          });
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
+        kt = 0;
+        ++ct;
+      } else {
+        ++kt;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next step has landed (and the epilogue's stores are out)
+      __syncthreads();                                   // ... and every wave is done reading this stage
+    }
+    if constexpr (MODE == 1) {  // deliver the wave's entries to the buckets of their receiving rows (as k_panel's half sweep)
+      const int nbl = (t1 - t0) * 4;
+      int* const s_cnt = reinterpret_cast<int*>(s_tc) + wave * (8 * TT_TILES);
+      int* const s_base = s_cnt + 4 * TT_TILES;
+      const int n = min(wcnt, TH_CAP);
+      const int own = rb * 4 + wave;
+      if (wcnt > TH_CAP && lane == 0) {
+        a.flags[chunk] = 1;
+        atomicAdd(&a.bucket_cnt[own], a.bucket_cap + 1);
+      }
+      for (int b = lane; b < nbl; b += 64) s_cnt[b] = 0;
+      int nrow = 0;
+      for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + lane;
+        const unsigned x = e < n ? hitbuf[e].x : 0u;
+        if (x & COL_SIDE) atomicAdd(&s_cnt[(int)((x & COL_MASK) >> 5) - t0 * 4], 1);
+        nrow += __popcll(__ballot((x & ROW_SIDE) != 0u));
+      }
+      int rbase = 0;
+      if (lane == 0 && nrow > 0) rbase = atomicAdd(&a.bucket_cnt[own], nrow);
+      for (int b = lane; b < nbl; b += 64) {
+        const int c = s_cnt[b];
+        s_base[b] = c > 0 ? atomicAdd(&a.bucket_cnt[t0 * 4 + b], c) : 0;
+        s_cnt[b] = 0;
+      }
+      rbase = __builtin_amdgcn_readfirstlane(rbase);
+      const unsigned irow0 = (unsigned)(rb * 128 + 32 * wave);
+      for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + lane;
+        const uint2 v = e < n ? hitbuf[e] : make_uint2(0u, 0u);
+        const bool rs = (v.x & ROW_SIDE) != 0u, cs = (v.x & COL_SIDE) != 0u;
+        const unsigned long long m = __ballot(rs);
+        const int rpos = rbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (rs && rpos < a.bucket_cap) a.bucket_ent[(size_t)own * a.bucket_cap + rpos] = make_uint2((v.x & ~COL_SIDE), v.y);
+        rbase += __popcll(m);
+        if (cs) {
+          const unsigned col = v.x & COL_MASK;
+          const int b = (int)(col >> 5) - t0 * 4;
+          const int cpos = s_base[b] + atomicAdd(&s_cnt[b], 1);
+          if (cpos < a.bucket_cap)
+            a.bucket_ent[(size_t)(col >> 5) * a.bucket_cap + cpos] = make_uint2(((col & 31u) << 27) | ROW_SIDE | (irow0 + (v.x >> 27)), v.y);
+        }
+      }
+    }
+    __syncthreads();  // the stages, the lists and the threshold window are free for the next item
+  }
+}
+
 // fp32 unit rows -> fp16 image of 16 * Yn, zero beyond (N, D)
 __global__ void k_panel_image(const float* Yn, int32_t ldn, _Float16* Yh, int32_t ldh, int32_t npad, int32_t N, int32_t D,
                               int32_t scatter) {
@@ -687,6 +953,15 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
 }
 
 template <int MODE>
+void launch_tile_thr(const PanelArgs& a, int nkt, int grid, hipStream_t s) {
+  constexpr size_t lds_bytes = MODE == 1 ? TILE_LDS_HITS : TILE_LDS;
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_thr<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes));
+  hipLaunchKernelGGL((k_tile_thr<MODE>), dim3(grid), dim3(256), lds_bytes, s, a, nkt);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <int MODE>
 void launch_panel(const PanelArgs& a, int nkt, int nrg, bool sym, int grid, hipStream_t s) {
 #define OSC_PANEL(NKT, NRG, SYM)                                                                                    \
   do {                                                                                                              \
@@ -716,6 +991,8 @@ void launch_panel(const PanelArgs& a, int nkt, int nrg, bool sym, int grid, hipS
 }  // namespace
 
 int knn_panel_nkt(int32_t D) { return D <= 384 ? 6 : D <= 768 ? 12 : 0; }
+// K steps of the tile core (both operands through LDS): any depth; used beyond 768 columns, up to 4096
+int knn_tile_nkt(int32_t D) { return (D > 768 && D <= 4096) ? (D + 63) / 64 : 0; }
 
 KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows, bool sym,
                             const KnnPanelTune& tune) {
@@ -736,6 +1013,11 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
     if (a < N) p.scatter = (int32_t)a;
   }
   p.nkt = knn_panel_nkt(D);
+  p.tile_core = false;
+  if (p.nkt == 0 && sym && knn_tile_nkt(D) != 0) {  // D > 768: the tile core under the same thresholds / buckets / select
+    p.nkt = knn_tile_nkt(D);
+    p.tile_core = true;
+  }
   p.ldh = 64 * p.nkt;
   // row groups per wave: two where the panel is small enough (D <= 384: 2 x 96 registers), see the file header
   p.nrg = (p.nkt == 6 && tune.nrg != 1) ? 2 : 1;
@@ -784,11 +1066,11 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
     // half sweep: column chunks of T tiles; a (wave, item) list takes the row-side AND the column-side hits of its tiles,
     // 2 x 32 rows x bound / nrb per tile, and should stay within ~2/3 of its LDS list; the item's column thresholds must
     // fit their LDS window (TC_TILES); T even where a set holds two row blocks (both then meet their diagonal in one chunk)
-    p.hit_cap = HB_CAP_SYM / p.nrg;
+    p.hit_cap = p.tile_core ? TH_CAP : HB_CAP_SYM / p.nrg;
     const double bound = std::max(5.0 * keep, 20.0 * rho);
     int T = (int)std::floor(0.66 * p.hit_cap * p.nrb / (64.0 * bound));
-    T = std::max(2, std::min(TC_TILES, T));
-    if (tune.T > 0) T = std::max(2, std::min(TC_TILES, tune.T));  // (A/B: tiles per chunk)
+    T = std::max(p.tile_core ? 1 : 2, std::min(p.tile_core ? TT_TILES : TC_TILES, T));
+    if (tune.T > 0) T = std::max(p.tile_core ? 1 : 2, std::min(p.tile_core ? TT_TILES : TC_TILES, tune.T));  // (A/B: tiles per chunk)
     if (p.nrg == 2) T &= ~1;
     p.T = T;
     p.S = (p.nrb + T - 1) / T;  // chunks
@@ -845,6 +1127,10 @@ void launch_panel_tilemax(const void* Yh, const void* Ys, const KnnPanelPlan& p,
   a.tmax = tmax;
   a.queue = queue;
   HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
+  if (p.tile_core) {
+    launch_tile_thr<0>(a, p.nkt, 2 * grid, s);
+    return;
+  }
   launch_panel<0>(a, p.nkt, p.nrg, false, grid, s);
 }
 
@@ -883,6 +1169,10 @@ void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int r
   a.hit_cap = p.hit_cap;
   a.queue = queue;
   HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
+  if (p.tile_core) {
+    launch_tile_thr<1>(a, p.nkt, 2 * grid, s);  // two workgroups per CU
+    return;
+  }
   launch_panel<1>(a, p.nkt, p.nrg, p.sym, grid, s);
 }
 

@@ -8,6 +8,8 @@ namespace osc {
 
 // K steps of 64 halfs the panel kernel is built for: 6 (D <= 384) or 12 (D <= 768); 0 = D not served by this route
 int knn_panel_nkt(int32_t D);
+// ... and of the tile core that serves 768 < D <= 4096 in single-process builds (0 = not served)
+int knn_tile_nkt(int32_t D);
 
 struct KnnPanelPlan {
   bool ok;             // the lattice is large enough for sampled thresholds (else: use the tile prefilter)
@@ -32,6 +34,7 @@ struct KnnPanelPlan {
   // (c + 1) T): nitems work items in all.  All hits are delivered to buckets of bucket_cap entries, one per group of 32
   // receiving rows (npad / 32 of them), which is all the select reads.
   bool sym;
+  bool tile_core;      // D > 768: both operands through LDS (k_tile_thr) instead of the register-resident panel; half sweep only
   int32_t T;
   int32_t nitems;
   int32_t bucket_cap;

@@ -957,9 +957,12 @@ void build_graph(L& h) {
   // register-resident sorted lists (k_knn_pref), which serves everything else.
   constexpr int panel_min = 16384;
   // (a hit entry packs the column index into 25 bits, next to its two side flags)
-  bool panel = prefilter && knn_panel_nkt(h.D) != 0 && N >= panel_min && N < (1 << 25) &&
-               knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, false, false, h.knn_tune).ok;
-  if (h.knn_mode == 3) panel = prefilter = (keep_f >= k + 8) && !any_k && knn_panel_nkt(h.D) != 0 && N >= 6144 && N < (1 << 25);
+  // (D > 768: the same route on the tile core, k_tile_thr -- half sweep only, so single-process builds only)
+  const bool sym_ok = h.knn_sym && parts == 1;
+  const bool depth_ok = knn_panel_nkt(h.D) != 0 || (sym_ok && knn_tile_nkt(h.D) != 0);
+  bool panel = prefilter && depth_ok && N >= panel_min && N < (1 << 25) &&
+               knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, false, sym_ok, h.knn_tune).ok;
+  if (h.knn_mode == 3) panel = prefilter = (keep_f >= k + 8) && !any_k && depth_ok && N >= 6144 && N < (1 << 25);
   if (h.knn_mode == 2) panel = false;
   h.knn_panel = panel;
   DevBuf<float> cand_val, cval;

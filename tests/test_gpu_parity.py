@@ -581,6 +581,8 @@ def test_config5_shape_gates_chain_properties(amd, orc):
     psi = Y[:32].mean(axis=0)
     psi = (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
     lat = amd.Oscillink(Y, kneighbors=k)
+    # (round 4: D > 768 builds through the thresholds-and-hits prefilter on the tile core, k_tile_thr, half sweep)
+    assert lat.build_info()["prefilter"] == 2 and lat.build_info()["fallback_rows"] <= 8
     rp, col, a, w, sd = lat.graph_csr()
     deg = np.diff(rp)
     assert deg.max() <= k and deg.min() >= 0 and a.min() > 0
@@ -1412,3 +1414,34 @@ def test_pool_off_and_planner_overrides():
         assert r.returncode == 0, r.stderr
         res[mb] = r.stdout.strip()
     assert res["0"] == res["16384"]
+
+
+@pytest.mark.parametrize("N,D,k", [(17000, 1000, 32), (20000, 1536, 64), (16400, 800, 8)])
+def test_tile_core_threshold_route_beyond_768_columns(amd, N, D, k, monkeypatch):
+    """D > 768: a wave's query panel no longer fits its registers, so the thresholds-and-hits prefilter runs on the tile core
+    (k_tile_thr: both operands through LDS, symmetric half sweep, hits to the 32-row buckets, same select / re-scoring /
+    proof).  Ragged D (1000 = 15.6 K steps), 24 K steps with keep = 96, a shallow k.  The lists are those of the tile
+    prefilter and of the all-fp32 kernel up to float64-proven near-ties."""
+    from tests._fullsize import near_tie_gap
+
+    rng = np.random.default_rng(N + D)
+    Y = rng.standard_normal((N, D), dtype=np.float32)
+    lists, info = {}, {}
+    for mode in ("panel", "prefilter", "exact"):
+        monkeypatch.setenv("OSC_KNN_MODE", mode)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        info[mode] = lat.build_info()
+        lists[mode] = _knn_sets(lat, N, k)
+        lat.close()
+    assert info["panel"]["prefilter"] == 2 and info["prefilter"]["prefilter"] == 1 and info["exact"]["prefilter"] == 0
+    # (k = 64 keeps 96 candidates: at 157 row blocks the column sample is too dense for thresholds that leave every row that
+    # many -- the planner would not choose this route here, forced it sends the short rows to the exact kernel)
+    assert info["panel"]["fallback_rows"] <= (8 if k <= 32 else N // 20)
+    for mode in ("panel", "prefilter"):
+        rows = np.nonzero((lists[mode] != lists["exact"]).any(axis=1))[0]
+        assert rows.size <= max(8, N // 2000), (mode, rows.size)
+        for r in rows:
+            members = sorted(set(lists[mode][r].tolist()) ^ set(lists["exact"][r].tolist()))
+            assert near_tie_gap(Y, int(r), members) < 1e-6, (mode, int(r), members)
+    # (the automatic choice needs a lattice large enough for sampled thresholds, as at D <= 768: config 5's full-size test,
+    # tests/test_gpu_fullsize.py, runs this route by default)
