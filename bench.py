@@ -667,8 +667,9 @@ def extras(lat, N, D, args, sharded):
     lat._call("osc_profile_enable", 0)
     info = lat.build_info()
     gemm_ms = total_ms.value / 3.0  # per build: the GEMM + selection kernels (panel route: sample sweep + thresholds + main sweep)
-    route = ("panel prefilter: fp16 MFMA GEMM (query panel in registers) + sampled thresholds + exact fp32 re-scoring"
-             if info["prefilter"] == 2 else
+    route = ("panel prefilter: fp16 MFMA GEMM (query panel in registers; tile core beyond 768 columns), sampled thresholds, "
+             "symmetric half sweep (row block I visits column tiles J >= I; 2 N^2 D flops are credited in full, as SURVEY 8d "
+             "counts them), exact fp32 re-scoring" if info["prefilter"] == 2 else
              "tile prefilter: fp16 MFMA top-(k+16) lists + exact fp32 re-scoring" if info["prefilter"] else
              "dense fp32 MFMA + argmax select" if N <= 8192 else "exact fp32 MFMA + running top-k")
     peak = MFMA_F16_DENSE_TFLOPS if info["prefilter"] else MFMA_F32_TFLOPS

@@ -67,16 +67,21 @@ constexpr size_t PANEL_LDS_HITS = PANEL_LDS + (size_t)4 * HB_CAP * 8;
 // the MFMA, LDS-fragment and LDS-DMA work of the sweep for about twice the hit test per visited tile.  The column
 // thresholds of an item's tiles wait in LDS (the per-lane tau[column] would otherwise be a vector load per tile on the
 // vmcnt queue the DMA ring is counted on): the same 56 KB behind the ring hold TC_TILES x 512 B of thresholds and four
-// hit lists of HB_CAP_SYM entries.  An entry carries two flags (bit 26: row side, bit 25: column side).  At the end of
-// an item a wave delivers its entries to global BUCKETS, one per group of 32 receiving rows (= one (row block, wave) of
+// hit lists of HB_CAP_SYM entries.  A delivered entry carries a flag (bit 26: a candidate of its receiving row).  At the end of
+// an item a wave delivers its hits to global BUCKETS, one per group of 32 receiving rows (= one (row block, wave) of
 // the select): the row-side ones to its own bucket behind one reservation, the column-side ones to the buckets of
 // their columns -- counted per bucket in LDS first (the item's tiles span at most 4 TC_TILES buckets), one returning
 // atomic per touched bucket, 64 buckets per wave instruction.  (A first version sent the column-side hits through one
 // global pool and counting-sorted it afterwards: 9.6 M same-address atomics made those two passes cost 2.7 ms at
 // config 3 -- more than the sweep saved at N = 20 000.)
-constexpr int TC_TILES = 44;
-constexpr int HB_CAP_SYM = 1056;
-static_assert((size_t)4 * HB_CAP_SYM * 8 + (size_t)TC_TILES * 512 <= (size_t)4 * HB_CAP * 8, "SYM layout must fit the hit area");
+// Round 4, second step: the epilogue no longer resolves WHICH of a query-row register's four subtile scores passed.  It
+// appends one COARSE entry per (row register, lane) whose union test fired -- {local row, tile of the item, lane} and the
+// four scores, 20 bytes -- behind ONE ballot per row register, and the flush, which runs once per item with a lane per
+// entry, takes the entries apart (row side / column side per score, the diagonal and the ragged tail).  Per visited tile
+// that is 16 scalar decisions instead of ~56 and ~8 instead of ~60 instructions per row register with a hit.
+constexpr int TC_TILES = 24;       // tiles per chunk the threshold window holds
+constexpr int HB_CAP_SYM = 560;    // coarse entries per wave
+static_assert((size_t)4 * HB_CAP_SYM * 20 + (size_t)TC_TILES * 512 <= (size_t)4 * HB_CAP * 8, "SYM layout must fit the hit area");
 constexpr unsigned ROW_SIDE = 1u << 26, COL_SIDE = 1u << 25, COL_MASK = (1u << 25) - 1u;
 
 struct PanelArgs {
@@ -142,7 +147,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const size_t ldh = (size_t)a.ldh;
   const size_t tile_stride = (size_t)128 * ldh;  // halfs between column tiles
-  float* const s_tc = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + PANEL_LDS + (size_t)4 * HB_CAP_SYM * 8);  // SYM: [tile of the item][lane 0..31][subtile 0..3]
+  // SYM: behind the ring [headers 4 x HB_CAP_SYM x 4 B][scores 4 x HB_CAP_SYM x 16 B][thresholds: tile of the item x lane 0..31 x subtile 0..3]
+  unsigned* const s_hdr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + PANEL_LDS);
+  v4f* const s_sc = reinterpret_cast<v4f*>(reinterpret_cast<char*>(lds) + PANEL_LDS + (size_t)4 * HB_CAP_SYM * 4);
+  float* const s_tc = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + PANEL_LDS + (size_t)4 * HB_CAP_SYM * 20);
   for (;;) {
     if (tid == 0) {
       const int it = (int)atomicAdd(a.queue, 1u);
@@ -387,7 +395,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               tc[0] = c4[0], tc[1] = c4[1], tc[2] = c4[2], tc[3] = c4[3];
             }
           }
-          hit_test_tile(acc[r], tg, tc, ct, rbv[r], hitbuf[r], wcnt[r]);
+          if constexpr (SYM) {
+            unsigned long long fm[16];
+            static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, acc[r], tg, tc); });
+            unsigned* const hd = s_hdr + (wave * NRG + r) * HCAP;
+            v4f* const sc = s_sc + (wave * NRG + r) * HCAP;
+            const unsigned tag = (unsigned)((ct - t0) << 5) | (unsigned)l31;
+            static_for<0, 16>([&](auto GC) {
+              constexpr int g = decltype(GC)::value;
+              const unsigned long long m = fm[g];
+              if (m != 0ull) {
+                const int pos = wcnt[r] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (((m >> lane) & 1ull) && pos < HCAP) {
+                  hd[pos] = ((unsigned)((g & 3) + 8 * (g >> 2) + 4 * h) << 10) | tag;
+                  sc[pos] = v4f{acc[r][0][g], acc[r][1][g], acc[r][2][g], acc[r][3][g]};
+                }
+                wcnt[r] += __popcll(m);
+              }
+            });
+          } else {
+            hit_test_tile(acc[r], tg, tc, ct, rbv[r], hitbuf[r], wcnt[r]);
+          }
         }
       }
     } else {
@@ -426,27 +454,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (lane == 0) a.hit_cnt[li] = wcnt[r];
       }
     }
-    if constexpr (SYM) {  // deliver the wave's entries to the buckets of their receiving rows
-      __syncthreads();    // every wave has finished its last tile: the threshold window becomes the waves' bucket counters
+    if constexpr (SYM) {  // take the coarse entries apart and deliver the hits to the buckets of their receiving rows
+      __syncthreads();    // every wave has finished its last tile: the ring (all landed, all read) holds the bucket counters now
       const int nbl = (t1 - t0) * 4;  // buckets the item's column tiles span: (t0 * 4 + b), b < nbl <= 4 TC_TILES
-      int* const s_cnt = reinterpret_cast<int*>(s_tc) + wave * (8 * TC_TILES);  // [2][4 TC_TILES]: counts / cursors, bases
+      int* const s_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + 2048) + wave * (8 * TC_TILES);  // [2][4 TC_TILES]: counts / cursors, bases
       int* const s_base = s_cnt + 4 * TC_TILES;
 #pragma unroll
       for (int r = 0; r < NRG; ++r) {
         if (!rok[r]) continue;
         const int n = min(wcnt[r], HCAP);
-        const int own = rbv[r] * 4 + wave;  // bucket of this wave's 32 rows
+        const int rb = rbv[r];
+        const int own = rb * 4 + wave;  // bucket of this wave's 32 rows
         if (wcnt[r] > HCAP && lane == 0) {  // dropped hits: row-side ones of these rows, column-side ones of any row of the chunk
           a.flags[chunk] = 1;
           atomicAdd(&a.bucket_cnt[own], a.bucket_cap + 1);
         }
+        const unsigned* const hd = s_hdr + (wave * NRG + r) * HCAP;
+        const v4f* const sc = s_sc + (wave * NRG + r) * HCAP;
+        const float* const taur = &s_tau[wave][r][0][0];  // [half][row register]
+        const int grow0 = rb * 128 + 32 * wave;
+        // one lane per coarse entry: score t of the entry is a candidate of its row (row side) and / or of its column
+        auto take_apart = [&](int e, int& rl, int& tl, int& l5, v4f& sv, bool (&rp)[4], bool (&cp)[4]) {
+          const bool valid = e < n;
+          const unsigned hdv = valid ? hd[e] : 0u;
+          rl = (int)(hdv >> 10);
+          tl = (int)((hdv >> 5) & 31u);
+          l5 = (int)(hdv & 31u);
+          sv = valid ? sc[e] : v4f{0.f, 0.f, 0.f, 0.f};
+          const int ct = t0 + tl;
+          const float trow = taur[((rl >> 2) & 1) * 16 + (rl & 3) + 4 * (rl >> 3)];
+          v4f tcv = v4f{3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+          if (valid && ct > rb) tcv = *reinterpret_cast<const v4f*>(&s_tc[tl * 128 + l5 * 4]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int col = ct * 128 + 32 * t + l5;
+            rp[t] = valid && sv[t] > trow && col != grow0 + rl && col < a.N;  // graph.py:37: no self-similarity; the ragged tail
+            cp[t] = valid && sv[t] > tcv[t];
+          }
+        };
         for (int b = lane; b < nbl; b += 64) s_cnt[b] = 0;
         int nrow = 0;
         for (int e0 = 0; e0 < n; e0 += 64) {  // (a wave's LDS accesses complete in order: no barrier between these passes)
-          const int e = e0 + lane;
-          const unsigned x = e < n ? hitbuf[r][e].x : 0u;
-          if (x & COL_SIDE) atomicAdd(&s_cnt[(int)((x & COL_MASK) >> 5) - t0 * 4], 1);
-          nrow += __popcll(__ballot((x & ROW_SIDE) != 0u));
+          int rl, tl, l5;
+          v4f sv;
+          bool rp[4], cp[4];
+          take_apart(e0 + lane, rl, tl, l5, sv, rp, cp);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            nrow += __popcll(__ballot(rp[t]));
+            if (cp[t]) atomicAdd(&s_cnt[tl * 4 + t], 1);
+          }
         }
         int rbase = 0;
         if (lane == 0 && nrow > 0) rbase = atomicAdd(&a.bucket_cnt[own], nrow);
@@ -456,22 +513,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           s_cnt[b] = 0;
         }
         rbase = __builtin_amdgcn_readfirstlane(rbase);
-        const unsigned irow0 = (unsigned)(rbv[r] * 128 + 32 * wave);
         for (int e0 = 0; e0 < n; e0 += 64) {
-          const int e = e0 + lane;
-          const uint2 v = e < n ? hitbuf[r][e] : make_uint2(0u, 0u);
-          const bool rs = (v.x & ROW_SIDE) != 0u, cs = (v.x & COL_SIDE) != 0u;
-          const unsigned long long m = __ballot(rs);
-          const int rpos = rbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-          if (rs && rpos < a.bucket_cap)
-            a.bucket_ent[(size_t)own * a.bucket_cap + rpos] = make_uint2((v.x & ~COL_SIDE), v.y);
-          rbase += __popcll(m);
-          if (cs) {
-            const unsigned col = v.x & COL_MASK;
-            const int b = (int)(col >> 5) - t0 * 4;
-            const int cpos = s_base[b] + atomicAdd(&s_cnt[b], 1);
-            if (cpos < a.bucket_cap)
-              a.bucket_ent[(size_t)(col >> 5) * a.bucket_cap + cpos] = make_uint2(((col & 31u) << 27) | ROW_SIDE | (irow0 + (v.x >> 27)), v.y);
+          int rl, tl, l5;
+          v4f sv;
+          bool rp[4], cp[4];
+          take_apart(e0 + lane, rl, tl, l5, sv, rp, cp);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const unsigned long long m = __ballot(rp[t]);
+            const int rpos = rbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (rp[t] && rpos < a.bucket_cap)
+              a.bucket_ent[(size_t)own * a.bucket_cap + rpos] =
+                  make_uint2(((unsigned)rl << 27) | ROW_SIDE | (unsigned)((t0 + tl) * 128 + 32 * t + l5), __float_as_uint(sv[t]));
+            rbase += __popcll(m);
+            if (cp[t]) {
+              const int b = tl * 4 + t;
+              const int cpos = s_base[b] + atomicAdd(&s_cnt[b], 1);
+              if (cpos < a.bucket_cap)
+                a.bucket_ent[(size_t)(t0 * 4 + b) * a.bucket_cap + cpos] =
+                    make_uint2(((unsigned)l5 << 27) | ROW_SIDE | (unsigned)(grow0 + rl), __float_as_uint(sv[t]));
+            }
           }
         }
       }
@@ -1080,6 +1141,9 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
     for (int c = 0; c < p.S; ++c) p.nitems += (std::min(p.nrb, (c + 1) * T) + p.nrg - 1) / p.nrg;
   }
   // phase A: splits of whole tile groups, again for the tail of the persistent grid
+  // (round 4: grouping a row's sample columns by (column split, lane) instead -- 32 running maxima per split, no shuffles and
+  // no stores inside the sweep -- took 0.14 ms off config 3's 1.8 ms sample sweep but moved the thresholds: 16 instead of 1
+  // rows short of candidates at N = 20000, config 4's build 412 -> 419 ms; not kept)
   best = 1e30;
   p.SA = 1;
   for (int S = 1; S <= 6 && S <= p.sample_groups; ++S) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential soak of the panel prefilter route (csrc/knn_gemm.hip) against the all-fp32 kernel on shapes and data the
 test suite does not cover: N 16k-60k (ragged, also exact multiples of 128), D 8-768 (both K depths, D = 384 / 385 at the
-boundary), k 1-64, i.i.d. / clustered / duplicated / scaled / grouped (cluster by cluster) anchors, zero rows.  Every edge present on one side only must
+boundary) and, every fifth case, 769-1600 (round 4: the same route on the tile core, k_tile_thr), k 1-64, i.i.d. / clustered / duplicated / scaled / grouped (cluster by cluster) anchors, zero rows.  Every edge present on one side only must
 be a rank-k near-tie of one of its end rows (gap below fp32 summation noise)."""
 import os
 import sys
@@ -15,12 +15,15 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 rng = np.random.default_rng(seed)
 bad = 0
-special = [(16384, 384, 16), (16385, 385, 8), (32768, 64, 1), (20000, 8, 5), (16400, 768, 64), (50000, 200, 33)]
+special = [(16384, 384, 16), (16385, 385, 8), (32768, 64, 1), (20000, 8, 5), (16400, 768, 64), (50000, 200, 33), (16384, 769, 12),
+           (30000, 1536, 40)]
 for t in range(count):
     if t < len(special):
         N, D, k = special[t]
     else:
         N, D, k = int(rng.integers(16384, 60000)), int(rng.integers(8, 769)), int(rng.integers(1, 65))
+        if t % 5 == 4:
+            D = int(rng.integers(769, 1601))
     kind = ("iid", "clustered", "dups", "scaled", "zeros", "grouped")[t % 6]
     if kind == "grouped":  # anchors handed over cluster by cluster (the row scatter of the prefilter image)
         C_ = int(rng.integers(40, 300))
