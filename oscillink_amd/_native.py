@@ -119,16 +119,25 @@ def device_count() -> int:
 
 
 _PINNED_MIN_BYTES = 8 << 20
+_result_sizes_seen: dict = {}
 
 
 def result_array(shape) -> np.ndarray:
     """An uninitialised float32 array for a device read-back.  Large ones live in pinned host memory from the library's
     pool (osc_host_alloc), so the read-back is one DMA with no host copy behind it; the block returns to the pool when
-    the array (and every view of it) is gone.  Small ones, and any failure to pin, give a plain `np.empty`."""
+    the array (and every view of it) is gone.  Pinning is slow (~55 ms for 300 MB, ~0.4 s for 1.2 GB; a pageable read-back
+    of those takes 20 / 150 ms), so the FIRST read-back of a size in a process gets a plain `np.empty` (a one-shot script
+    never pins) and pinned arrays start with the second, after which the pool recycles them.  Small arrays, and any
+    failure to pin, give `np.empty` as well.  OSC_PINNED_RESULTS=0 / =2: never / from the first read-back on."""
     import weakref
 
     n = int(np.prod(shape))
-    if n * 4 < _PINNED_MIN_BYTES or os.environ.get("OSC_PINNED_RESULTS", "1") == "0":
+    mode = os.environ.get("OSC_PINNED_RESULTS", "1")
+    if n * 4 < _PINNED_MIN_BYTES or mode == "0":
+        return np.empty(shape, dtype=np.float32)
+    seen = _result_sizes_seen.get(n, 0)
+    _result_sizes_seen[n] = seen + 1
+    if seen == 0 and mode != "2":
         return np.empty(shape, dtype=np.float32)
     p = C.c_void_p()
     if lib().osc_host_alloc(n * 4, C.byref(p)) != OSC_OK or not p.value:

@@ -459,7 +459,7 @@ void release_stage(int device, const StagePair& sp) {
 // solve_Ustar() return, so a read-back is ONE DMA at PCIe rate with no host copy and no page faults behind it.  Pinning
 // is slow (tens of ms for 300 MB), so freed arrays are parked per size class and handed out again; at most kHostParkBytes
 // stay parked.
-constexpr size_t kHostParkBytes = (size_t)2 << 30;
+constexpr size_t kHostParkBytes = (size_t)4 << 30;
 struct HostBlock {
   void* p;
   size_t bytes;
@@ -498,9 +498,16 @@ bool host_pool_free(void* p) {
     if (it == g_host_live.end()) return false;
     cap = it->second;
     g_host_live.erase(it);
-    if (g_host_parked_bytes + cap <= kHostParkBytes) {
+    if (cap <= kHostParkBytes) {  // park it; the blocks parked longest make room (a workload's current size class stays)
+      std::vector<void*> evict;
+      while (g_host_parked_bytes + cap > kHostParkBytes && !g_host_parked.empty()) {
+        evict.push_back(g_host_parked.front().p);
+        g_host_parked_bytes -= g_host_parked.front().bytes;
+        g_host_parked.erase(g_host_parked.begin());
+      }
       g_host_parked.push_back(HostBlock{p, cap});
       g_host_parked_bytes += cap;
+      for (void* q : evict) (void)hipHostFree(q);
       return true;
     }
   }

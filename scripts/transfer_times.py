@@ -35,7 +35,7 @@ def child(N, D, k):
     ok = bool(np.isfinite(U).all() and np.isfinite(Us).all() and abs(float(U[N // 2, 3])) > 0)
     ref = np.empty_like(U)
     os.environ["OSC_PINNED_DL_CHECK"] = "1"
-    print(f"N={N} D={D} pinned_dl={os.environ.get('OSC_PINNED_DL', '1')} threads={os.environ.get('OSC_COPY_THREADS', 'auto')}: "
+    print(f"N={N} D={D} pinned_results={os.environ.get('OSC_PINNED_RESULTS', '1')} pinned_dl={os.environ.get('OSC_PINNED_DL', '1')} threads={os.environ.get('OSC_COPY_THREADS', 'auto')}: "
           f"settle_ms={1e3 * np.median(ts):.2f} U_read_ms={1e3 * np.median(tu[1:]):.2f} (first {1e3 * tu[0]:.1f}) "
           f"refresh_Ustar_ms={1e3 * np.median(tr[1:]):.2f} (solve {lat.last_ustar['solve_ms']:.2f}) finite={ok} "
           f"checksum={float(U.astype(np.float64).sum()):.6e}", flush=True)
@@ -46,5 +46,6 @@ if __name__ == "__main__":
         child(*(int(x) for x in sys.argv[2:5]))
     else:
         cfg = sys.argv[1:4] if len(sys.argv) > 3 else ["100000", "768", "32"]
-        for env in ({"OSC_PINNED_DL": "0"}, {}, {"OSC_COPY_THREADS": "2"}, {"OSC_COPY_THREADS": "4"}, {"OSC_COPY_THREADS": "16"}):
+        for env in ({"OSC_PINNED_RESULTS": "0", "OSC_PINNED_DL": "0"}, {"OSC_PINNED_RESULTS": "0"},
+                    {"OSC_PINNED_RESULTS": "0", "OSC_COPY_THREADS": "4"}, {}, {"OSC_PINNED_RESULTS": "2"}):
             subprocess.run([sys.executable, os.path.abspath(__file__), "--child", *cfg], env={**os.environ, **env}, check=False)

@@ -510,6 +510,7 @@ def test_large_read_backs_pinned_and_staged_agree(amd, monkeypatch):
     lat = amd.Oscillink(Y, kneighbors=8)
     lat.set_query(Y[0] / np.linalg.norm(Y[0]))
     lat.settle(max_iters=6, tol=1e-3)
+    monkeypatch.setenv("OSC_PINNED_RESULTS", "2")  # pinned from the first read-back of a size (default: from the second)
     U_pinned = lat.U
     Us_pinned = lat.solve_Ustar()
     assert np.array_equal(lat.Y, Y)
@@ -520,7 +521,7 @@ def test_large_read_backs_pinned_and_staged_agree(amd, monkeypatch):
     U_staged = lat.U
     Us_staged = lat._download_ustar()
     assert U_staged is not U_pinned and np.array_equal(U_staged, U_pinned) and np.array_equal(Us_staged, Us_pinned)
-    monkeypatch.delenv("OSC_PINNED_RESULTS")
+    monkeypatch.setenv("OSC_PINNED_RESULTS", "2")
     lat.close()
     view = U_pinned[5:9]  # a view keeps the pinned block alive
     del U_pinned
