@@ -79,9 +79,14 @@ constexpr size_t PANEL_LDS_HITS = PANEL_LDS + (size_t)4 * HB_CAP * 8;
 // four scores, 20 bytes -- behind ONE ballot per row register, and the flush, which runs once per item with a lane per
 // entry, takes the entries apart (row side / column side per score, the diagonal and the ragged tail).  Per visited tile
 // that is 16 scalar decisions instead of ~56 and ~8 instead of ~60 instructions per row register with a hit.
+// The lists are a SOFT limit: a wave whose list is more than half full after a tile delivers it then and there (the
+// counters it needs are its own, behind the threshold window), so an item is as long as the window allows whatever the
+// hit density, and only a single tile that adds more than half a list can overflow (the overflow path stays: the rows
+// concerned go to the exact kernel).
 constexpr int TC_TILES = 24;       // tiles per chunk the threshold window holds
-constexpr int HB_CAP_SYM = 560;    // coarse entries per wave
-static_assert((size_t)4 * HB_CAP_SYM * 20 + (size_t)TC_TILES * 512 <= (size_t)4 * HB_CAP * 8, "SYM layout must fit the hit area");
+constexpr int HB_CAP_SYM = 520;    // coarse entries per wave
+constexpr size_t SYM_CNT_BYTES = (size_t)4 * 8 * TC_TILES * 4;  // per wave [2][4 TC_TILES] ints: bucket counts / cursors, bases
+static_assert((size_t)4 * HB_CAP_SYM * 20 + (size_t)TC_TILES * 512 + SYM_CNT_BYTES <= (size_t)4 * HB_CAP * 8, "SYM layout must fit the hit area");
 constexpr unsigned ROW_SIDE = 1u << 26, COL_SIDE = 1u << 25, COL_MASK = (1u << 25) - 1u;
 
 struct PanelArgs {
@@ -374,94 +379,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int q = 0; q < 4; ++q) bsrc[q] = nsrc[q];
     };
-    if constexpr (MODE == 1) {
-      for (int ct = t0; ct < t1; ++ct) {
-        k_loop(ct);
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the asm MFMAs' results -> VALU reads: hipcc pads nothing for asm
-#pragma unroll
-        for (int r = 0; r < NRG; ++r) {
-          if (!rok[r]) continue;
-          if (SYM && ct < rbv[r]) continue;  // (second row group of a set: the tile below its diagonal belongs to the first)
-          float tg[16];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][r][h][4 * q]);
-            tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
-          }
-          float tc[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-          if constexpr (SYM) {
-            if (ct > rbv[r]) {
-              const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(ct - t0) * 128 + l31 * 4]);
-              tc[0] = c4[0], tc[1] = c4[1], tc[2] = c4[2], tc[3] = c4[3];
-            }
-          }
-          if constexpr (SYM) {
-            unsigned long long fm[16];
-            static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, acc[r], tg, tc); });
-            unsigned* const hd = s_hdr + (wave * NRG + r) * HCAP;
-            v4f* const sc = s_sc + (wave * NRG + r) * HCAP;
-            const unsigned tag = (unsigned)((ct - t0) << 5) | (unsigned)l31;
-            static_for<0, 16>([&](auto GC) {
-              constexpr int g = decltype(GC)::value;
-              const unsigned long long m = fm[g];
-              if (m != 0ull) {
-                const int pos = wcnt[r] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (((m >> lane) & 1ull) && pos < HCAP) {
-                  hd[pos] = ((unsigned)((g & 3) + 8 * (g >> 2) + 4 * h) << 10) | tag;
-                  sc[pos] = v4f{acc[r][0][g], acc[r][1][g], acc[r][2][g], acc[r][3][g]};
-                }
-                wcnt[r] += __popcll(m);
-              }
-            });
-          } else {
-            hit_test_tile(acc[r], tg, tc, ct, rbv[r], hitbuf[r], wcnt[r]);
-          }
-        }
-      }
-    } else {
-      for (int ct = t0; ct < t1; ++ct) {
-        k_loop(ct);
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-        // ---- tile maxima of the sample sweep --------------------------------------------------------------------
-#pragma unroll
-        for (int r = 0; r < NRG; ++r) {
-#pragma unroll
-          for (int g = 0; g < 16; ++g)
-            taug[r][g] = fmaxf(taug[r][g], fmaxf(fmaxf(acc[r][0][g], acc[r][1][g]), fmaxf(acc[r][2][g], acc[r][3][g])));
-          if ((ct + 1) % a.group_tiles == 0 || ct + 1 == t1) {  // close the group: maximum over its columns
-            const int grp = ct / a.group_tiles;
-            const int grow0 = rbv[r] * 128 + 32 * wave + 4 * h;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-              float m = taug[r][g];
-#pragma unroll
-              for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));  // within the 32 lanes of the half
-              if (l31 == 0 && rok[r]) a.tmax[(size_t)(grow0 + (g & 3) + 8 * (g >> 2)) * a.ngroups + grp] = m;
-              taug[r][g] = -3.0e38f;
-            }
-          }
-        }
-      }
-    }
-    if constexpr (MODE == 1 && !SYM) {  // flush the wave's hit lists (coalesced 8-byte stores) and their counts
-#pragma unroll
-      for (int r = 0; r < NRG; ++r) {
-        if (!rok[r]) continue;
-        const size_t li = list_of(r) * 4 + wave;
-        const int n = min(wcnt[r], HCAP);
-        uint2* out = a.hit_list + li * (size_t)a.hit_cap;
-        for (int e = lane; e < n; e += 64) out[e] = hitbuf[r][e];
-        if (lane == 0) a.hit_cnt[li] = wcnt[r];
-      }
-    }
-    if constexpr (SYM) {  // take the coarse entries apart and deliver the hits to the buckets of their receiving rows
-      __syncthreads();    // every wave has finished its last tile: the ring (all landed, all read) holds the bucket counters now
-      const int nbl = (t1 - t0) * 4;  // buckets the item's column tiles span: (t0 * 4 + b), b < nbl <= 4 TC_TILES
-      int* const s_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + 2048) + wave * (8 * TC_TILES);  // [2][4 TC_TILES]: counts / cursors, bases
-      int* const s_base = s_cnt + 4 * TC_TILES;
-#pragma unroll
-      for (int r = 0; r < NRG; ++r) {
-        if (!rok[r]) continue;
+    // SYM: take the coarse entries of row group r apart and deliver the hits to the buckets of their receiving rows (a lane
+    // per entry).  Runs at the end of the item, and earlier whenever the list is more than half full.
+    const int nbl = (t1 - t0) * 4;  // buckets the item's column tiles span: (t0 * 4 + b), b < nbl <= 4 TC_TILES
+    int* const s_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + PANEL_LDS + (size_t)4 * HB_CAP_SYM * 20 + (size_t)TC_TILES * 512) +
+                       wave * (8 * TC_TILES);  // [2][4 TC_TILES]: counts / cursors, bases -- this wave's own
+    int* const s_base = s_cnt + 4 * TC_TILES;
+    auto deliver = [&](auto RC) {
+      constexpr int r = decltype(RC)::value;
+
         const int n = min(wcnt[r], HCAP);
         const int rb = rbv[r];
         const int own = rb * 4 + wave;  // bucket of this wave's 32 rows
@@ -535,6 +461,94 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
           }
         }
+          };
+    if constexpr (MODE == 1) {
+      for (int ct = t0; ct < t1; ++ct) {
+        k_loop(ct);
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the asm MFMAs' results -> VALU reads: hipcc pads nothing for asm
+#pragma unroll
+        for (int r = 0; r < NRG; ++r) {
+          if (!rok[r]) continue;
+          if (SYM && ct < rbv[r]) continue;  // (second row group of a set: the tile below its diagonal belongs to the first)
+          float tg[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][r][h][4 * q]);
+            tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
+          }
+          float tc[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+          if constexpr (SYM) {
+            if (ct > rbv[r]) {
+              const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(ct - t0) * 128 + l31 * 4]);
+              tc[0] = c4[0], tc[1] = c4[1], tc[2] = c4[2], tc[3] = c4[3];
+            }
+          }
+          if constexpr (SYM) {
+            unsigned long long fm[16];
+            static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, acc[r], tg, tc); });
+            unsigned* const hd = s_hdr + (wave * NRG + r) * HCAP;
+            v4f* const sc = s_sc + (wave * NRG + r) * HCAP;
+            const unsigned tag = (unsigned)((ct - t0) << 5) | (unsigned)l31;
+            static_for<0, 16>([&](auto GC) {
+              constexpr int g = decltype(GC)::value;
+              const unsigned long long m = fm[g];
+              if (m != 0ull) {
+                const int pos = wcnt[r] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (((m >> lane) & 1ull) && pos < HCAP) {
+                  hd[pos] = ((unsigned)((g & 3) + 8 * (g >> 2) + 4 * h) << 10) | tag;
+                  sc[pos] = v4f{acc[r][0][g], acc[r][1][g], acc[r][2][g], acc[r][3][g]};
+                }
+                wcnt[r] += __popcll(m);
+              }
+            });
+          } else {
+            hit_test_tile(acc[r], tg, tc, ct, rbv[r], hitbuf[r], wcnt[r]);
+          }
+        }
+        if constexpr (SYM) {  // the item's last tile, or a list more than half full: deliver now
+          static_for<0, NRG>([&](auto RC) {
+            constexpr int r = decltype(RC)::value;
+            if (rok[r] && (ct + 1 == t1 || wcnt[r] > HCAP / 2)) {
+              deliver(RC);
+              wcnt[r] = 0;
+            }
+          });
+        }
+      }
+    } else {
+      for (int ct = t0; ct < t1; ++ct) {
+        k_loop(ct);
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        // ---- tile maxima of the sample sweep --------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < NRG; ++r) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g)
+            taug[r][g] = fmaxf(taug[r][g], fmaxf(fmaxf(acc[r][0][g], acc[r][1][g]), fmaxf(acc[r][2][g], acc[r][3][g])));
+          if ((ct + 1) % a.group_tiles == 0 || ct + 1 == t1) {  // close the group: maximum over its columns
+            const int grp = ct / a.group_tiles;
+            const int grow0 = rbv[r] * 128 + 32 * wave + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              float m = taug[r][g];
+#pragma unroll
+              for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));  // within the 32 lanes of the half
+              if (l31 == 0 && rok[r]) a.tmax[(size_t)(grow0 + (g & 3) + 8 * (g >> 2)) * a.ngroups + grp] = m;
+              taug[r][g] = -3.0e38f;
+            }
+          }
+        }
+      }
+    }
+    if constexpr (MODE == 1 && !SYM) {  // flush the wave's hit lists (coalesced 8-byte stores) and their counts
+#pragma unroll
+      for (int r = 0; r < NRG; ++r) {
+        if (!rok[r]) continue;
+        const size_t li = list_of(r) * 4 + wave;
+        const int n = min(wcnt[r], HCAP);
+        uint2* out = a.hit_list + li * (size_t)a.hit_cap;
+        for (int e = lane; e < n; e += 64) out[e] = hitbuf[r][e];
+        if (lane == 0) a.hit_cnt[li] = wcnt[r];
       }
     }
     __syncthreads();  // every wave is done with the ring before the next item refills it
@@ -1123,13 +1137,15 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
     }
   }
   p.tiles_per_split = (p.nrb + p.S - 1) / p.S;
+  p.hit_bound = std::max(5.0 * keep, 20.0 * rho);
   if (sym) {
     // half sweep: column chunks of T tiles; a (wave, item) list takes the row-side AND the column-side hits of its tiles,
     // 2 x 32 rows x bound / nrb per tile, and should stay within ~2/3 of its LDS list; the item's column thresholds must
     // fit their LDS window (TC_TILES); T even where a set holds two row blocks (both then meet their diagonal in one chunk)
     p.hit_cap = p.tile_core ? TH_CAP : HB_CAP_SYM / p.nrg;
     const double bound = std::max(5.0 * keep, 20.0 * rho);
-    int T = (int)std::floor(0.66 * p.hit_cap * p.nrb / (64.0 * bound));
+    int T = (int)std::floor(0.66 * p.hit_cap * p.nrb / (64.0 * bound));  // (the tile core's lists are a hard limit)
+    if (!p.tile_core) T = TC_TILES;  // k_panel delivers a list that is half full: the threshold window alone limits an item
     T = std::max(p.tile_core ? 1 : 2, std::min(p.tile_core ? TT_TILES : TC_TILES, T));
     if (tune.T > 0) T = std::max(p.tile_core ? 1 : 2, std::min(p.tile_core ? TT_TILES : TC_TILES, tune.T));  // (A/B: tiles per chunk)
     if (p.nrg == 2) T &= ~1;
@@ -1254,8 +1270,10 @@ void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int3
     sy.flags = sd->flags;
   }
   // rows of one wave-of-32 a workgroup sorts: as many as keeps ~5 keep entries per row within 3/4 of its LDS array
+  // (per row: the planner's bound on the candidates its threshold lets through, max(5 keep, 20 rho) -- with 5 keep alone a
+  // sparse sample (large rho) or a small k overflowed the sort array and sent whole 32-row groups to the exact kernel)
   int nsub = 1;
-  while (nsub < 8 && 5.0 * p.keep * (32 / nsub) > 0.75 * SORT_CAP) nsub *= 2;
+  while (nsub < 32 && p.hit_bound * (32 / nsub) > 0.75 * SORT_CAP) nsub *= 2;
   hipLaunchKernelGGL(k_panel_select, dim3((unsigned)(rb_count * 4 * nsub)), dim3(256), 0, s,
                      static_cast<const uint2*>(hit_list), hit_cnt, p.hit_cap, p.S, rb_begin, rb_count, nsub, p.keep, N, p.scatter, cval, cidx,
                      fail_rows, fail_count, sy);

@@ -28,6 +28,7 @@ struct KnnPanelPlan {
   int32_t sample_tiles_per_split;
   int32_t hit_cap;     // entries of one hit list (one per work item and wave)
   int32_t keep;        // candidates handed to the exact re-scoring
+  double hit_bound;    // candidates per row the thresholds are expected to let through at most: max(5 keep, 20 rho)
   // Half sweep (single-process builds): the similarity matrix is symmetric bit for bit, so row block I visits only the
   // column tiles J >= I and every accumulator is tested against its row's AND its column's threshold.  The sweep is cut
   // into S column CHUNKS of T tiles (S, tiles_per_split = T above); chunk c is swept by the row blocks I < min(nrb,
