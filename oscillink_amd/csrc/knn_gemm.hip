@@ -79,10 +79,12 @@ constexpr size_t PANEL_LDS_HITS = PANEL_LDS + (size_t)4 * HB_CAP * 8;
 // four scores, 20 bytes -- behind ONE ballot per row register, and the flush, which runs once per item with a lane per
 // entry, takes the entries apart (row side / column side per score, the diagonal and the ragged tail).  Per visited tile
 // that is 16 scalar decisions instead of ~56 and ~8 instead of ~60 instructions per row register with a hit.
-// The lists are a SOFT limit: a wave whose list is more than half full after a tile delivers it then and there (the
-// counters it needs are its own, behind the threshold window), so an item is as long as the window allows whatever the
-// hit density, and only a single tile that adds more than half a list can overflow (the overflow path stays: the rows
-// concerned go to the exact kernel).
+// The lists are a SOFT limit: a wave delivers its list whenever the next tile's entries (counted from the union masks before
+// they are appended) would not fit -- the counters it needs are its own, behind the threshold window -- so an item is as
+// long as the window allows whatever the hit density, and only ONE tile that yields more than a whole list can overflow
+// (the overflow path stays: the rows concerned go to the exact kernel).  (Delivering a half-full list AFTER a tile was
+// not enough: at N = 40 000, D = 256 on clustered anchors a tile adds 39 entries on average to lists of 260, some tiles
+// five times that, and every overflow sends its chunk's 3072 rows to the exact kernel: 8768 fallback rows against 66.)
 constexpr int TC_TILES = 24;       // tiles per chunk the threshold window holds
 constexpr int HB_CAP_SYM = 520;    // coarse entries per wave
 constexpr size_t SYM_CNT_BYTES = (size_t)4 * 8 * TC_TILES * 4;  // per wave [2][4 TC_TILES] ints: bucket counts / cursors, bases
@@ -462,30 +464,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
         }
           };
-    if constexpr (MODE == 1) {
-      for (int ct = t0; ct < t1; ++ct) {
-        k_loop(ct);
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the asm MFMAs' results -> VALU reads: hipcc pads nothing for asm
+    if constexpr (MODE == 1 && SYM) {
+      // One more pass than tiles: the pass behind the last tile only delivers what the lists still hold.  A list is
+      // delivered BEFORE a tile's entries are appended whenever they would not fit (their count is known from the union
+      // masks), so no entry is ever dropped unless ONE tile alone yields more than a whole list.
+      for (int ct = t0; ct <= t1; ++ct) {
+        const bool flush_only = ct == t1;
+        if (!flush_only) {
+          k_loop(ct);
+          asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the asm MFMAs' results -> VALU reads: hipcc pads nothing for asm
+        }
+        static_for<0, NRG>([&](auto RC) {
+          constexpr int r = decltype(RC)::value;
+          if (!rok[r]) return;
+          const bool test = !flush_only && ct >= rbv[r];  // (second row group of a set: the tile below its diagonal belongs to the first)
+          unsigned long long fm[16];
+          int add = 0;
+          if (test) {
+            float tg[16];
 #pragma unroll
-        for (int r = 0; r < NRG; ++r) {
-          if (!rok[r]) continue;
-          if (SYM && ct < rbv[r]) continue;  // (second row group of a set: the tile below its diagonal belongs to the first)
-          float tg[16];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][r][h][4 * q]);
-            tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
-          }
-          float tc[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-          if constexpr (SYM) {
+            for (int q = 0; q < 4; ++q) {
+              const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][r][h][4 * q]);
+              tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
+            }
+            float tc[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
             if (ct > rbv[r]) {
               const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(ct - t0) * 128 + l31 * 4]);
               tc[0] = c4[0], tc[1] = c4[1], tc[2] = c4[2], tc[3] = c4[3];
             }
+            static_for<0, 16>([&](auto GC) {
+              fm[decltype(GC)::value] = row_mask(GC, acc[r], tg, tc);
+              add += __popcll(fm[decltype(GC)::value]);
+            });
           }
-          if constexpr (SYM) {
-            unsigned long long fm[16];
-            static_for<0, 16>([&](auto GC) { fm[decltype(GC)::value] = row_mask(GC, acc[r], tg, tc); });
+          if (wcnt[r] > 0 && (flush_only || wcnt[r] + add > HCAP)) {
+            deliver(RC);
+            wcnt[r] = 0;
+          }
+          if (test && add > 0) {
             unsigned* const hd = s_hdr + (wave * NRG + r) * HCAP;
             v4f* const sc = s_sc + (wave * NRG + r) * HCAP;
             const unsigned tag = (unsigned)((ct - t0) << 5) | (unsigned)l31;
@@ -501,18 +517,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 wcnt[r] += __popcll(m);
               }
             });
-          } else {
-            hit_test_tile(acc[r], tg, tc, ct, rbv[r], hitbuf[r], wcnt[r]);
           }
-        }
-        if constexpr (SYM) {  // the item's last tile, or a list more than half full: deliver now
-          static_for<0, NRG>([&](auto RC) {
-            constexpr int r = decltype(RC)::value;
-            if (rok[r] && (ct + 1 == t1 || wcnt[r] > HCAP / 2)) {
-              deliver(RC);
-              wcnt[r] = 0;
-            }
-          });
+        });
+      }
+    } else if constexpr (MODE == 1) {
+      for (int ct = t0; ct < t1; ++ct) {
+        k_loop(ct);
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the asm MFMAs' results -> VALU reads: hipcc pads nothing for asm
+#pragma unroll
+        for (int r = 0; r < NRG; ++r) {
+          if (!rok[r]) continue;
+          float tg[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][r][h][4 * q]);
+            tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
+          }
+          const float tc[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+          hit_test_tile(acc[r], tg, tc, ct, rbv[r], hitbuf[r], wcnt[r]);
         }
       }
     } else {
@@ -1027,6 +1049,103 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
   }
 }
 
+// ---- second-stage proof for rows the first re-scoring could not decide (half-sweep builds) ---------------------------
+// k_knn_rescore proves a row from its `keep` best candidates: "every left-out column has fp16 score <= the list's last".  On
+// clustered anchors that often fails -- the exact k-th score is not delta above the keep-th fp16 score -- and such rows used
+// to go to the all-fp32 kernel (4-6 ms for ~1 % of the rows of a 100k lattice).  But the row's BUCKET holds every column
+// whose fp16 score beat tau_row, so a far weaker statement is available: "every column outside the bucket has fp16 score
+// <= tau_row".  One wave per undecided row re-scores ALL its bucket candidates exactly (same products, same order and
+// butterfly as k_knn_rescore: bit-identical scores), takes the k best by (score desc, index asc) and accepts the row iff
+// tau_row / 256 + delta < its exact k-th score.  Rows it cannot decide either (fewer than k candidates, > WIDE_CAP, a
+// bucket that overflowed, a k-th score within delta of tau) stay on the list for the exact kernel.
+constexpr int WIDE_CAP = 1024;  // candidates of one row (= SEL_CAP)
+__global__ __launch_bounds__(256) void k_bucket_rescore(const float* __restrict__ Yn, int32_t ldn, int32_t N, const int32_t* rows_in,
+                                                        int32_t nrows, const uint2* bucket_ent, const int32_t* bucket_cnt,
+                                                        int32_t bucket_cap, const int32_t* flags, int32_t T, const float* tau,
+                                                        int32_t scatter, int64_t scatter_inv, int32_t k, float delta,
+                                                        float* out_val, int32_t* out_idx, int32_t* fail_rows, int32_t* fail_count) {
+  __shared__ int s_idx[4][WIDE_CAP];
+  __shared__ float s_sc[4][WIDE_CAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = blockIdx.x * 4 + wave;
+  if (slot >= nrows) return;
+  const int row = rows_in[slot];
+  auto give_up = [&]() {
+    if (lane == 0) fail_rows[atomicAdd(fail_count, 1)] = row;
+  };
+  const int irow = (int)(((int64_t)row * scatter_inv) % N);  // image row of this lattice row (KnnPanelPlan::scatter)
+  const int b = irow >> 5, rl = irow & 31;
+  const int raw = bucket_cnt[b];
+  if (raw > bucket_cap || flags[(irow >> 7) / T] != 0) {  // hits of this row were lost: nothing can be concluded from the bucket
+    give_up();
+    return;
+  }
+  // 1. the row's candidates (image columns -> lattice columns)
+  const uint2* ent = bucket_ent + (size_t)b * bucket_cap;
+  int n = 0;
+  for (int e0 = 0; e0 < raw; e0 += 64) {
+    const int e = e0 + lane;
+    const unsigned x = e < raw ? ent[e].x : 0u;
+    const bool mine = (x & ROW_SIDE) != 0u && (int)(x >> 27) == rl;
+    const unsigned long long m = __ballot(mine);
+    const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (mine && pos < WIDE_CAP) s_idx[wave][pos] = (int)(((int64_t)(x & COL_MASK) * scatter) % N);
+    n += __popcll(m);
+  }
+  if (n < k || n > WIDE_CAP) {
+    give_up();
+    return;
+  }
+  // 2. exact scores (k_knn_rescore's arithmetic: lanes stride the row, fmaf chain per lane, butterfly sum)
+  const float* yi = Yn + (size_t)row * ldn;
+  for (int q0 = 0; q0 < n; q0 += 4) {
+    float ss[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ss[u] = 0.f;
+      if (q0 + u < n) {
+        const float* yj = Yn + (size_t)s_idx[wave][q0 + u] * ldn;
+        float acc = 0.f;
+        for (int c = lane * 4; c < ldn; c += 256) {
+          const float4 a = *reinterpret_cast<const float4*>(yi + c), bb = *reinterpret_cast<const float4*>(yj + c);
+          acc = fmaf(a.x, bb.x, acc);
+          acc = fmaf(a.y, bb.y, acc);
+          acc = fmaf(a.z, bb.z, acc);
+          acc = fmaf(a.w, bb.w, acc);
+        }
+        ss[u] = acc;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ss[u] += __shfl_xor(ss[u], o, 64);
+      if (lane == 0 && q0 + u < n) s_sc[wave][q0 + u] = ss[u];
+    }
+  }
+  // 3. rank of every candidate among all (score desc, index asc); the k best are the row's list
+  float tk = -3.0e38f;
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    const int c = c0 + lane;
+    const float sv = c < n ? s_sc[wave][c] : 0.f;
+    const int iv = c < n ? s_idx[wave][c] : 0;
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float ov = s_sc[wave][j];
+      const int oi = s_idx[wave][j];
+      rank += (ov > sv || (ov == sv && oi < iv)) ? 1 : 0;
+    }
+    if (c < n && rank < k) {
+      out_val[(size_t)row * k + rank] = fmaxf(sv, 0.f);
+      out_idx[(size_t)row * k + rank] = iv;
+      if (rank == k - 1) tk = sv;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tk = fmaxf(tk, __shfl_xor(tk, o, 64));
+  if (!(tau[irow] * (1.0f / 256.0f) + delta < tk)) give_up();
+}
+
 template <int MODE>
 void launch_tile_thr(const PanelArgs& a, int nkt, int grid, hipStream_t s) {
   constexpr size_t lds_bytes = MODE == 1 ? TILE_LDS_HITS : TILE_LDS;
@@ -1137,13 +1256,22 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
     }
   }
   p.tiles_per_split = (p.nrb + p.S - 1) / p.S;
-  p.hit_bound = std::max(5.0 * keep, 20.0 * rho);
+  // Candidates a row's threshold lets through, in expectation: tau is the r-th largest of G group maxima, so r of G groups
+  // hold a sample column above it; with lambda such columns per group, 1 - exp(-lambda) = r / G, and every sample column
+  // stands for nrb / sample_tiles columns of the sweep.  G = 65 (config 3): 190 (the "16 rho" of round 2); G = 26 (N = 40 000):
+  // 242 -- a bound of max(5 keep, 20 rho) = 240 then sized the 32-row buckets below their mean load and sent whole
+  // buckets to the exact kernel (8768 fallback rows on clustered anchors at N = 40 000, D = 256, k = 24).
+  {
+    const double G = (double)p.sample_groups, r = std::min((double)p.sample_rank, 0.95 * G);
+    const double mean_hits = (double)p.nrb / p.sample_tiles * G * -std::log(1.0 - r / G);
+    p.hit_bound = std::max(std::max(5.0 * keep, 20.0 * rho), 1.25 * mean_hits);
+  }
   if (sym) {
     // half sweep: column chunks of T tiles; a (wave, item) list takes the row-side AND the column-side hits of its tiles,
     // 2 x 32 rows x bound / nrb per tile, and should stay within ~2/3 of its LDS list; the item's column thresholds must
     // fit their LDS window (TC_TILES); T even where a set holds two row blocks (both then meet their diagonal in one chunk)
     p.hit_cap = p.tile_core ? TH_CAP : HB_CAP_SYM / p.nrg;
-    const double bound = std::max(5.0 * keep, 20.0 * rho);
+    const double bound = p.hit_bound;
     int T = (int)std::floor(0.66 * p.hit_cap * p.nrb / (64.0 * bound));  // (the tile core's lists are a hard limit)
     if (!p.tile_core) T = TC_TILES;  // k_panel delivers a list that is half full: the threshold window alone limits an item
     T = std::max(p.tile_core ? 1 : 2, std::min(p.tile_core ? TT_TILES : TC_TILES, T));
@@ -1152,7 +1280,7 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
     p.T = T;
     p.S = (p.nrb + T - 1) / T;  // chunks
     p.tiles_per_split = T;
-    p.bucket_cap = (int32_t)(32.0 * bound);  // a group of 32 rows may receive all its candidates here (the last rows: all column-side)
+    p.bucket_cap = (int32_t)(32.0 * 1.5 * bound);  // a group of 32 rows receives all its candidates here; 1.5: rows of a group vary, clustered anchors have heavy tails
     p.nitems = 0;
     for (int c = 0; c < p.S; ++c) p.nitems += (std::min(p.nrb, (c + 1) * T) + p.nrg - 1) / p.nrg;
   }
@@ -1277,6 +1405,29 @@ void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int3
   hipLaunchKernelGGL(k_panel_select, dim3((unsigned)(rb_count * 4 * nsub)), dim3(256), 0, s,
                      static_cast<const uint2*>(hit_list), hit_cnt, p.hit_cap, p.S, rb_begin, rb_count, nsub, p.keep, N, p.scatter, cval, cidx,
                      fail_rows, fail_count, sy);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_bucket_rescore(const KnnPanelPlan& p, const KnnPanelSymDev& sd, const float* Yn, int32_t ldn, int32_t N,
+                           const int32_t* rows_in, int32_t nrows, const float* tau, int32_t k, float delta, float* out_val,
+                           int32_t* out_idx, int32_t* fail_rows, int32_t* fail_count, hipStream_t s) {
+  if (nrows <= 0) return;
+  // inverse of the row scatter modulo N (extended Euclid; scatter is coprime to N, 1 = identity)
+  int64_t inv = 1;
+  if (p.scatter != 1) {
+    int64_t t = 0, nt = 1, r = N, nr = p.scatter % N;
+    while (nr != 0) {
+      const int64_t q = r / nr;
+      std::swap(t, nt);
+      nt -= q * t;
+      std::swap(r, nr);
+      nr -= q * r;
+    }
+    inv = ((t % N) + N) % N;
+  }
+  hipLaunchKernelGGL(k_bucket_rescore, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, Yn, ldn, N, rows_in, nrows,
+                     static_cast<const uint2*>(sd.bucket_ent), sd.bucket_cnt, p.bucket_cap, sd.flags, p.T, tau, p.scatter, inv, k,
+                     delta, out_val, out_idx, fail_rows, fail_count);
   HIP_CHECK(hipGetLastError());
 }
 

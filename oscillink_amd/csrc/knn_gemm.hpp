@@ -91,4 +91,10 @@ void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int3
                          const int32_t* hit_cnt, float* cval, int32_t* cidx, int32_t* fail_rows, int32_t* fail_count,
                          hipStream_t s, const KnnPanelSymDev* sd = nullptr);
 
+// Half-sweep builds: rows the first re-scoring could not prove (rows_in, nrows) are re-scored against EVERY candidate of
+// their bucket and proven against tau_row instead of the list's last score; rows still undecided are appended to fail_rows
+void launch_bucket_rescore(const KnnPanelPlan& p, const KnnPanelSymDev& sd, const float* Yn, int32_t ldn, int32_t N,
+                           const int32_t* rows_in, int32_t nrows, const float* tau, int32_t k, float delta, float* out_val,
+                           int32_t* out_idx, int32_t* fail_rows, int32_t* fail_count, hipStream_t s);
+
 }  // namespace osc

@@ -1095,18 +1095,30 @@ void build_graph(L& h) {
     int32_t nfail = 0;
     HIP_CHECK(hipMemcpyAsync(&nfail, fail_count.p, 4, hipMemcpyDeviceToHost, h.stream));
     sync(h);
+    DevBuf<int32_t> fail_rows2, fail_count2;
+    int32_t* fail_list = fail_rows.p;
+    if (panel && pp.sym && nfail > 0) {  // second-stage proof from the rows' whole buckets (knn_gemm.hip: k_bucket_rescore)
+      fail_rows2.alloc((size_t)nfail);
+      fail_count2.alloc(1);
+      HIP_CHECK(hipMemsetAsync(fail_count2.p, 0, 4, h.stream));
+      launch_bucket_rescore(pp, sym_dev, Yn.p, ldn, N, fail_rows.p, nfail, p_tau.p, k, delta, h.knn_val.p, h.knn_idx.p,
+                            fail_rows2.p, fail_count2.p, h.stream);
+      HIP_CHECK(hipMemcpyAsync(&nfail, fail_count2.p, 4, hipMemcpyDeviceToHost, h.stream));
+      sync(h);
+      fail_list = fail_rows2.p;
+    }
     h.knn_fallback_rows = nfail;
     bool few_done = false;
     if (nfail > 0 && nfail <= 32) {  // a handful of rows: stream the columns once, select per row (0.15 vs 3.9 ms at N = 100k)
       const int32_t ldS = ((N + 31) / 32) * 32;
       DevBuf<float> Sm;
       Sm.alloc((size_t)nfail * ldS);
-      few_done = launch_knn_few_rows(Yn.p, ldn, N, k, fail_rows.p, nfail, Sm.p, ldS, h.knn_val.p, h.knn_idx.p, h.stream);
+      few_done = launch_knn_few_rows(Yn.p, ldn, N, k, fail_list, nfail, Sm.p, ldS, h.knn_val.p, h.knn_idx.p, h.stream);
       if (few_done) sync(h);  // Sm goes back to the pool at scope exit
     }
     if (nfail > 0 && !few_done) {  // redo the unproven rows with the exact kernel (ties / dense clusters of near-equal scores)
       KnnPlan plan = knn_plan(N, k, slots, 0, (nfail + 127) / 128, false, h.knn_splits);
-      plan.qrows = fail_rows.p;
+      plan.qrows = fail_list;
       plan.nq = nfail;
       const size_t ncand = (size_t)h.N * plan.S * plan.KC;
       cand_val.alloc(ncand);

@@ -1445,3 +1445,28 @@ def test_tile_core_threshold_route_beyond_768_columns(amd, N, D, k, monkeypatch)
             assert near_tie_gap(Y, int(r), members) < 1e-6, (mode, int(r), members)
     # (the automatic choice needs a lattice large enough for sampled thresholds, as at D <= 768: config 5's full-size test,
     # tests/test_gpu_fullsize.py, runs this route by default)
+
+
+def test_second_stage_proof_keeps_clustered_rows_off_the_exact_kernel(amd, monkeypatch):
+    """Clustered anchors: for ~1 % of the rows the exact k-th score is not delta above the keep-th fp16 score, so the first
+    re-scoring cannot prove their lists.  Half-sweep builds then re-score EVERY candidate of the row's bucket and prove the
+    list against tau_row (k_bucket_rescore); only what is left goes to the all-fp32 kernel.  The full sweep (no buckets)
+    shows how many rows the first stage leaves; the lattices are equal."""
+    rng = np.random.default_rng(21)
+    N, D, k, csize = 40000, 256, 24, 100
+    centers = rng.standard_normal((N // csize, D)).astype(np.float32)
+    Y = (centers[np.repeat(np.arange(N // csize), csize)] + 0.35 * rng.standard_normal((N, D))).astype(np.float32)
+    Y = Y[rng.permutation(N)]
+    monkeypatch.setenv("OSC_KNN_MODE", "panel")
+    out = {}
+    for sym in ("1", "0"):
+        monkeypatch.setenv("OSC_KNN_PANEL_SYM", sym)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        out[sym] = (lat.build_info()["fallback_rows"], lat.graph_csr()[:3])
+        lat.close()
+    assert out["0"][0] >= 20, out["0"][0]            # the first stage alone leaves these to the exact kernel
+    assert out["1"][0] <= out["0"][0] // 4, (out["1"][0], out["0"][0])
+    # same edges; the weights of the rows the two builds decided differently come from two summation orders of the same fp32
+    # products (the re-scoring's lane-strided sums vs the exact kernel's MFMA tiles)
+    assert np.array_equal(out["1"][1][0], out["0"][1][0]) and np.array_equal(out["1"][1][1], out["0"][1][1])
+    assert np.allclose(out["1"][1][2], out["0"][1][2], rtol=2e-6, atol=1e-8)
