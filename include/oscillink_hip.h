@@ -89,6 +89,9 @@ int osc_build_info(osc_handle h, int32_t* prefilter, int32_t* fallback_rows, int
  * is invisible at this API (every call speaks the caller's row ids); clustering = sampled local clustering
  * coefficient that decided it (OSC_REORDER=0/1 overrides the automatic choice) */
 int osc_order_info(osc_handle h, int32_t* reordered, double* clustering);
+/* the internal row order itself (test / diagnostic aid): perm[new] = caller's row id, N entries; the identity when the
+ * rows are stored in the caller's order */
+int osc_get_row_order(osc_handle h, int32_t* perm);
 
 /* how one operator apply (the CG matvec over this handle's column window) is launched: launches = kernel launches per
  * apply, slab_cols = columns each launch covers, xs_workgroups = 0 for sequential column slabs swept by the whole

@@ -38,6 +38,7 @@ SIGNATURES = {
     "osc_graph_stats": (C.c_int, [Handle, c_i64p, c_i32p, c_f64p]),
     "osc_build_info": (C.c_int, [Handle, c_i32p, c_i32p, c_i64p]),
     "osc_order_info": (C.c_int, [Handle, c_i32p, c_f64p]),
+    "osc_get_row_order": (C.c_int, [Handle, c_i32p]),
     "osc_spmm_plan": (C.c_int, [Handle, c_i32p, c_i32p, c_i32p]),
     "osc_get_csr": (C.c_int, [Handle, c_i64p, c_i32p, c_f32p, c_f32p, c_f32p]),
     "osc_set_csr": (C.c_int, [Handle, c_i64p, c_i32p, c_f32p]),

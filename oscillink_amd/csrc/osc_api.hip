@@ -241,6 +241,7 @@ struct osc_lattice {
   bool knn_sym = true;         // OSC_KNN_PANEL_SYM
   KnnPanelTune knn_tune{};     // OSC_KNN_PANEL_NRG / _RHO / _T
   int halo_force = 0;          // OSC_HALO: 1 full, 2 lists
+  bool bfs_host = false;       // OSC_BFS_HOST=1: the breadth-first row order is walked on the host (A/B, tests)
   int fake_col_r = 0, fake_col_w = 0;  // OSC_FAKE_COL_SHARD "r/w"
   int predicted_iters[3] = {0, 0, 0};  // iterations the last general-path solve of each kind (CgBuffers::kind) took (0 = unknown)
   bool x_defer = true;                // the x update rides in the next iteration's p update (run_cg; OSC_X_DEFER=0: beside the r update)
@@ -896,7 +897,20 @@ void maybe_reorder(L& l) {
     l.clustering = hc[1] ? (double)hc[0] / (double)hc[1] : 0.0;
     if (l.clustering < 0.05) return;
   }
-  apply_order(l, bfs_order(l));
+  // the order itself: on the device (bfs_order.hip; the same order as the host walk below it, OSC_BFS_HOST=1 forces that)
+  bool on_device = false;
+  if (!l.bfs_host) {
+    DevBuf<int32_t> perm;
+    perm.alloc((size_t)l.N);
+    if (device_bfs_order(l.ell_col.p, l.deg.p, l.width, (int32_t)l.N, perm.p, l.stream)) {
+      std::vector<int32_t> ph((size_t)l.N);
+      HIP_CHECK(hipMemcpyAsync(ph.data(), perm.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+      sync(l);
+      apply_order(l, ph);
+      on_device = true;
+    }
+  }
+  if (!on_device) apply_order(l, bfs_order(l));
   l.reordered = true;
 }
 
@@ -2138,6 +2152,7 @@ void read_env(L& h) {
   if (num("OSC_KNN_PANEL_NRG", v)) h.knn_tune.nrg = v;
   if (const char* e = getenv("OSC_KNN_PANEL_RHO")) h.knn_tune.rho = atof(e);
   if (num("OSC_KNN_PANEL_T", v)) h.knn_tune.T = v;
+  h.bfs_host = num("OSC_BFS_HOST", v) && v != 0;
   h.halo_force = 0;
   if (const char* e = getenv("OSC_HALO")) h.halo_force = !strcmp(e, "full") ? 1 : !strcmp(e, "lists") ? 2 : 0;
 }
@@ -2385,6 +2400,13 @@ int osc_order_info(osc_handle h, int32_t* reordered, double* clustering) {
   return guarded(h, [&](L& l) {
     if (reordered) *reordered = l.reordered ? 1 : 0;
     if (clustering) *clustering = l.clustering;
+  });
+}
+
+int osc_get_row_order(osc_handle h, int32_t* perm) {
+  return guarded(h, [&](L& l) {
+    if (!perm) throw Invalid("osc_get_row_order: perm is NULL");
+    for (int64_t i = 0; i < l.N; ++i) perm[i] = l.perm_h.empty() ? (int32_t)i : l.perm_h[(size_t)i];
   });
 }
 

@@ -11,6 +11,11 @@ void launch_permute_ell(const int32_t* col_in, const float* a_in, const float* w
                         const int32_t* from, const int32_t* relabel, int32_t width, int64_t N, int32_t* col_out,
                         float* a_out, float* w_out, int32_t* deg_out, hipStream_t s);
 
+// The breadth-first row order of the lattice graph computed on the device (bfs_order.hip): perm_out[new] = old, identical to
+// the host's queue BFS (components by smallest row id, neighbours in slot order).  false: graph too deep / too large for
+// the device form -- walk it on the host.
+bool device_bfs_order(const int32_t* col, const int32_t* deg, int32_t width, int32_t N, int32_t* perm_out, hipStream_t s);
+
 void launch_clustering_sample(const int32_t* col, const int32_t* deg, int32_t width, int64_t N, int32_t nsample,
                               unsigned long long* counts, hipStream_t s);
 

@@ -534,3 +534,35 @@ def test_large_read_backs_pinned_and_staged_agree(amd, monkeypatch):
     assert nat.lib().osc_host_alloc(N * D * 4, C.byref(q)) == 0 and q.value == p.value
     assert nat.lib().osc_host_free(q) == 0
     assert nat.lib().osc_host_free(C.c_void_p(12345)) == nat.OSC_E_INVALID  # not a block of the pool
+
+
+@pytest.mark.parametrize("N,D,k,csize", [(9000, 48, 12, 90), (30000, 64, 8, 60), (12000, 32, 4, 3)])
+def test_device_bfs_order_equals_the_host_walk(amd, N, D, k, csize, monkeypatch):
+    """The breadth-first row order of a clustered lattice is computed on the device (csrc/bfs_order.hip: connected components,
+    level-synchronous frontiers ordered by (claiming parent, slot), one radix sort); it must be the host's queue BFS order,
+    entry for entry -- many components (clusters that the mutual-kNN graph leaves unconnected, singletons at csize 3 with
+    k 4), deep and shallow ones."""
+    import ctypes as C
+
+    from oscillink_amd import _native as nat
+
+    rng = np.random.default_rng(N)
+    centers = rng.standard_normal((N // csize, D)).astype(np.float32)
+    Y = (centers[np.repeat(np.arange(N // csize), csize)] + 0.3 * rng.standard_normal((N, D))).astype(np.float32)
+    Y = Y[rng.permutation(N)]
+    monkeypatch.setenv("OSC_REORDER", "1")
+    orders, results = {}, {}
+    for host in ("0", "1"):
+        monkeypatch.setenv("OSC_BFS_HOST", host)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        assert lat.build_info()["reordered"] == 1
+        perm = np.zeros(N, dtype=np.int32)
+        lat._call("osc_get_row_order", nat.i32(perm))
+        orders[host] = perm
+        lat.set_query(Y[0] / np.linalg.norm(Y[0]))
+        st = lat.settle(max_iters=8, tol=1e-4)
+        results[host] = (st["iters"], lat.U.copy())
+        lat.close()
+    assert sorted(orders["0"].tolist()) == list(range(N))  # a permutation
+    assert np.array_equal(orders["0"], orders["1"])
+    assert results["0"][0] == results["1"][0] and np.array_equal(results["0"][1], results["1"][1])
