@@ -1018,9 +1018,13 @@ __global__ __launch_bounds__(256) void k_mutual_ell(const float* kval, const int
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= N) return;
   int total = 0;
-  // k <= 128: two passes of 64 entries; ranks computed against all kept entries of both passes
-  int jcol[2];
-  float jw[2];
+  // k <= 128: two passes of 64 entries; ranks computed against all kept entries of both passes.
+  // The back-edge test "is `row` in the list of j?" is done by the WAVE for one neighbour at a time: 64 lanes read j's
+  // list in one coalesced load (two for k > 64) and a ballot finds the slot.  Before round 4 every lane scanned the list of
+  // ITS neighbour with 16-byte loads -- 64 different lines per wave instruction, k / 4 instructions: 1024 line requests per
+  // row at k = 64, 7.5 ms of config 5's build; this form makes 128.
+  int jcol[2], bpos[2];
+  float jw[2], myv[2];
   bool keep[2];
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
@@ -1028,31 +1032,51 @@ __global__ __launch_bounds__(256) void k_mutual_ell(const float* kval, const int
     keep[ps] = false;
     jcol[ps] = 0x7fffffff;
     jw[ps] = 0.f;
+    myv[ps] = 0.f;
+    bpos[ps] = -1;
     if (e < k) {
       const int j = kidx[(size_t)row * k + e];
       const float v = kval[(size_t)row * k + e];
       if (v > 0.f && j >= 0 && j < N) {
-        float back = 0.f;
-        const int32_t* lj = kidx + (size_t)j * k;
-        const float* vj = kval + (size_t)j * k;
-        if ((k & 3) == 0) {  // four ids per load (the rows of the list array are 16-byte aligned then): at k = 64 the
-                             // scan of 64 dependent 4-byte loads per lane was 9.5 ms of config 5's build
-          for (int q = 0; q < k; q += 4) {
-            const int4 c = *reinterpret_cast<const int4*>(lj + q);
-            const int hit = c.x == row ? 0 : c.y == row ? 1 : c.z == row ? 2 : c.w == row ? 3 : -1;
-            if (hit >= 0) back = vj[q + hit];
-          }
-        } else {
-          for (int q = 0; q < k; ++q)
-            if (lj[q] == row) back = vj[q];
-        }
-        if (back > 0.f) {
-          keep[ps] = true;
-          jcol[ps] = j;
-          jw[ps] = fmaxf(v, back);
-        }
+        jcol[ps] = j;
+        myv[ps] = v;
       }
     }
+  }
+  const int npass = k > 64 ? 2 : 1;
+  for (int ps = 0; ps < npass; ++ps) {
+    const int ne = min(64, k - 64 * ps);
+    for (int e0 = 0; e0 < ne; e0 += 4) {  // four neighbours' lists in flight
+      int jj[4], c0[4], c1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        jj[u] = e0 + u < ne ? __shfl(jcol[ps], e0 + u, 64) : 0x7fffffff;
+        c0[u] = c1[u] = -1;
+        if (jj[u] != 0x7fffffff) {
+          const int32_t* lj = kidx + (size_t)jj[u] * k;
+          if (lane < k) c0[u] = lj[lane];
+          if (lane + 64 < k) c1[u] = lj[lane + 64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (jj[u] == 0x7fffffff) continue;  // (wave-uniform)
+        const unsigned long long m0 = __ballot(c0[u] == row), m1 = __ballot(c1[u] == row);
+        const int pos = m0 ? __ffsll((long long)m0) - 1 : m1 ? 64 + __ffsll((long long)m1) - 1 : -1;
+        if (lane == e0 + u) bpos[ps] = pos;
+      }
+    }
+  }
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    if (bpos[ps] >= 0) {  // the back edge's similarity: one gather per lane
+      const float back = kval[(size_t)jcol[ps] * k + bpos[ps]];
+      if (back > 0.f) {
+        keep[ps] = true;
+        jw[ps] = fmaxf(myv[ps], back);
+      }
+    }
+    if (!keep[ps]) jcol[ps] = 0x7fffffff;
   }
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
