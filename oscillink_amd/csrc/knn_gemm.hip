@@ -1239,6 +1239,7 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
   // short of candidates: below 14 the low tail of the candidate count reaches `keep`)
   // -- where the sample is denser than planned relative to keep (small lattices with a large k), rank 16 keeps the margin
   p.sample_rank = ((double)p.nrb / p.sample_tiles * 6.5 >= (double)keep) ? 14 : 16;
+  if (tune.rank > 0) p.sample_rank = std::max(2, std::min(p.sample_groups, tune.rank));
   // column splits: whatever leaves the smallest idle tail on `cus` persistent workgroups (per-item overhead ~1 %)
   // ... and few enough hits per wave and item for its LDS list: 32 rows x ~5 keep / S <= ~2/3 of HB_CAP
   p.hit_cap = HB_CAP / p.nrg;

@@ -53,11 +53,12 @@ struct KnnPanelPlan {
 inline int32_t knn_panel_row(const KnnPanelPlan& p, int32_t N, int32_t r) {
   return r < N ? (int32_t)(((int64_t)r * p.scatter) % N) : r;
 }
-// A/B overrides of the planner (OSC_KNN_PANEL_NRG / _RHO / _T, read by the caller; 0 = the planner's own choice)
+// A/B overrides of the planner (OSC_KNN_PANEL_NRG / _RHO / _T / _RANK, read by the caller; 0 = the planner's own choice)
 struct KnnPanelTune {
   int nrg = 0;     // 1: one row group per wave also at K depth 6
   double rho = 0;  // one sample column in rho
   int T = 0;       // half sweep: tiles per chunk
+  int rank = 0;    // threshold = rank-th largest group maximum of the sample
 };
 KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows = false, bool sym = false,
                             const KnnPanelTune& tune = KnnPanelTune{});

@@ -239,7 +239,7 @@ struct osc_lattice {
   int knn_splits = 0;          // OSC_KNN_SPLITS (tile / exact routes: column splits)
   bool knn_scatter = true;     // OSC_KNN_PANEL_SCATTER
   bool knn_sym = true;         // OSC_KNN_PANEL_SYM
-  KnnPanelTune knn_tune{};     // OSC_KNN_PANEL_NRG / _RHO / _T
+  KnnPanelTune knn_tune{};     // OSC_KNN_PANEL_NRG / _RHO / _T / _RANK
   int halo_force = 0;          // OSC_HALO: 1 full, 2 lists
   bool bfs_host = false;       // OSC_BFS_HOST=1: the breadth-first row order is walked on the host (A/B, tests)
   int fake_col_r = 0, fake_col_w = 0;  // OSC_FAKE_COL_SHARD "r/w"
@@ -2152,6 +2152,7 @@ void read_env(L& h) {
   if (num("OSC_KNN_PANEL_NRG", v)) h.knn_tune.nrg = v;
   if (const char* e = getenv("OSC_KNN_PANEL_RHO")) h.knn_tune.rho = atof(e);
   if (num("OSC_KNN_PANEL_T", v)) h.knn_tune.T = v;
+  if (num("OSC_KNN_PANEL_RANK", v)) h.knn_tune.rank = v;
   h.bfs_host = num("OSC_BFS_HOST", v) && v != 0;
   h.halo_force = 0;
   if (const char* e = getenv("OSC_HALO")) h.halo_force = !strcmp(e, "full") ? 1 : !strcmp(e, "lists") ? 2 : 0;

@@ -1375,9 +1375,9 @@ def test_panel_planner_overrides_give_the_same_lattice(amd, monkeypatch):
     Y = rng.standard_normal((N, D), dtype=np.float32)
     monkeypatch.setenv("OSC_KNN_MODE", "panel")
     want = None
-    for env in ({}, {"OSC_KNN_PANEL_T": "4"}, {"OSC_KNN_PANEL_RHO": "16"}, {"OSC_KNN_PANEL_NRG": "1"},
+    for env in ({}, {"OSC_KNN_PANEL_T": "4"}, {"OSC_KNN_PANEL_RHO": "16"}, {"OSC_KNN_PANEL_NRG": "1"}, {"OSC_KNN_PANEL_RANK": "12"},
                 {"OSC_KNN_PANEL_NRG": "1", "OSC_KNN_PANEL_T": "9", "OSC_KNN_PANEL_SYM": "0"}):
-        for v in ("OSC_KNN_PANEL_T", "OSC_KNN_PANEL_RHO", "OSC_KNN_PANEL_NRG", "OSC_KNN_PANEL_SYM"):
+        for v in ("OSC_KNN_PANEL_T", "OSC_KNN_PANEL_RHO", "OSC_KNN_PANEL_NRG", "OSC_KNN_PANEL_RANK", "OSC_KNN_PANEL_SYM"):
             monkeypatch.delenv(v, raising=False)
         for v, val in env.items():
             monkeypatch.setenv(v, val)
