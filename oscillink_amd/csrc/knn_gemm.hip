@@ -1230,15 +1230,25 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
   p.sample_tiles = (int32_t)std::max(24.0, std::min(p.nrb / 2.0, std::round(p.nrb / rho)));
   // tile maxima are folded over groups of consecutive sample tiles so that a row has at most 128 of them (the r-th
   // largest group maximum is still a lower bound of the r-th best sample score)
-  // (small lattices cannot afford a sparse enough sample: with fewer than keep / 8 columns per sampled one, too many rows
-  // would end with fewer than keep candidates -- the tile prefilter serves those)
-  p.ok = (double)p.nrb / p.sample_tiles * 8.0 >= (double)keep;
   p.group_tiles = (p.sample_tiles + 127) / 128;
   p.sample_groups = (p.sample_tiles + p.group_tiles - 1) / p.group_tiles;
-  // rank 14 (measured at config 3: rank 16 / 14 / 12 / 10 -> build 22.5 / 22.1 / 21.7 / 26.0 ms with 2 / 2 / 21 / 346 rows
-  // short of candidates: below 14 the low tail of the candidate count reaches `keep`)
-  // -- where the sample is denser than planned relative to keep (small lattices with a large k), rank 16 keeps the margin
-  p.sample_rank = ((double)p.nrb / p.sample_tiles * 6.5 >= (double)keep) ? 14 : 16;
+  // The threshold rank.  tau = the r-th largest of G group maxima lets (N / sample columns) G -ln(1 - r / G) columns of a row
+  // through in expectation; the target is 4 keep of them (= 16 rho at rho = keep / 4; at least 192), which is rank 14 at
+  // configs 3 / 4 / 5 (G = 65; measured there: rank 16 / 14 / 12 / 10 -> 2 / 2 / 21 / 346 rows short of candidates).  Where
+  // the sample cannot be that sparse (small lattices: at least 24 sample tiles) the rank rises with the need, up to 0.9 G;
+  // the route is offered as long as even that leaves a row twice `keep` candidates.  (Until round 4 the route was held
+  // to N >= 16384 and samples of < keep / 8 density: rows short of candidates went to the exact kernel then; now they are
+  // proven from their buckets, and between 8192 and 16384 rows this route builds in half the tile prefilter's time:
+  // 12000 x 768, k 16: 1.70 -> 0.79 ms; 15000 x 768, k 32: 3.20 -> 1.30 ms.)
+  {
+    const double G = (double)p.sample_groups, per_col = (double)p.nrb / p.sample_tiles;
+    const double target = std::max(4.0 * keep, 192.0);
+    const double rmax = std::floor(0.9 * G);
+    double r = std::ceil(G * (1.0 - std::exp(-target / (per_col * G))) - 0.25);
+    r = std::max(std::min(14.0, rmax), std::min(r, rmax));
+    p.sample_rank = (int32_t)r;
+    p.ok = per_col * G * -std::log(1.0 - rmax / G) >= 2.0 * keep;
+  }
   if (tune.rank > 0) p.sample_rank = std::max(2, std::min(p.sample_groups, tune.rank));
   // column splits: whatever leaves the smallest idle tail on `cus` persistent workgroups (per-item overhead ~1 %)
   // ... and few enough hits per wave and item for its LDS list: 32 rows x ~5 keep / S <= ~2/3 of HB_CAP

@@ -976,7 +976,7 @@ void build_graph(L& h) {
   // The prefilter's GEMM has two shapes: "panel" (knn_gemm.hip: query panel in registers, thresholds from a column
   // sample, hits appended -- D <= 768 and enough row blocks for the sample) and the older 128 x 128 tile with
   // register-resident sorted lists (k_knn_pref), which serves everything else.
-  constexpr int panel_min = 16384;
+  constexpr int panel_min = 8193;  // (up to 8192 rows: the dense route)
   // (a hit entry packs the column index into 25 bits, next to its two side flags)
   // (D > 768: the same route on the tile core, k_tile_thr -- half sweep only, so single-process builds only)
   const bool sym_ok = h.knn_sym && parts == 1;
