@@ -109,6 +109,7 @@ struct PanelArgs {
   int32_t* bucket_cnt;   // [npad / 32] entries delivered (may exceed bucket_cap: overflow); zeroed by the caller
   int32_t bucket_cap;
   int32_t* flags;        // [c]: an LDS list of chunk c overflowed (hits of its tiles' rows were lost); zeroed by the caller
+  int32_t set0, nset;    // k_tile_thr2: the sets of two row blocks this launch sweeps (a group whose image rows stay in the Infinity Cache)
 };
 
 // LDS-DMA of one 1 KiB piece: M0 = LDS destination - K offset, the K offset rides in the immediate
@@ -1049,6 +1050,262 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
   }
 }
 
+// ---- the main sweep of the tile core with 64 x 128 wave tiles (round 4) ---------------------------------------------------
+// k_tile_thr<1> reads 5 KB of LDS fragments per 4 MFMAs and wave (one A fragment, four B fragments per k16 slice); eight
+// waves per CU ask the LDS for ~156 B per clock at full MFMA rate, which it does not deliver -- config 5's sweep ran at 31 %
+// MFMA-busy.  Here a wave owns 64 rows x 128 columns (two row groups share every B fragment: 6 KB per 8 MFMAs, ~94 B per
+// clock), a workgroup of 8 waves a 256 x 256 tile pair -- two row blocks against two column tiles --, 64 KB per stage, two
+// stages, one workgroup per CU (still two waves per SIMD).  Everything else is k_tile_thr<1>: flat (tile pair, K step)
+// pipeline, threshold test on both sides, fine 8-byte entries in per-(wave, row group) LDS lists that are delivered to the
+// 32-row buckets when the next tile might not fit and at the end of the item.
+constexpr int T2_CAP = 160;
+constexpr unsigned T2_STAGE = (256 + 256) * 128;
+constexpr size_t T2_LDS = (size_t)2 * T2_STAGE;
+constexpr size_t T2_LDS_ALL = T2_LDS + (size_t)16 * T2_CAP * 8 + (size_t)TT_TILES * 512 + (size_t)8 * 8 * TT_TILES * 4;
+
+__global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const int nkt) {
+  extern __shared__ __attribute__((aligned(1024))) float lds[];
+  __shared__ int s_item, s_chunk, s_first;
+  __shared__ __attribute__((aligned(16))) float s_tau[8][2][2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int frow = lane >> 3;
+  const int swz = (l31 >> 1) & 7;
+  const int rg = wave >> 1, cg = wave & 1;  // the wave's 64 rows (of the set's 256) and 128 columns (of the tile pair's 256)
+  const unsigned lds_base = (unsigned)(size_t)lds;
+  const char* ldsc = reinterpret_cast<const char*>(lds);
+  uint2* const lists = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds) + T2_LDS);
+  float* const s_tc = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + T2_LDS + (size_t)16 * T2_CAP * 8);
+  int* const s_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + T2_LDS + (size_t)16 * T2_CAP * 8 + (size_t)TT_TILES * 512) +
+                     wave * (8 * TT_TILES);
+  int* const s_base = s_cnt + 4 * TT_TILES;
+  const size_t ldh = (size_t)a.ldh;
+  const int nrb = a.ntileB;
+  auto chunk_sets = [&](int c) { return max(0, min((min(nrb, (c + 1) * a.T) + 1) / 2 - a.set0, a.nset)); };  // sets of this launch that sweep chunk c
+  int nitems = 0;
+  for (int c = 0; c < a.nchunks; ++c) nitems += chunk_sets(c);
+  auto glds16 = [&](const _Float16* src, unsigned dst_bytes) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst_bytes)
+                 : "memory");
+  };
+  for (;;) {
+    if (tid == 0) {
+      const int it = (int)atomicAdd(a.queue, 1u);
+      int c = a.nchunks - 1, first = 0;
+      if (it < nitems)
+        while (it >= first + chunk_sets(c)) first += chunk_sets(c), --c;
+      s_item = it;
+      s_chunk = c;
+      s_first = first;
+    }
+    __syncthreads();
+    const int item = s_item, chunk = s_chunk, first_item = s_first;
+    __syncthreads();
+    if (item >= nitems) break;
+    const int rb0 = (a.set0 + item - first_item) * 2;  // the set's row blocks rb0, rb0 + 1
+    const int t1 = min(nrb, (chunk + 1) * a.T);
+    const int t0 = max(chunk * a.T, rb0);          // (T and rb0 are even: tile pairs never straddle a chunk)
+    if (t0 >= t1) continue;
+    const int rb = rb0 + (rg >> 1);                // this wave's row block
+    const bool rok = rb < nrb;
+    const int wrow0 = rb * 128 + 64 * (rg & 1);    // first of the wave's 64 image rows
+    int wcnt[2] = {0, 0};
+    if (rok && l31 < 16) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) s_tau[wave][r][h][l31] = a.tau[wrow0 + 32 * r + 4 * h + (l31 & 3) + 8 * (l31 >> 2)];
+    }
+    for (int e = tid; e < (t1 - t0) * 128; e += 512) {  // the chunk's column thresholds: [tile][lane][subtile]
+      const int col = t0 * 128 + e;
+      s_tc[(e >> 7) * 128 + (e & 31) * 4 + ((e >> 5) & 3)] = col < a.N ? a.tau[col] : 3.0e38f;
+    }
+    // LDS-DMA sources: this wave fills rows 32 wave .. + 31 of the stage's A half (256 rows) and of its B half
+    const _Float16* a_src[4];
+    const _Float16* b_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t off = (size_t)(32 * wave + 8 * q + frow) * ldh + ((lane & 7) ^ (((q & 1) << 2) | (frow >> 1))) * 8;
+      a_src[q] = a.A + (size_t)rb0 * 128 * ldh + off;  // (the image carries one zero tile behind its last row block)
+      b_src[q] = a.B + off;
+    }
+    auto issue = [&](int stage, int ct, int kt) {
+      const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)stage * T2_STAGE + (unsigned)(32 * wave) * 128u);
+      const unsigned b_dst = a_dst + 256u * 128u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds16(a_src[q] + kt * 64, a_dst + (unsigned)(8 * q) * 128u);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds16(b_src[q] + (size_t)ct * 128 * ldh + kt * 64, b_dst + (unsigned)(8 * q) * 128u);
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[r][t][g] = 0.f;
+    // deliver the fine entries of row group r to the buckets (k_tile_thr<1>'s flush, per list)
+    auto deliver = [&](auto RC) {
+      constexpr int r = decltype(RC)::value;
+      const uint2* hb = lists + (wave * 2 + r) * T2_CAP;
+      const int nbl = (t1 - t0) * 4;
+      const int n = min(wcnt[r], T2_CAP);
+      const int own = rb * 4 + 2 * (rg & 1) + r;
+      if (wcnt[r] > T2_CAP && lane == 0) {
+        a.flags[chunk] = 1;
+        atomicAdd(&a.bucket_cnt[own], a.bucket_cap + 1);
+      }
+      for (int b = lane; b < nbl; b += 64) s_cnt[b] = 0;
+      int nrow = 0;
+      for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + lane;
+        const unsigned x = e < n ? hb[e].x : 0u;
+        if (x & COL_SIDE) atomicAdd(&s_cnt[(int)((x & COL_MASK) >> 5) - t0 * 4], 1);
+        nrow += __popcll(__ballot((x & ROW_SIDE) != 0u));
+      }
+      int rbase = 0;
+      if (lane == 0 && nrow > 0) rbase = atomicAdd(&a.bucket_cnt[own], nrow);
+      for (int b = lane; b < nbl; b += 64) {
+        const int c = s_cnt[b];
+        s_base[b] = c > 0 ? atomicAdd(&a.bucket_cnt[t0 * 4 + b], c) : 0;
+        s_cnt[b] = 0;
+      }
+      rbase = __builtin_amdgcn_readfirstlane(rbase);
+      const unsigned irow0 = (unsigned)(wrow0 + 32 * r);
+      for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + lane;
+        const uint2 v = e < n ? hb[e] : make_uint2(0u, 0u);
+        const bool rs = (v.x & ROW_SIDE) != 0u, cs = (v.x & COL_SIDE) != 0u;
+        const unsigned long long m = __ballot(rs);
+        const int rpos = rbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (rs && rpos < a.bucket_cap) a.bucket_ent[(size_t)own * a.bucket_cap + rpos] = make_uint2((v.x & ~COL_SIDE), v.y);
+        rbase += __popcll(m);
+        if (cs) {
+          const unsigned col = v.x & COL_MASK;
+          const int b = (int)(col >> 5) - t0 * 4;
+          const int cpos = s_base[b] + atomicAdd(&s_cnt[b], 1);
+          if (cpos < a.bucket_cap)
+            a.bucket_ent[(size_t)(col >> 5) * a.bucket_cap + cpos] = make_uint2(((col & 31u) << 27) | ROW_SIDE | (irow0 + (v.x >> 27)), v.y);
+        }
+      }
+      wcnt[r] = 0;
+    };
+    // the hit test of row group r on the tile pct (k_panel's, fine entries)
+    auto hit_test = [&](auto RC, int pct) {
+      constexpr int r = decltype(RC)::value;
+      float tg[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][r][h][4 * q]);
+        tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
+      }
+      float tc[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+      if (pct > rb) {
+        const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(pct - t0) * 128 + l31 * 4]);
+        tc[0] = c4[0], tc[1] = c4[1], tc[2] = c4[2], tc[3] = c4[3];
+      }
+      uint2* const hb = lists + (wave * 2 + r) * T2_CAP;
+      const bool special = pct == rb || (pct + 1) * 128 > a.N;
+      unsigned long long fm[16];
+      static_for<0, 16>([&](auto GC) {
+        constexpr int g = decltype(GC)::value;
+        bool any = fmaxf(fmaxf(acc[r][0][g], acc[r][1][g]), fmaxf(acc[r][2][g], acc[r][3][g])) > tg[g];
+        any = any | (fmaxf(fmaxf(acc[r][0][g] - tc[0], acc[r][1][g] - tc[1]), fmaxf(acc[r][2][g] - tc[2], acc[r][3][g] - tc[3])) > 0.f);
+        fm[g] = __ballot(any);
+      });
+      static_for<0, 16>([&](auto GC) {
+        constexpr int g = decltype(GC)::value;
+        if (fm[g] == 0ull) return;
+        const int rl = (g & 3) + 8 * (g >> 2) + 4 * h;
+        const int grow = wrow0 + 32 * r + rl;
+        const int cbase = pct * 128 + l31;
+        unsigned long long mk[4];
+        unsigned side[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          bool pred = acc[r][t][g] > tg[g];
+          if (special) pred = pred && (cbase + 32 * t) != grow && (cbase + 32 * t) < a.N;
+          const bool cp = acc[r][t][g] > tc[t];
+          side[t] = (pred ? ROW_SIDE : 0u) | (cp ? COL_SIDE : 0u);
+          mk[t] = __ballot(pred | cp);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (mk[t] == 0ull) continue;
+          const bool pred = (mk[t] >> lane) & 1ull;
+          const int pos = wcnt[r] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[t] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[t], 0u));
+          if (pred && pos < T2_CAP)
+            hb[pos] = make_uint2(((unsigned)rl << 27) | side[t] | (unsigned)(cbase + 32 * t), __float_as_uint(acc[r][t][g]));
+          wcnt[r] += __popcll(mk[t]);
+        }
+      });
+    };
+    // ---- flat (tile pair, K step) pipeline ---------------------------------------------------------------------------------
+    const int npair = (t1 - t0 + 1) / 2;
+    const int total = npair * nkt;
+    int ct = t0, kt = 0, ict = t0, ikt = 0, issued = 0;
+    auto issue_next = [&]() {
+      issue(issued & 1, ict, ikt);
+      ++issued;
+      if (++ikt == nkt) {
+        ikt = 0;
+        ict += 2;
+      }
+    };
+    issue_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int step = 0; step < total; ++step) {
+      const int stage = step & 1;
+      if (issued < total) issue_next();
+      const char* Asw = ldsc + (size_t)stage * T2_STAGE + (size_t)(64 * rg + l31) * 128;
+      const char* Bsw = ldsc + (size_t)stage * T2_STAGE + 256 * 128 + (size_t)(128 * cg + l31) * 128;
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        const int co = ((2 * sl + h) ^ swz) * 16;
+        half8 av[2], bv[4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) av[r] = *reinterpret_cast<const half8*>(Asw + (size_t)r * 32 * 128 + co);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const half8*>(Bsw + (size_t)t * 32 * 128 + co);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[r], bv[t], acc[r][t], 0, 0, 0);
+      }
+      if (kt == nkt - 1) {  // ---- the tile pair's accumulators are complete ----
+        const int pct = ct + cg;  // this wave's column tile
+        if (rok && pct >= rb && pct < t1) {
+          static_for<0, 2>([&](auto RC) {
+            constexpr int r = decltype(RC)::value;
+            if (wcnt[r] > T2_CAP - 96) deliver(RC);  // (a tile adds ~20 entries to a list on average)
+            hit_test(RC, pct);
+          });
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[r][t][g] = 0.f;
+        kt = 0;
+        ct += 2;
+      } else {
+        ++kt;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (rok) {
+      static_for<0, 2>([&](auto RC) {
+        if (wcnt[decltype(RC)::value] > 0) deliver(RC);
+      });
+    }
+    __syncthreads();  // the stages, the lists and the threshold window are free for the next item
+  }
+}
+
 // ---- second-stage proof for rows the first re-scoring could not decide (half-sweep builds) ---------------------------
 // k_knn_rescore proves a row from its `keep` best candidates: "every left-out column has fp16 score <= the list's last".  On
 // clustered anchors that often fails -- the exact k-th score is not delta above the keep-th fp16 score -- and such rows used
@@ -1281,19 +1538,30 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
     // half sweep: column chunks of T tiles; a (wave, item) list takes the row-side AND the column-side hits of its tiles,
     // 2 x 32 rows x bound / nrb per tile, and should stay within ~2/3 of its LDS list; the item's column thresholds must
     // fit their LDS window (TC_TILES); T even where a set holds two row blocks (both then meet their diagonal in one chunk)
-    p.hit_cap = p.tile_core ? TH_CAP : HB_CAP_SYM / p.nrg;
+    // (k_tile_thr2 delivers a list before a tile that might not fit: a tile's mean load must stay well below the 96 entries
+    // that check leaves it -- small N with a deep k goes through k_tile_thr<1>, whose lists hold a whole item)
+    p.tile_wide = p.tile_core && tune.tile_wide != 0 && 64.0 * p.hit_bound / p.nrb <= 40.0;
+    p.hit_cap = p.tile_core ? (p.tile_wide ? T2_CAP : TH_CAP) : HB_CAP_SYM / p.nrg;
     const double bound = p.hit_bound;
     int T = (int)std::floor(0.66 * p.hit_cap * p.nrb / (64.0 * bound));  // (the tile core's lists are a hard limit)
     if (!p.tile_core) T = TC_TILES;  // k_panel delivers a list that is half full: the threshold window alone limits an item
     T = std::max(p.tile_core ? 1 : 2, std::min(p.tile_core ? TT_TILES : TC_TILES, T));
     if (tune.T > 0) T = std::max(p.tile_core ? 1 : 2, std::min(p.tile_core ? TT_TILES : TC_TILES, tune.T));  // (A/B: tiles per chunk)
-    if (p.nrg == 2) T &= ~1;
+    if (p.tile_wide) T = TT_TILES;  // (its lists are delivered as they fill: the threshold window alone limits an item)
+    if (p.nrg == 2 || p.tile_wide) T &= ~1;
     p.T = T;
     p.S = (p.nrb + T - 1) / T;  // chunks
     p.tiles_per_split = T;
     p.bucket_cap = (int32_t)(32.0 * 1.5 * bound);  // a group of 32 rows receives all its candidates here; 1.5: rows of a group vary, clustered anchors have heavy tails
     p.nitems = 0;
-    for (int c = 0; c < p.S; ++c) p.nitems += (std::min(p.nrb, (c + 1) * T) + p.nrg - 1) / p.nrg;
+    const int per_item = p.tile_wide ? 2 : p.nrg;  // row blocks of one work item
+    if (p.tile_wide) {  // groups of sets whose image rows fit the Infinity Cache next to the passing chunks (equal sizes)
+      const int nsets = (p.nrb + 1) / 2;
+      const double group_mb = tune.tile_group_mb > 0 ? tune.tile_group_mb : 128.0;
+      const int ngroups = std::max(1, (int)std::ceil(nsets * 256.0 * p.ldh * 2.0 / (group_mb * 1048576.0)));
+      p.tile_group_sets = (nsets + ngroups - 1) / ngroups;
+    }
+    for (int c = 0; c < p.S; ++c) p.nitems += (std::min(p.nrb, (c + 1) * T) + per_item - 1) / per_item;
   }
   // phase A: splits of whole tile groups, again for the tail of the persistent grid
   // (round 4: grouping a row's sample columns by (column split, lane) instead -- 32 running maxima per split, no shuffles and
@@ -1388,6 +1656,24 @@ void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int r
   a.hit_cap = p.hit_cap;
   a.queue = queue;
   HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
+  if (p.tile_core && p.tile_wide) {  // 64 x 128 wave tiles, one workgroup of 8 waves per CU
+    // One launch per group of row sets: a group's image rows (sets x 256 rows x ldh halfs) are streamed once per tile
+    // pair of every chunk; swept chunk-major over ALL sets (614 MB at config 5) they come from HBM every time, 235 GB per
+    // build; a group of <= 128 MB stays in the 256 MB Infinity Cache while its chunks pass.
+    const int nsets = (p.nrb + 1) / 2, gs = std::max(1, p.tile_group_sets);
+    auto go = [&](auto kern) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2_LDS_ALL));
+      for (int g = 0; g * gs < nsets; ++g) {
+        if (g > 0) HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
+        a.set0 = g * gs;
+        a.nset = std::min(gs, nsets - g * gs);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), T2_LDS_ALL, s, a, p.nkt);
+      }
+    };
+    go(&k_tile_thr2);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (p.tile_core) {
     launch_tile_thr<1>(a, p.nkt, 2 * grid, s);  // two workgroups per CU
     return;

@@ -36,6 +36,8 @@ struct KnnPanelPlan {
   // receiving rows (npad / 32 of them), which is all the select reads.
   bool sym;
   bool tile_core;      // D > 768: both operands through LDS (k_tile_thr) instead of the register-resident panel; half sweep only
+  int tile_group_sets;  // k_tile_thr2: row sets per launch
+  bool tile_wide;      // ... its main sweep with 64 x 128 wave tiles (k_tile_thr2); the fp16 image then carries one zero tile behind npad
   int32_t T;
   int32_t nitems;
   int32_t bucket_cap;
@@ -59,6 +61,8 @@ struct KnnPanelTune {
   double rho = 0;  // one sample column in rho
   int T = 0;       // half sweep: tiles per chunk
   int rank = 0;    // threshold = rank-th largest group maximum of the sample
+  int tile_wide = 1;  // 0: the tile core's main sweep with 32 x 128 wave tiles (k_tile_thr<1>)
+  int tile_group_mb = 0;  // k_tile_thr2: image bytes of one group of row sets (0: 128 MB)
 };
 KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows = false, bool sym = false,
                             const KnnPanelTune& tune = KnnPanelTune{});

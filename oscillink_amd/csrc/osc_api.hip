@@ -1004,7 +1004,8 @@ void build_graph(L& h) {
     // a sharded build's ranks own row blocks and would have to exchange the column-side hits, so they keep the full sweep
     // (OSC_KNN_PANEL_SCATTER=0 / OSC_KNN_PANEL_SYM=0: A/B and tests)
     pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, h.knn_scatter && parts == 1, h.knn_sym && parts == 1, h.knn_tune);
-    p_img.alloc((size_t)pp.npad * pp.ldh / 2);
+    p_img.alloc((size_t)(pp.npad + 128) * pp.ldh / 2);  // (+ one zero tile: k_tile_thr2 sweeps row blocks and column tiles in pairs)
+    HIP_CHECK(hipMemsetAsync(p_img.p + (size_t)pp.npad * pp.ldh / 2, 0, (size_t)128 * pp.ldh * 2, h.stream));
     p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
     p_tmax.alloc((size_t)pp.npad * pp.sample_groups);
     p_tau.alloc((size_t)pp.npad);
@@ -2153,6 +2154,8 @@ void read_env(L& h) {
   if (const char* e = getenv("OSC_KNN_PANEL_RHO")) h.knn_tune.rho = atof(e);
   if (num("OSC_KNN_PANEL_T", v)) h.knn_tune.T = v;
   if (num("OSC_KNN_PANEL_RANK", v)) h.knn_tune.rank = v;
+  if (num("OSC_KNN_TILE_WIDE", v)) h.knn_tune.tile_wide = v != 0 ? 1 : 0;
+  if (num("OSC_KNN_TILE_GROUP_MB", v)) h.knn_tune.tile_group_mb = v;
   h.bfs_host = num("OSC_BFS_HOST", v) && v != 0;
   h.halo_force = 0;
   if (const char* e = getenv("OSC_HALO")) h.halo_force = !strcmp(e, "full") ? 1 : !strcmp(e, "lists") ? 2 : 0;

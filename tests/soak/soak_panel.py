@@ -13,12 +13,15 @@ import oscillink_amd as amd  # noqa: E402
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"  # only shapes whose main sweep runs with 64 x 128 wave tiles (k_tile_thr2): D > 768, N >= ~49k
 rng = np.random.default_rng(seed)
 bad = 0
 special = [(16384, 384, 16), (16385, 385, 8), (32768, 64, 1), (20000, 8, 5), (16400, 768, 64), (50000, 200, 33), (16384, 769, 12),
            (30000, 1536, 40)]
 for t in range(count):
-    if t < len(special):
+    if wide:
+        N, D, k = int(rng.integers(49200, 90000)), int(rng.integers(769, 1601)), int(rng.integers(1, 33))
+    elif t < len(special):
         N, D, k = special[t]
     else:
         N, D, k = int(rng.integers(8200, 60000)), int(rng.integers(8, 769)), int(rng.integers(1, 65))

@@ -1416,6 +1416,38 @@ def test_pool_off_and_planner_overrides():
     assert res["0"] == res["16384"]
 
 
+def test_wide_wave_tiles_of_the_tile_core_give_the_same_lattice(amd, monkeypatch):
+    """From ~49 000 rows (k <= 32) the tile core's main sweep runs with 64 x 128 wave tiles, two row blocks against two
+    column tiles per workgroup (k_tile_thr2; OSC_KNN_TILE_WIDE=0 keeps k_tile_thr<1>).  391 row blocks: odd, the last set's
+    second block is the zero tile behind the image.  Same K order per score, same thresholds: the graphs are identical,
+    and the lists are the exact kernel's up to float64-proven near-ties."""
+    from tests._fullsize import near_tie_gap
+
+    N, D, k = 50000, 800, 16
+    Y = np.random.default_rng(77).standard_normal((N, D), dtype=np.float32)
+    graphs, lists = {}, {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("OSC_KNN_TILE_WIDE", wide)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        info = lat.build_info()
+        assert info["prefilter"] == 2 and info["fallback_rows"] <= 8, info
+        graphs[wide] = lat.graph_csr()
+        lists[wide] = _knn_sets(lat, N, k)
+        lat.close()
+    for a, b in zip(graphs["1"], graphs["0"]):
+        assert np.array_equal(a, b)
+    monkeypatch.delenv("OSC_KNN_TILE_WIDE")
+    monkeypatch.setenv("OSC_KNN_MODE", "exact")
+    lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+    exact = _knn_sets(lat, N, k)
+    lat.close()
+    rows = np.nonzero((lists["1"] != exact).any(axis=1))[0]
+    assert rows.size <= 25, rows.size
+    for r in rows:
+        members = sorted(set(lists["1"][r].tolist()) ^ set(exact[r].tolist()))
+        assert near_tie_gap(Y, int(r), members) < 1e-6, (int(r), members)
+
+
 @pytest.mark.parametrize("N,D,k", [(17000, 1000, 32), (20000, 1536, 64), (16400, 800, 8)])
 def test_tile_core_threshold_route_beyond_768_columns(amd, N, D, k, monkeypatch):
     """D > 768: a wave's query panel no longer fits its registers, so the thresholds-and-hits prefilter runs on the tile core
