@@ -16,7 +16,7 @@ last = max(i for i, n in enumerate(names) if 'k_normalize_rows' in n)
 t0 = int(rows[last]['Start_Timestamp']); prev = t0
 for r in rows[last:]:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    n = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('osc::', '').replace('(anonymous namespace)::', '')[:60]
+    n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').replace('osc::', '').split('(')[0][:60]
     print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:9.1f} gap {(s - prev) / 1e3:8.1f}  {n}")
     prev = e
 print(f"total {(prev - t0) / 1e3:.1f} us")
