@@ -220,7 +220,14 @@ int osc_dynamics(osc_handle h, const float* U_prev_or_null, const float* U_next_
 /* Per-kernel HIP-event timing on the handle's own stream.  which: 0 = operator apply inside the CG loop (SpMM, the
  * CG matvec; one sample per apply = all its launches), 1 = fused x/r update, 2 = p update, 3 = kNN GEMM+top-k,
  * 4 = the initial-residual apply of a solve (same gather plus the rhs / r / p streams).  Returns samples and the
- * summed device time since the last reset.  Enabling adds two event records per sample. */
+ * summed device time since the last reset.  Enabling adds two event records per sample.
+ * Diagnostic slots of the source-blocked matvec (k_apply_blocked): with OSC_BLK_STAMP=1 in the environment at creation
+ * and profiling on, its loop-form launches run a cycle-stamping instantiation; which = 8..11 then return, in *total_ms,
+ * the shader cycles a gathering wave spent (mean over the waves, summed over the stamped launches) in all / in its gather
+ * rounds / at the workgroup barrier / in its epilogues, 12..13 the list wave's cycles fetching slot rows / at the barrier,
+ * and *launches = the stamped launches.  which = 14: *launches = the kernel shape the last blocked matvec ran with
+ * (0 = two 8-wave workgroups per CU, one gather round in flight; 1..3 = one workgroup per CU, four rounds in flight,
+ * 20 / 24 / 28 row groups per wave; OSC_BLK_VARIANT forces one), *total_ms = 0. */
 int osc_profile_enable(osc_handle h, int32_t on);
 int osc_profile_reset(osc_handle h);
 int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* total_ms);

@@ -14,6 +14,7 @@
 // Column sums never use atomics: each block keeps per-lane partials in registers over its grid-stride rows,
 // folds its 4 waves through LDS and writes one row of part[grid][ld]; a small second kernel finishes in fp64.
 #include "common.hpp"
+#include <type_traits>
 
 namespace osc {
 
@@ -375,9 +376,16 @@ __device__ __forceinline__ void blk_fold(float4 dot, float (&red)[NW][32], float
 // as P from here on --, copies x0 into the solution array where that is another one, and the column sums are those of
 // r . z.  Saves the separate pass over A x0, x0, y, r, p (k_init_finish: five array passes) for one more row read or
 // write here.
-template <int GM, int CW, bool INIT = false>
-__global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_apply_blocked(const BlkArgs a,
-                                                                                                            const BlkInit ii) {
+// PD: gather rounds a wave keeps in flight (round 5).  A wave's loads return in issue order and about a fifth of the gathers
+// miss the L2, so a round of 32 lines practically always waits for one fabric round trip: with one round in flight the
+// kernel is bound by bytes in flight / miss latency.  PD > 1 issues round g + PD - 1 before it consumes round g (the
+// slots' weights and the gathered rows of PD rounds in registers).  WPE: waves per SIMD the register budget is set for.
+// STAMP (diagnostic instantiations, OSC_BLK_STAMP=1; loop form only): every wave adds the shader cycles it spent in its
+// gather rounds / epilogues / at the barrier (the list wave: fetching / at the barrier) to words of its own in the
+// buffer ii.R points to -- where a launch's time goes, wave by wave (osc_profile_get slots 8-13).
+template <int GM, int CW, bool INIT = false, int PD = 1, int WPE = 4, bool STAMP = false>
+__global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_apply_blocked(const BlkArgs a,
+                                                                                                                const BlkInit ii) {
   constexpr int SL = OSC_BLK_SLOTS, NT = (CW + 1) * 64;
   __shared__ __attribute__((aligned(16))) float red[CW + 1][32];
   // per gathering wave: the slots of each of its rows in the current block, and (other half) in the next one
@@ -427,8 +435,12 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
       const int w8 = opaque(W8);
 #pragma unroll
       for (int g = 0; g < GM; ++g) {
-        if (g >= ng || row0 + g * w8 >= a.N) continue;  // (a group that starts past the lattice: nobody reads its area)
-        const char* src = sb + (size_t)(uint32_t)(row0 + g * w8) * (8u * SL);
+        const bool inside = g < ng && row0 + g * w8 < a.N;
+        if (PD == 1 && !inside) continue;  // (a group that starts past the lattice: nobody reads its area)
+        // PD > 1: the gather rounds carry no tests at all, so every group's area is staged -- one that does not exist from the
+        // zeroed padding behind the last block ({row 0, 0.0f}: one line for the whole wave, a product with zero)
+        const char* src = inside ? sb + (size_t)(uint32_t)(row0 + g * w8) * (8u * SL)
+                                 : reinterpret_cast<const char*>(a.slots + (size_t)nb * (size_t)a.N * SL);
         const unsigned dst = __builtin_amdgcn_readfirstlane(stage_lds + (unsigned)(((ph & 1) * GM + g) * GROUP_BYTES));
 #pragma unroll
         for (int q = 0; q < PIECES; ++q) {
@@ -442,16 +454,38 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
           }
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    unsigned long long t_fetch = 0, t_bar = 0, t_all = 0, ts = 0;
+    if constexpr (STAMP) t_all = ts = __builtin_amdgcn_s_memtime();
+    auto lap = [&](unsigned long long& into) {
+      if constexpr (STAMP) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        into += now - ts;
+        ts = now;
+      }
     };
     if (nphase > 0) fetch_slots(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lap(t_fetch);
     __syncthreads();
+    lap(t_bar);
     for (int ph = 0; ph < nphase; ++ph) {
       if (ph + 1 < nphase) fetch_slots(ph + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lap(t_fetch);
       __syncthreads();
+      lap(t_bar);
       if ((ph + 1) % per_slab == 0) {
         const int sc0 = phase(ph).sc0;
         blk_fold<CW + 1>(f4(0.f), red, a.part, ld, sc0, min(a.c1, sc0 + 32), wave, lane);
+      }
+    }
+    if constexpr (STAMP) {
+      if (lane == 0) {
+        unsigned long long* w = reinterpret_cast<unsigned long long*>(ii.R) + ((size_t)blockIdx.x * (CW + 1) + wave) * 4;
+        w[0] += __builtin_amdgcn_s_memtime() - t_all;
+        w[1] += t_fetch;
+        w[2] += t_bar;
       }
     }
     return;
@@ -461,7 +495,17 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
   const uint32_t lr16 = (uint32_t)lr * 16u;
   float4 acc[GM];
   float4 dot[1] = {f4(0.f)};
+  unsigned long long t_gather = 0, t_epi = 0, t_bar = 0, t_all = 0, ts = 0;
+  if constexpr (STAMP) t_all = ts = __builtin_amdgcn_s_memtime();
+  auto lap = [&](unsigned long long& into) {
+    if constexpr (STAMP) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      into += now - ts;
+      ts = now;
+    }
+  };
   __syncthreads();
+  lap(t_bar);
   for (int ph = 0; ph < nphase; ++ph) {
     const BlkPhase p = phase(ph);
     const bool cok = p.sc0 + lr * 4 < a.c1;
@@ -476,25 +520,63 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
     // round is bound by instruction issue (four waves share a SIMD), and a compare + exec-mask + branch per slot cost
     // more than the fifth of the gathers they saved.
     const int wg_row0 = rlo + p.slice * slice_rows + ((wgx * CW) << 3);  // first row of this workgroup's group 0
+    if constexpr (PD == 1) {
 #pragma unroll
-    for (int g = 0; g < GM; ++g) {
-      if (g >= ng || wg_row0 + g * W8 >= a.N) continue;  // (same test as the list wave's: that area was not staged)
-      int2 e[SL];
-      float4 v[SL];
+      for (int g = 0; g < GM; ++g) {
+        if (g >= ng || wg_row0 + g * W8 >= a.N) continue;  // (same test as the list wave's: that area was not staged)
+        int2 e[SL];
+        float4 v[SL];
 #pragma unroll
-      for (int u = 0; u < SL; ++u) e[u] = st[g][wave][sub * SL + u];
+        for (int u = 0; u < SL; ++u) e[u] = st[g][wave][sub * SL + u];
 #pragma unroll
-      for (int u = 0; u < SL; ++u) v[u] = ld4_at(xbase, (uint32_t)e[u].x * 128u + lr16);
+        for (int u = 0; u < SL; ++u) v[u] = ld4_at(xbase, (uint32_t)e[u].x * 128u + lr16);
 #pragma unroll
-      for (int u = 0; u < SL; ++u) acc[g] = fma4(__int_as_float(e[u].y), v[u], acc[g]);
+        for (int u = 0; u < SL; ++u) acc[g] = fma4(__int_as_float(e[u].y), v[u], acc[g]);
+      }
+    } else {
+      // PD rounds in flight, straight-line: round g + PD - 1 is issued (slots from LDS, four row gathers per lane) before
+      // round g is consumed, so the compiler's counted waits leave SL * (PD - 1) loads in flight in the steady state.
+      // No test per group: the list wave staged every group's area (see there).
+      typedef float f32x4 __attribute__((ext_vector_type(4)));  // (a native vector: one 128-bit operand of the asm below)
+      f32x4 v[PD][SL];
+      float w[PD][SL];
+      auto issue = [&](int g, f32x4 (&vv)[SL], float (&ww)[SL]) {
+        int2 e[SL];
+#pragma unroll
+        for (int u = 0; u < SL; ++u) e[u] = st[g][wave][sub * SL + u];
+#pragma unroll
+        for (int u = 0; u < SL; ++u)
+          vv[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xbase) + ((uint32_t)e[u].x * 128u + lr16));
+#pragma unroll
+        for (int u = 0; u < SL; ++u) ww[u] = __int_as_float(e[u].y);
+      };
+#pragma unroll
+      for (int j = 0; j < PD - 1 && j < GM; ++j) issue(j, v[j % PD], w[j % PD]);
+#pragma unroll
+      for (int g = 0; g < GM; ++g) {
+        if (g + PD - 1 < GM) issue(g + PD - 1, v[(g + PD - 1) % PD], w[(g + PD - 1) % PD]);
+        // round g's rows pass through an empty asm with a memory clobber: its sums can start only here (behind the
+        // issue of round g + PD - 1), and a later round's loads cannot be moved up past it
+#pragma unroll
+        for (int u = 0; u < SL; ++u) asm volatile("" : "+v"(v[g % PD][u])::"memory");
+#pragma unroll
+        for (int u = 0; u < SL; ++u) {
+          const f32x4 t = v[g % PD][u];
+          acc[g] = fma4(w[g % PD][u], make_float4(t.x, t.y, t.z, t.w), acc[g]);
+        }
+        // ... and end here (volatile asm statements keep their order): otherwise the compiler may postpone the sums of
+        // all rounds and park the gathered rows in scratch memory meanwhile
+        asm volatile("" : "+v"(acc[g].x), "+v"(acc[g].y), "+v"(acc[g].z), "+v"(acc[g].w));
+      }
     }
+    lap(t_gather);
     if (p.b == nb - 1) {  // the rows of this slice are complete: the rest of long lists, diagonal term, output, p.Ap
       const int w8 = opaque(W8);
       const int row_first = rlo + p.slice * slice_rows + ((wgx * CW + wave) << 3) + sub;
       // Own rows / gates / rest descriptors of EC groups at a time (these loads miss).  Loads and stores of a wave retire
       // in issue order, so the loads of batch k + 1 are issued BEFORE the stores of batch k: otherwise every batch would
       // also wait for the previous batch's stores to be acknowledged.
-      constexpr int EC = INIT ? 1 : 2, NBATCH = (GM + EC - 1) / EC;  // (INIT: the y rows take the second group's registers; two groups: 72 spills)
+      constexpr int EC = INIT ? 1 : WPE <= 2 ? 4 : 2, NBATCH = (GM + EC - 1) / EC;  // (INIT: the y rows take the second group's registers; two groups: 72 spills)
       float4 xs[2][EC];
       float4 ys[2][INIT ? EC : 1];
       int2 rr[2][EC];
@@ -566,10 +648,21 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4
         }
       }
     }
+    lap(t_epi);
     __syncthreads();
+    lap(t_bar);
     if ((ph + 1) % per_slab == 0) {  // the slab's column sums
       blk_fold<CW + 1>(dot[0], red, a.part, ld, p.sc0, min(a.c1, p.sc0 + 32), wave, lane);
       dot[0] = f4(0.f);
+    }
+  }
+  if constexpr (STAMP) {
+    if (lane == 0) {
+      unsigned long long* w = reinterpret_cast<unsigned long long*>(ii.R) + ((size_t)blockIdx.x * (CW + 1) + wave) * 4;
+      w[0] += __builtin_amdgcn_s_memtime() - t_all;
+      w[1] += t_gather;
+      w[2] += t_bar;
+      w[3] += t_epi;
     }
   }
 }
@@ -1063,8 +1156,31 @@ void launch_blocked_fill(const int32_t* col, const float* w, const int32_t* deg,
                      slots, rest, over, over_count);
   HIP_CHECK(hipGetLastError());
 }
-int blocked_groups_max() { return kBlkGroups; }
-int blocked_gather_waves() { return kBlkGatherWaves; }
+// The shapes of k_apply_blocked the library holds: {row groups per gathering wave, gathering waves per workgroup, gather
+// rounds in flight per wave, waves per SIMD}.  0: rounds 2-4 (two 8-wave workgroups per CU, one round in flight, tests per
+// group).  1-3 (round 5, "wide"): ONE 8-wave workgroup per CU at two waves per SIMD, four rounds in flight, test-free
+// straight-line rounds -- so the group count is a template constant and there are three of them (blocked_shape_for picks
+// the smallest that holds the lattice's groups).
+struct BlkShape {
+  int gm, cw, pd, wpe;
+};
+constexpr BlkShape kBlkShapes[] = {{kBlkGroups, kBlkGatherWaves, 1, 4}, {20, 7, 4, 2}, {24, 7, 4, 2}, {28, 7, 4, 2}};
+constexpr int kBlkShapeCount = (int)(sizeof(kBlkShapes) / sizeof(kBlkShapes[0]));
+#define OSC_BLK_SHAPE_SWITCH(v, CALL) \
+  switch (v) {                        \
+    case 0: CALL(kBlkGroups, kBlkGatherWaves, 1, 4); break; \
+    case 1: CALL(20, 7, 4, 2); break; \
+    case 2: CALL(24, 7, 4, 2); break; \
+    case 3: CALL(28, 7, 4, 2); break; \
+    default: throw std::runtime_error("blocked apply: unknown kernel shape"); \
+  }
+static const BlkShape& blk_shape(int variant) {
+  if (variant < 0 || variant >= kBlkShapeCount) throw std::runtime_error("blocked apply: unknown kernel shape");
+  return kBlkShapes[variant];
+}
+int blocked_variants() { return kBlkShapeCount; }
+int blocked_groups_max(int variant) { return blk_shape(variant).gm; }
+int blocked_gather_waves(int variant) { return blk_shape(variant).cw; }
 void launch_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, int32_t c0, int32_t c1, int grid, hipStream_t s) {
   for (int32_t s0 = c0; s0 < c1; s0 += 2048) {  // at most 2048 columns per launch, like the other elementwise kernels
     const int32_t s1 = std::min(c1, s0 + 2048);
@@ -1090,22 +1206,35 @@ void launch_chain_fix(const ChainFixArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_chain_fix, dim3((a.c1 - a.c0 + 63) / 64, a.chunks), dim3(64), 0, s, a);
   HIP_CHECK(hipGetLastError());
 }
-int blocked_resident_per_cu() {
+int blocked_resident_per_cu(int variant) {
   int n = 0;
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_apply_blocked<kBlkGroups, kBlkGatherWaves, false>, (kBlkGatherWaves + 1) * 64, 0));
+#define CALL(G, W, P, E) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_apply_blocked<G, W, false, P, E>, (W + 1) * 64, 0))
+  OSC_BLK_SHAPE_SWITCH(variant, CALL);
+#undef CALL
   return n;
 }
 
-void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s, const BlkInit* init) {
+void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s, const BlkInit* init, int variant, unsigned long long* stamps) {
+  const BlkShape& sh = blk_shape(variant);
   if (grid < 8 || (grid & 7) != 0 || a.xs < 1 || a.xs > grid / 8 || a.xs_groups < 1 || 8 % a.xs_groups != 0 || a.groups < 1 ||
-      a.groups > kBlkGroups || a.slices < 1 || a.nb < 1 || a.nb > OSC_MAX_SRC_BLOCKS || !a.slots || !a.rest ||
+      a.groups > sh.gm || a.slices < 1 || a.nb < 1 || a.nb > OSC_MAX_SRC_BLOCKS || !a.slots || !a.rest ||
       (int64_t)a.N * a.ld * 4 >= ((int64_t)1 << 32) || (a.c0 & 31) != 0)
     throw std::runtime_error("blocked apply: unsupported arguments");
   if (init != nullptr) {
     if (!init->R || !init->Z || !init->psi || init->Z == a.X) throw std::runtime_error("blocked apply: bad INIT arguments");
-    hipLaunchKernelGGL((k_apply_blocked<kBlkGroups, kBlkGatherWaves, true>), dim3(grid), dim3((kBlkGatherWaves + 1) * 64), 0, s, a, *init);
+#define CALL(G, W, P, E) hipLaunchKernelGGL((k_apply_blocked<G, W, true, P, E>), dim3(grid), dim3((W + 1) * 64), 0, s, a, *init)
+    OSC_BLK_SHAPE_SWITCH(variant, CALL);
+#undef CALL
+  } else if (stamps != nullptr) {  // diagnostic: [grid][waves][4] cycle counters, added to launch after launch
+    BlkInit st{};
+    st.R = reinterpret_cast<float*>(stamps);
+#define CALL(G, W, P, E) hipLaunchKernelGGL((k_apply_blocked<G, W, false, P, E, true>), dim3(grid), dim3((W + 1) * 64), 0, s, a, st)
+    OSC_BLK_SHAPE_SWITCH(variant, CALL);
+#undef CALL
   } else {
-    hipLaunchKernelGGL((k_apply_blocked<kBlkGroups, kBlkGatherWaves, false>), dim3(grid), dim3((kBlkGatherWaves + 1) * 64), 0, s, a, BlkInit{});
+#define CALL(G, W, P, E) hipLaunchKernelGGL((k_apply_blocked<G, W, false, P, E>), dim3(grid), dim3((W + 1) * 64), 0, s, a, BlkInit{})
+    OSC_BLK_SHAPE_SWITCH(variant, CALL);
+#undef CALL
   }
   HIP_CHECK(hipGetLastError());
 }

@@ -212,8 +212,9 @@ void launch_blocked_count(const int32_t* col, const int32_t* deg, int32_t width,
 void launch_blocked_fill(const int32_t* col, const float* w, const int32_t* deg, int32_t width, int32_t N, int32_t nb,
                          int2* slots, int2* rest, int2* over, unsigned* over_count, hipStream_t s);
 // row groups per wave the blocked apply holds in registers, and the workgroups per CU it needs resident
-int blocked_groups_max();
-int blocked_gather_waves();
+int blocked_variants();                 // kernel shapes of the blocked matvec (OSC_BLK_VARIANT)
+int blocked_groups_max(int variant);
+int blocked_gather_waves(int variant);
 // Chain prior beside the blocked matvec: out_i -= cP sum_j Wp_ij x_j for the (few) rows of the chain's path graph, and
 // the matching terms of the p . Ap column sums into the rows [part_row0, part_row0 + chunks) of `part`.
 constexpr int OSC_CHAIN_FIX_MAX_ROWS = 4096;
@@ -259,8 +260,9 @@ void launch_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, in
 void launch_init_finish(const InitFinishArgs& a, int grid, hipStream_t s);
 int chain_fix_chunks(int32_t prows);
 void launch_chain_fix(const ChainFixArgs& a, hipStream_t s);
-void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s, const BlkInit* init = nullptr);
-int blocked_resident_per_cu();
+void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s, const BlkInit* init = nullptr, int variant = 0,
+                          unsigned long long* stamps = nullptr);
+int blocked_resident_per_cu(int variant);
 void launch_spmm(int mode, const SpmmArgs& a, int grid, hipStream_t s);
 void launch_update_xr(const UpdateArgs& a, int grid, hipStream_t s);
 void launch_update_p(const UpdateArgs& a, int grid, hipStream_t s);

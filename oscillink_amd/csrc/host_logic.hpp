@@ -249,6 +249,12 @@ inline int64_t blocked_list_extent(int64_t N, const BlockedGeom& g, int gather_w
 // per slab at N = 100k, also run fastest at 3.3).  Config 5 (N = 200k, k = 64): 16 -> 24 blocks took the L2 misses per
 // apply from 367 M to 183 M, the bytes fetched from 45.6 to 22.5 GB and the apply from 6.98 to 5.00 ms.
 inline double blocked_edges_per_block(int64_t N) { return N <= 140000 ? 3.3 : 2.5; }
+// ... under the wide kernel shapes (round 5: one workgroup per CU, four gather rounds in flight) fuller slot rows win at
+// every size -- fewer sub-phases per slab, fewer slot rows to stage, and the displaced edges' misses travel in a deeper
+// pipeline (scripts/exp/nb_sweep.py, profiles/r05_nb_sweep.txt, per AP launch): 100k x 768 k 32 8 blocks 0.554 ms / 9 0.557
+// / 12 0.627; k 16 4-5 blocks; k 64 16-18; 160k and 200k x 768 k 32 9 blocks (200k: 1.220 against 1.303 at the 12 the old
+// rule gives); 260k 10; 200k x 1536 k 64 16-18 blocks 4.03 ms against 4.59 at 24.
+inline double blocked_edges_per_block_wide(int64_t N) { return N <= 140000 ? 3.5 : N <= 220000 ? 3.2 : 2.9; }
 inline int blocked_block_count(double mean_deg, double edges_per_block, int max_blocks) {
   const int nb = (int)std::max(2.0, std::floor(mean_deg / edges_per_block + 0.5));
   return std::min(nb, max_blocks);

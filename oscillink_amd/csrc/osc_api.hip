@@ -255,7 +255,14 @@ struct osc_lattice {
   int spmm_blocked = -1;   // -1 by lattice size, 0 off, > 0 = that many source blocks (OSC_SPMM_BLOCKED)
   double blk_mb = 2.0;     // smallest slab (N x 128 B, MiB) the blocked apply is chosen for
   double blk_edges = 0.0;  // edges of a row per source block the block count aims at; 0 = by lattice size: 3.3 / 2.5
-  int blk_resident = -1;   // workgroups per XCD the blocked apply gets resident (queried once)
+  mutable int blk_resident[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // workgroups per XCD each shape of the blocked apply gets resident (queried once)
+  int blk_variant = -1;    // kernel shape of the blocked matvec (cg_kernels.hip: kBlkShapes); -1 = by geometry (blocked_shape_for), OSC_BLK_VARIANT forces one
+  int blk_shape_last = 0;  // the shape the last general-path solve's blocked matvec ran with
+  int blk_wide_min_rows = 0;  // smallest lattice the wide shapes are chosen for (OSC_BLK_WIDE_MIN_ROWS; 0 = default)
+  bool blk_stamp = false;  // OSC_BLK_STAMP=1: while profiling is on, the AP applies run the cycle-stamping instantiation
+  DevBuf<unsigned long long> blk_stamps;  // [grid][waves per workgroup][4] (osc_profile_get slots 8-13)
+  int64_t blk_stamp_launches = 0;
+  int blk_stamp_grid = 0;
   int blk_last = 0;        // source blocks the last general-path solve's matvec used (0 = plain apply)
   double temporal_mb = 200.0;  // largest solve (5 arrays x N x window) whose update kernels use ordinary instead of nontemporal accesses
   bool spmm_deep = true;   // re-ordered lattices: the operator apply with 8 gathers in flight per row (OSC_SPMM_DEEP=0: the usual 2)
@@ -1257,6 +1264,36 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   return nb;
 }
 
+// workgroups per XCD a shape of the blocked apply gets resident
+int blocked_resident(const L& h, int shape) {
+  if (h.blk_resident[shape] < 0) {
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, h.device));
+    h.blk_resident[shape] = blocked_resident_per_cu(shape) * std::max(1, prop.multiProcessorCount / 8);
+  }
+  return h.blk_resident[shape];
+}
+
+// Kernel shape of the blocked matvec for a window cut into xg slab groups (cg_kernels.hip: kBlkShapes).  The wide shapes
+// (one workgroup per CU, four gather rounds in flight, no tests in the rounds) carry their group count as a template
+// constant and gather padding for the groups a lattice does not fill, so they are taken where the lattice fills at least
+// 17 of the smallest one's 20 -- in practice N >= ~60k rows per slab group -- and the smallest that fits is used.
+int blocked_shape_for(const L& h, int xg, int grid) {
+  if (h.blk_variant >= 0) return h.blk_variant;
+  const int wide_last = blocked_variants() - 1;
+  const host::BlockedGeom g = host::blocked_geometry(h.N, xg, grid, blocked_resident(h, wide_last), blocked_groups_max(wide_last),
+                                                     blocked_gather_waves(wide_last));
+  // Measured against shape 0 (profiles/r05_blk_shape_sweep.txt, per AP launch): 40k x 768 +5.5 %, 60k x 768 +6.0 %, 80k x 768
+  // +2.2 %, 100k x 768 -4.6 %, 100k x 384 k 16 -4.8 %, 100k x 1024 k 48 -4.0 %, 160k x 768 -10.9 %, 200k x 768 -9.6 %, 260k x 512
+  // -15.0 %, 400k x 384 k 16 -7.1 %; one slab per XCD (130k x 256) +3.6 %: there the wide shapes wait for N = 150k.
+  const int64_t min_rows = h.blk_wide_min_rows > 0 ? h.blk_wide_min_rows : 96000;
+  const int slabs_per_group = ((h.c1 - h.c0 + 31) / 32 + xg - 1) / std::max(1, xg);
+  if (h.N < min_rows || g.groups < 17 || (h.blk_wide_min_rows <= 0 && slabs_per_group < 2 && h.N < 150000)) return 0;
+  for (int v = 1; v <= wide_last; ++v)
+    if (g.groups <= blocked_groups_max(v)) return v;
+  return 0;
+}
+
 // Source blocks of the blocked CG matvec (k_apply_blocked): 0 = use the plain apply.
 int blocked_plan(const L& h, bool with_path) {
   if (h.spmm_blocked == 0 || (with_path && (h.prows < 1 || h.prows > OSC_CHAIN_FIX_MAX_ROWS)) || (int64_t)h.N * h.width >= ((int64_t)1 << 28) || h.N >= ((int64_t)1 << 24) ||
@@ -1267,7 +1304,12 @@ int blocked_plan(const L& h, bool with_path) {
   // overrides the edges a row should have per block
   const double mean_deg = h.N > 0 ? (double)h.nnz / (double)h.N : 0.0;
   // (a lattice in BFS order: 2.2 edges per block -- x4 of x2 / x3 / x4 / x6 / x8 at mean degree 8.3, x8 of x6 / x8 / x12 at 20.2)
-  const double e = h.blk_edges > 0.0 ? h.blk_edges : h.reordered ? 2.2 : host::blocked_edges_per_block(h.N);
+  const int ncols = h.c1 - h.c0, xg0 = xs_groups_for(h, ncols);
+  const bool wide = blocked_shape_for(h, xg0 > 0 ? xg0 : xs_groups(ncols, h.xs_groups_cap), cg_grid(h)) > 0;
+  const double e = h.blk_edges > 0.0 ? h.blk_edges
+                   : h.reordered     ? 2.2
+                   : wide            ? host::blocked_edges_per_block_wide(h.N)
+                                     : host::blocked_edges_per_block(h.N);
   const int nb = host::blocked_block_count(mean_deg, e, OSC_MAX_SRC_BLOCKS);
   if (h.spmm_blocked == -2) return nb;  // "whenever possible" (experiments)
   // ... and wherever the XCD-affine slab mode itself runs from a 2 MiB slab (N = 16384) on.  Measured against the plain
@@ -1295,7 +1337,8 @@ BlockedView blocked_view(L& h, int nb) {
     // the apply's list wave copies whole row groups: up to 8 x gather-waves slot rows past the lattice's end
     // (host_logic.hpp: blocked_list_extent <= N - 1 + 8 x gather waves, swept in tests/host_logic)
     constexpr size_t kPadRows = 8192;
-    if ((size_t)blocked_gather_waves() * 8 > kPadRows) throw std::runtime_error("blocked graph copy: padding too small");
+    for (int v = 0; v < blocked_variants(); ++v)
+      if ((size_t)blocked_gather_waves(v) * 8 > kPadRows) throw std::runtime_error("blocked graph copy: padding too small");
     const size_t nslots = (size_t)nb * h.N * OSC_BLK_SLOTS, npad = kPadRows * OSC_BLK_SLOTS;
     h.blk_slots.alloc(nslots + npad);
     HIP_CHECK(hipMemsetAsync(h.blk_slots.p + nslots, 0, npad * sizeof(int2), h.stream));  // {row 0, 0.0f}
@@ -1306,11 +1349,6 @@ BlockedView blocked_view(L& h, int nb) {
                         h.stream);
     sync(h);  // cnt goes out of scope
     h.blk_nb = nb;
-  }
-  if (h.blk_resident < 0) {
-    hipDeviceProp_t prop;
-    HIP_CHECK(hipGetDeviceProperties(&prop, h.device));
-    h.blk_resident = blocked_resident_per_cu() * std::max(1, prop.multiProcessorCount / 8);  // per XCD
   }
   BlockedView v{};
   v.slots = h.blk_slots.p;
@@ -1542,6 +1580,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   // source-blocked CG matvec (k_apply_blocked) where the slab an XCD gathers from is far larger than its L2
   BlkArgs ba{};
   ChainFixArgs cf{};
+  int blk_shape = 0;
   if (pblk && b.c0 == h.c0 && b.c1 == h.c1) {
     if (const int nb = blocked_plan(h, with_path)) {
       const BlockedView bv = blocked_view(h, nb);
@@ -1561,9 +1600,10 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       ba.c1 = b.c1;
       ba.nb = nb;
       // workgroups per XCD (what is resident at once), slab groups, row groups per wave, destination slices
-      const int xg = xs_groups_for(h, b.c1 - b.c0);
-      const host::BlockedGeom geom = host::blocked_geometry(h.N, xg > 0 ? xg : xs_groups(b.c1 - b.c0, h.xs_groups_cap), grid,
-                                                           h.blk_resident, blocked_groups_max(), blocked_gather_waves());
+      const int xg0 = xs_groups_for(h, b.c1 - b.c0), xg = xg0 > 0 ? xg0 : xs_groups(b.c1 - b.c0, h.xs_groups_cap);
+      blk_shape = blocked_shape_for(h, xg, grid);
+      const host::BlockedGeom geom = host::blocked_geometry(h.N, xg, grid, blocked_resident(h, blk_shape), blocked_groups_max(blk_shape),
+                                                           blocked_gather_waves(blk_shape));
       ba.xs = geom.xs;
       ba.xs_groups = geom.xs_groups;
       ba.slices = geom.slices;
@@ -1617,7 +1657,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     bi.md_const = op.precond ? op.md_const : 1.f;
     ba.gate = nullptr;
     ba.OUT = nullptr;
-    launch_apply_blocked(ba, grid, h.stream, &bi);
+    launch_apply_blocked(ba, grid, h.stream, &bi, blk_shape);
     if (cf.chunks > 0) {  // the chain prior's rows: their r, z and r . z still lack the chain term
       ChainFixArgs ci = cf;
       ci.gate = nullptr;
@@ -1639,7 +1679,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
     ProfScope ps(h, 4, 0);
     launch_rows_to_slab(b.x0, b.P, h.N, b.ld, b.c0, b.c1, grid, h.stream);
     ba.gate = nullptr;
-    launch_apply_blocked(ba, grid, h.stream);
+    launch_apply_blocked(ba, grid, h.stream, nullptr, blk_shape);
     if (cf.chunks > 0) {
       cf.gate = nullptr;
       launch_chain_fix(cf, h.stream);
@@ -1690,6 +1730,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   sa.xblk = pblk ? h.N : 0;
   sa.pblk = 0;
   h.blk_last = ba.nb;
+  h.blk_shape_last = ba.nb > 0 ? blk_shape : 0;
   // Deferred x update: iteration it's x += alpha p is applied by iteration it + 1's p update, which reads p anyway (x, r,
   // p in / x, p out there, r, Ap in / r out in the x-r kernel: 8 array passes per iteration instead of 9), or by
   // finish_x behind an iteration that has no successor enqueued.  The iteration expected to be the last (the count of
@@ -1728,7 +1769,19 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
       ProfScope ps(h, 0, it);
       ba.gate = g.p;
       ba.gate_tol = tol;
-      launch_apply_blocked(ba, grid, h.stream);
+      unsigned long long* stamps = nullptr;
+      if (h.blk_stamp && h.prof_on) {  // diagnostic: per-wave cycle counters of where the launch's time goes
+        const size_t words = (size_t)grid * (size_t)(blocked_gather_waves(blk_shape) + 1) * 4;
+        if (h.blk_stamps.n != words || h.blk_stamp_grid != grid) {
+          h.blk_stamps.alloc(words);
+          HIP_CHECK(hipMemsetAsync(h.blk_stamps.p, 0, words * 8, h.stream));
+          h.blk_stamp_launches = 0;
+          h.blk_stamp_grid = grid;
+        }
+        stamps = h.blk_stamps.p;
+        h.blk_stamp_launches += 1;
+      }
+      launch_apply_blocked(ba, grid, h.stream, nullptr, blk_shape, stamps);
       if (cf.chunks > 0) {
         cf.gate = g.p;
         cf.gate_tol = tol;
@@ -2120,6 +2173,9 @@ void read_env(L& h) {
   if (num("OSC_XS_GROUPS", v)) h.xs_groups_cap = v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : 1;
   if (num("OSC_P_BLOCKED", v)) h.p_blocked = v != 0;
   if (num("OSC_SPMM_BLOCKED", v)) h.spmm_blocked = v;
+  if (num("OSC_BLK_STAMP", v)) h.blk_stamp = v != 0;
+  if (num("OSC_BLK_VARIANT", v)) h.blk_variant = (v >= 0 && v < blocked_variants()) ? v : -1;
+  if (num("OSC_BLK_WIDE_MIN_ROWS", v)) h.blk_wide_min_rows = std::max(0, v);
   if (num("OSC_BLK_INIT", v)) {
     h.blk_init = v != 0;
     h.blk_init_fused = v == 1;
@@ -3272,11 +3328,41 @@ int osc_profile_reset(osc_handle h) {
       l.prof_count[i] = 0;
       l.prof_ms[i] = 0.0;
     }
+    if (l.blk_stamps.n) {
+      HIP_CHECK(hipMemsetAsync(l.blk_stamps.p, 0, l.blk_stamps.n * 8, l.stream));
+      l.blk_stamp_launches = 0;
+    }
   });
 }
 int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* total_ms) {
   return guarded(h, [&](L& l) {
-    if (which < 0 || which > 4) throw Invalid("osc_profile_get: which must be 0..4");
+    if (which == 14) {  // the kernel shape of the last blocked matvec
+      if (launches) *launches = l.blk_shape_last;
+      if (total_ms) *total_ms = 0.0;
+      return;
+    }
+    if (which >= 8 && which <= 13) {
+      // cycle stamps of the blocked matvec (OSC_BLK_STAMP=1): mean over the waves of a role of the shader cycles summed
+      // over the stamped launches.  8-11: gathering waves' lifetime / gather rounds / barrier / epilogue; 12-13: the list
+      // waves' fetch / barrier.  *launches = stamped launches (speculative, gated-off ones included: they add ~nothing).
+      prof_drain(l);
+      sync(l);
+      const int wpg = blocked_gather_waves(l.blk_shape_last) + 1;
+      std::vector<unsigned long long> w(l.blk_stamps.n);
+      if (!w.empty()) HIP_CHECK(hipMemcpy(w.data(), l.blk_stamps.p, w.size() * 8, hipMemcpyDeviceToHost));
+      double sum = 0.0;
+      int64_t cnt = 0;
+      for (size_t i = 0; i + 3 < w.size(); i += 4) {
+        const bool list_wave = (int)((i / 4) % (size_t)wpg) == wpg - 1;
+        if (w[i] == 0 || list_wave != (which >= 12)) continue;  // (workgroups that took no part have no stamps)
+        sum += (double)w[i + (which >= 12 ? which - 11 : which - 8)];
+        cnt += 1;
+      }
+      if (launches) *launches = l.blk_stamp_launches;
+      if (total_ms) *total_ms = cnt ? sum / (double)cnt : 0.0;
+      return;
+    }
+    if (which < 0 || which > 4) throw Invalid("osc_profile_get: which must be 0..4 (or 8..14: blocked matvec diagnostics)");
     prof_drain(l);
     if (launches) *launches = l.prof_count[which];
     if (total_ms) *total_ms = l.prof_ms[which];

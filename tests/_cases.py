@@ -43,6 +43,21 @@ def relerr(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def ctor_kwargs(recipe):
+    """The constructor's other arguments a fixture was generated with (lattice.py:33-43): row_cap_val, lamG, lamC, lamQ --
+    present in the recipe only where they are off the reference's defaults (round-5 fixtures)."""
+    return {k: recipe[k] for k in ("row_cap_val", "lamG", "lamC", "lamQ") if k in recipe}
+
+
+# round 5: the row-sum cap below 1 / inactive, lambdas off their defaults and exactly zero (tests/golden/make_golden.py)
+PARAM_CASES = [
+    "cap025_n300_d48_k8",
+    "capoff_n300_d48_k8",
+    "lam_g03_c0_q0_n240_d40_k6",
+    "lam_g03_c07_q0_n240_d40_k6",
+    "lam_g25_c2_q15_cap05_n240_d40_k6",
+]
+
 ALL_CASES = [
     "c1_n80_d128_k8",
     "c2_n1200_d128_k16",
@@ -51,4 +66,4 @@ ALL_CASES = [
     "gates_chain_n333_d50_k7",
     "c5mini_n600_d96_k12",
     "nondet_n256_d32_k5",
-]
+] + PARAM_CASES

@@ -92,7 +92,10 @@ def history_of(lat, mode, dt=1.0, tol=1e-3, max_iters=12):
 
 
 def run_case(name, *, N, D, k, gen, psi_mode, chain=None, lamP=0.2, gates=None, settle=(12, 1e-3),
-             detail="full", seed=0, store_U=True, neighbor_seed=None, deterministic=True, diffusion=None):
+             detail="full", seed=0, store_U=True, neighbor_seed=None, deterministic=True, diffusion=None,
+             row_cap_val=None, lams=None):
+    """row_cap_val / lams = (lamG, lamC, lamQ): the constructor's other arguments (lattice.py:33-43); None = the
+    reference's defaults (1.0 and (1.0, 0.5, 4.0)) -- the recipe then carries no such key, as in the round-1 fixtures."""
     if gen == "RandomState":
         rs = np.random.RandomState(seed)
         Y = rs.randn(N, D).astype(np.float32)
@@ -102,7 +105,12 @@ def run_case(name, *, N, D, k, gen, psi_mode, chain=None, lamP=0.2, gates=None, 
         Y = rng.standard_normal((N, D)).astype(np.float32)
         psi = (Y[: min(32, N)].mean(axis=0)).astype(np.float32) if psi_mode == "mean32" else rng.standard_normal(D).astype(np.float32)
     psi = (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
-    lat = OscillinkLattice(Y, kneighbors=k, deterministic_k=deterministic, neighbor_seed=neighbor_seed)
+    extra = {}
+    if row_cap_val is not None:
+        extra["row_cap_val"] = float(row_cap_val)
+    if lams is not None:
+        extra.update(lamG=float(lams[0]), lamC=float(lams[1]), lamQ=float(lams[2]))
+    lat = OscillinkLattice(Y, kneighbors=k, deterministic_k=deterministic, neighbor_seed=neighbor_seed, **extra)
     lat.set_receipt_detail(detail)
     g = None
     if gates == "random":
@@ -118,10 +126,12 @@ def run_case(name, *, N, D, k, gen, psi_mode, chain=None, lamP=0.2, gates=None, 
     rec = lat.receipt()
     Ustar = lat.solve_Ustar()
     indptr, indices, data = csr_of(lat.A)
+    recipe = dict(N=N, D=D, k=k, gen=gen, psi_mode=psi_mode, seed=seed, chain=list(chain) if chain else None,
+                  lamP=lamP if chain else 0.0, gates=gates, settle_max_iters=settle[0], settle_tol=settle[1],
+                  deterministic=deterministic, neighbor_seed=neighbor_seed, diffusion=diffusion, detail=detail)
+    recipe.update(extra)
     out = dict(
-        recipe=json.dumps(dict(N=N, D=D, k=k, gen=gen, psi_mode=psi_mode, seed=seed, chain=list(chain) if chain else None,
-                               lamP=lamP if chain else 0.0, gates=gates, settle_max_iters=settle[0], settle_tol=settle[1],
-                               deterministic=deterministic, neighbor_seed=neighbor_seed, diffusion=diffusion, detail=detail)),
+        recipe=json.dumps(recipe),
         indptr=indptr, indices=indices, A_data=data, sqrt_deg=lat.sqrt_deg.astype(np.float32),
         settle_iters=st["iters"], settle_res=st["res"], hist_settle=hist_settle, hist_ustar=hist_ustar,
         ustar_iters=lat.last_ustar["iters"], ustar_res=lat.last_ustar["res"],
@@ -176,6 +186,19 @@ def main():
     # non-deterministic (argpartition) path -- no exact ties in Gaussian data so the edge set is defined
     run_case("nondet_n256_d32_k5", N=256, D=32, k=5, gen="default_rng", psi_mode="mean32", deterministic=False,
              store_U=False)
+    # round 5: the constructor's other arguments (lattice.py:33-43) -- the row-sum cap below 1, the cap inactive
+    # (row sums << cap: every scale exactly 1, graph.py:76-80), and lambdas off their defaults including exact zeros
+    # (legal: lattice.py:49-53 only demands lamG > 0, lamC >= 0, lamQ >= 0)
+    run_case("cap025_n300_d48_k8", N=300, D=48, k=8, gen="default_rng", psi_mode="mean32", gates="random",
+             chain=[4, 17, 2, 250], row_cap_val=0.25, seed=3)
+    run_case("capoff_n300_d48_k8", N=300, D=48, k=8, gen="default_rng", psi_mode="mean32", gates="random",
+             chain=[4, 17, 2, 250], row_cap_val=1e6, seed=3)
+    run_case("lam_g03_c0_q0_n240_d40_k6", N=240, D=40, k=6, gen="default_rng", psi_mode="randn", gates="random",
+             chain=[0, 9, 200, 31], lamP=0.2, lams=(0.3, 0.0, 0.0), seed=4)
+    run_case("lam_g03_c07_q0_n240_d40_k6", N=240, D=40, k=6, gen="default_rng", psi_mode="randn", gates="random",
+             chain=[0, 9, 200, 31], lamP=0.2, lams=(0.3, 0.7, 0.0), seed=4)
+    run_case("lam_g25_c2_q15_cap05_n240_d40_k6", N=240, D=40, k=6, gen="default_rng", psi_mode="randn", gates="random",
+             lams=(2.5, 2.0, 1.5), row_cap_val=0.5, seed=5)
 
 
 if __name__ == "__main__":

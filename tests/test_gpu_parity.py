@@ -8,7 +8,7 @@ expected to do better (the tighter ones are regression guards, not the contract)
 import numpy as np
 import pytest
 
-from tests._cases import ALL_CASES, known_answers, load_case, make_inputs, random_gates, relerr
+from tests._cases import ALL_CASES, PARAM_CASES, ctor_kwargs, known_answers, load_case, make_inputs, random_gates, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -85,7 +85,7 @@ def test_cg_with_injected_graph_matches_reference(amd, name):
     case = load_case(name)
     rc = case["recipe"]
     Y, psi = make_inputs(rc)
-    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False, **ctor_kwargs(rc))
     lat.set_graph_csr(*_csr_from_case(case))
     assert np.allclose(lat.sqrt_deg, case["sqrt_deg"], rtol=2e-6)
     _configure(lat, case, rc, psi)
@@ -102,7 +102,7 @@ def test_general_multi_kernel_cg_on_small_fixtures(amd, name, monkeypatch):
     case = load_case(name)
     rc = case["recipe"]
     Y, psi = make_inputs(rc)
-    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False, **ctor_kwargs(rc))
     lat.set_graph_csr(*_csr_from_case(case))
     _configure(lat, case, rc, psi)
     _check_solves(lat, case, rc, tol_u=2e-5)
@@ -114,7 +114,7 @@ def test_device_knn_graph_matches_reference(amd, name):
     case = load_case(name)
     rc = case["recipe"]
     Y, _ = make_inputs(rc)
-    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"])
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], **ctor_kwargs(rc))
     rowptr, col, a, w, sd = lat.graph_csr()
     assert np.array_equal(rowptr, case["indptr"])
     assert np.array_equal(col, case["indices"])
@@ -132,7 +132,7 @@ def test_end_to_end_device_path_matches_reference(amd, name):
     case = load_case(name)
     rc = case["recipe"]
     Y, psi = make_inputs(rc)
-    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"])
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], **ctor_kwargs(rc))
     if rc["gates"] == "diffusion":
         g = amd.compute_diffusion_gates(Y, psi, kneighbors=rc["k"], deterministic_k=True, **rc["diffusion"])
         assert np.allclose(g, case["gates"], atol=1e-4)
@@ -983,7 +983,7 @@ def test_xcd_affine_slab_apply_matches_reference(amd, name, nb, monkeypatch):
     case = load_case(name)
     rc = case["recipe"]
     Y, psi = make_inputs(rc)
-    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False, **ctor_kwargs(rc))
     lat.set_graph_csr(*_csr_from_case(case))
     _configure(lat, case, rc, psi)
     info = lat.build_info()
@@ -1062,7 +1062,7 @@ def test_padded_row_pitch_is_invisible(amd, name, ld, small, monkeypatch):
     case = load_case(name)
     rc = case["recipe"]
     Y, psi = make_inputs(rc)
-    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"])
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], **ctor_kwargs(rc))
     assert np.array_equal(lat.Y, Y) and np.array_equal(lat.U, Y)
     rows = np.array([0, Y.shape[0] - 1, 7], dtype=np.int32)
     assert np.array_equal(lat._fetch_rows(1, rows), Y[rows])
@@ -1086,12 +1086,109 @@ def test_source_blocked_apply_matches_reference(amd, name, nb, monkeypatch):
     case = load_case(name)
     rc = case["recipe"]
     Y, psi = make_inputs(rc)
-    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], _build_graph=False, **ctor_kwargs(rc))
     lat.set_graph_csr(*_csr_from_case(case))
     _configure(lat, case, rc, psi)
     _check_solves(lat, case, rc, tol_u=2e-5)
     info = lat.build_info()
     assert info["apply_src_blocks"] == int(nb) and info["blocked_applies"] > 0 and info["small_solves"] == 0
+
+
+@pytest.mark.parametrize("name", PARAM_CASES)
+@pytest.mark.parametrize("path", ["general", "blocked"])
+def test_constructor_parameter_fixtures_on_the_multi_kernel_paths(amd, name, path, monkeypatch):
+    """The round-5 fixtures (row_cap_val 0.25 / 1e6 / 0.5, lamG 0.3 / 2.5, lamC 0 / 0.7 / 2, lamQ 0 / 1.5: tests/golden/
+    make_golden.py, generated by the reference) through the paths config 3 runs: OSC_SMALL_PATH=0 keeps the one-launch
+    solve out, "blocked" also forces XCD-affine slabs and the source-blocked matvec (whose epilogue folds lamG, lamQ B and
+    the Jacobi diagonal into cs_const / cs_B -- exactly where a zero lambda would show).  Device-built graph: the cap
+    kernels (k_row_scale / k_apply_cap) below 1, inactive, and at 0.5 against the reference's adjacency."""
+    monkeypatch.setenv("OSC_SMALL_PATH", "0")
+    if path == "blocked":
+        monkeypatch.setenv("OSC_SPMM_XS", "1")
+        monkeypatch.setenv("OSC_SPMM_BLOCKED", "3")
+    case = load_case(name)
+    rc = case["recipe"]
+    Y, psi = make_inputs(rc)
+    lat = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], **ctor_kwargs(rc))
+    rowptr, col, a, w, sd = lat.graph_csr()
+    assert np.array_equal(rowptr, case["indptr"]) and np.array_equal(col, case["indices"])
+    assert np.allclose(a, case["A_data"], rtol=1e-5, atol=1e-8) and np.allclose(sd, case["sqrt_deg"], rtol=1e-5)
+    if "row_cap_val" in rc and rc["row_cap_val"] >= 1e5:  # cap inactive: every scale is exactly 1 (graph.py:76-80)
+        monkeypatch.setenv("OSC_SPMM_BLOCKED", "0")
+        raw = amd.Oscillink(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"], row_cap_val=3.0e38)
+        assert np.array_equal(raw.graph_csr()[2], a)
+        raw.close()
+    _configure(lat, case, rc, psi)
+    _check_solves(lat, case, rc, tol_u=2e-5)
+    info = lat.build_info()
+    assert info["small_solves"] == 0 and info["apply_src_blocks"] == (3 if path == "blocked" else 0)
+
+
+def test_rebuild_graph_with_another_cap_against_the_oracle(amd, orc):
+    """rebuild_graph(row_cap_val=...) (lattice.py:760-801): the cap kernels run again on the handle's lattice; adjacency,
+    sqrt_deg and the solves that follow equal the oracle's for the new cap, and going back to cap 1.0 restores the first
+    graph bit for bit."""
+    rng = np.random.default_rng(21)
+    N, D, k = 700, 64, 10
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    gates = rng.uniform(0.0, 1.0, N).astype(np.float32)
+    lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True, lamG=0.8, lamC=1.3, lamQ=0.0)
+    first = [x.copy() for x in lat.graph_csr()]
+    for cap in (0.3, 1e6, 2.0, 1.0):
+        lat.rebuild_graph(row_cap_val=cap)
+        lat.set_query(psi, gates=gates)
+        lat.reset_U()
+        ref = orc.OracleLattice(Y, kneighbors=k, deterministic_k=True, row_cap_val=cap, lamG=0.8, lamC=1.3, lamQ=0.0, dense=False)
+        ref.set_query(psi, gates=gates)
+        rowptr, col, a, w, sd = lat.graph_csr()
+        r, c, wa = orc._edges(ref.A)
+        assert np.array_equal(col, c) and np.allclose(a, wa, rtol=1e-5, atol=1e-9) and np.allclose(sd, ref.sqrt_deg, rtol=1e-5)
+        st, rs = lat.settle(max_iters=12, tol=1e-4), ref.settle(max_iters=12, tol=1e-4)
+        assert st["iters"] == rs["iters"] and relerr(lat.U, ref.U) < 2e-5
+        Us, Ur = lat.solve_Ustar(), ref.solve_Ustar()
+        assert lat.last_ustar["iters"] == ref.last_ustar["iters"] and relerr(Us, Ur) < 2e-5
+    again = lat.graph_csr()
+    assert all(np.array_equal(x, y) for x, y in zip(first, again))
+
+
+@pytest.mark.parametrize("shape", ["0", "1", "2", "3"])
+def test_blocked_apply_kernel_shapes_against_the_plain_one(amd, shape, monkeypatch):
+    """OSC_BLK_VARIANT forces one kernel shape of the blocked matvec (cg_kernels.hip: kBlkShapes; 0 = two workgroups per CU,
+    one gather round in flight, tests per group; 1-3 = one workgroup per CU, four rounds in flight, 20 / 24 / 28 test-free
+    groups per wave -- chosen by geometry from N = 96k on, so a 36 000-row lattice fills only part of their groups and
+    exercises the padding).  Settle, U* solve, a chain prior (fix-up launch) and ragged shapes (N not a multiple of the
+    row groups, D = 200: a partial last slab): same iteration counts, states equal to summation-order noise."""
+    monkeypatch.delenv("OSC_SPMM_XS", raising=False)
+    monkeypatch.delenv("OSC_REORDER", raising=False)
+    rng = np.random.default_rng(5)
+    N, D, k = 36001, 200, 20
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    gates = rng.uniform(0.1, 1.0, N).astype(np.float32)
+    res = {}
+    for mode in ("plain", "blocked"):
+        monkeypatch.setenv("OSC_SPMM_BLOCKED", "0" if mode == "plain" else "6")
+        monkeypatch.setenv("OSC_BLK_VARIANT", shape)
+        lat = amd.Oscillink(Y, kneighbors=k)
+        lat.set_query(psi, gates=gates)
+        st = lat.settle(max_iters=12, tol=1e-4)
+        U1 = lat.U.copy()
+        Us = lat.solve_Ustar().copy()
+        it_us = lat.last_ustar["iters"]
+        lat.add_chain([5, 1, 36000, 18000, 7, 2], lamP=0.3)
+        lat.reset_U()
+        st2 = lat.settle(max_iters=12, tol=1e-4)
+        info = lat.build_info()
+        if mode == "blocked":
+            assert info["apply_src_blocks"] == 6 and info["apply_blocked_shape"] == int(shape), info
+        else:
+            assert info["apply_src_blocks"] == 0, info
+        res[mode] = (st["iters"], U1, Us, it_us, st2["iters"], lat.U.copy())
+        lat.close()
+    a, b = res["plain"], res["blocked"]
+    assert a[0] == b[0] and a[3] == b[3] and a[4] == b[4]
+    assert relerr(b[1], a[1]) < 1e-6 and relerr(b[2], a[2]) < 1e-6 and relerr(b[5], a[5]) < 1e-6
 
 
 def test_source_blocked_apply_against_the_plain_one(amd, orc, monkeypatch):

@@ -8,14 +8,14 @@ import numpy as np
 import pytest
 
 from oracle import oscillink_oracle as orc
-from tests._cases import ALL_CASES, known_answers, load_case, make_inputs, random_gates, relerr
+from tests._cases import ALL_CASES, ctor_kwargs, known_answers, load_case, make_inputs, random_gates, relerr
 
 
 def _build(case, dense):
     rc = case["recipe"]
     Y, psi = make_inputs(rc)
     lat = orc.OracleLattice(Y, kneighbors=rc["k"], deterministic_k=rc["deterministic"],
-                            neighbor_seed=rc["neighbor_seed"], dense=dense)
+                            neighbor_seed=rc["neighbor_seed"], dense=dense, **ctor_kwargs(rc))
     gates = None
     if rc["gates"] == "random":
         gates = random_gates(rc)
