@@ -584,14 +584,20 @@ def main():
         out.update(extras(lat, N, D, args, launched))
     elif launched:
         out["extras"] = "skipped in a multi-GPU run (--extras runs them: sharded rebuilds, U* solves, receipts)"
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(lat, Y, psi, args)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # The CPU oracle leg is CPU-only: rank 0 takes the device-built graph while the lattice is alive, every rank then
+    # leaves the communicator (the other ranks are done), and rank 0 times the oracle -- at every world size, so that a
+    # multi-GPU line carries the field too.
+    csr = None
+    if rank == 0 and not args.no_cpu_baseline:
+        csr = lat.graph_csr()[:3]
     if launched:
         sync_all(lat)
         lat.close()
         rdzv.close()
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(csr, Y, psi, args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def cold_and_mispredicted(lat, Y, psi, args, k, device, step):
@@ -676,8 +682,14 @@ def extras(lat, N, D, args, sharded):
     flops = 2.0 * N * N * D
     tf = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     world = int(os.environ.get("WORLD_SIZE", "1")) if sharded else 1
+    # flops the matrix pipe really issues: the panel route sweeps half the tiles on one GPU (all of them
+    # when the build is sharded) plus the threshold sample, a strided 1 / rho of the columns, rho = (k + 16) / 4
+    rho = (args.k + 16) / 4.0
+    executed = flops * ((0.5 if world == 1 else 1.0) + 1.0 / rho) if info["prefilter"] == 2 else flops
+    tf_exec = executed / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     knn = {"route": route, "build_device_ms": float(np.median(builds)), "gemm_topk_ms": gemm_ms,
            "flops": flops / world, "achieved": tf / world, "peak": peak, "unit": "TFLOP/s", "frac": tf / world / peak,
+           "executed_flops": executed / world, "executed_achieved": tf_exec / world, "executed_frac": tf_exec / world / peak,
            "bound": "mfma", "fallback_rows": info["fallback_rows"]}
     ustar = []
     for _ in range(5):
@@ -728,7 +740,7 @@ def pmc_traffic(N, D, k, world, kernel):
     return None, None
 
 
-def cpu_baseline(lat, Y, psi, args):
+def cpu_baseline(csr, Y, psi, args):
     """The CPU oracle (sparse flavour: SciPy CSR SpMM + NumPy, oracle/oscillink_oracle.py) on the same workload, with
     the device-built graph injected so the CPU leg times exactly the settle the GPU leg times.
 
@@ -745,7 +757,7 @@ def cpu_baseline(lat, Y, psi, args):
 
     from oracle import oscillink_oracle as orc
 
-    rowptr, col, a, _, _ = lat.graph_csr()
+    rowptr, col, a = csr  # (rowptr, col, A_ij) of the device-built lattice graph
     N, D = Y.shape
     A = sp.csr_matrix((a, col, rowptr), shape=(N, N), dtype=np.float32)
     ref = orc.OracleLattice(Y, kneighbors=args.k, dense=False, graph=A)

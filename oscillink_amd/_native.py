@@ -123,8 +123,10 @@ _PINNED_MIN_BYTES = 8 << 20
 _result_sizes_seen: dict = {}
 
 
-def result_array(shape) -> np.ndarray:
-    """An uninitialised float32 array for a device read-back.  Large ones live in pinned host memory from the library's
+def result_array(shape, pinned: bool = True) -> np.ndarray:
+    """An uninitialised float32 array for a device read-back.  pinned=False: always a plain `np.empty` (arrays a lattice
+    keeps for its lifetime, like its cached copy of Y: pinned pages cannot be swapped and are not inherited by a forked
+    worker -- INTEGRATION.md section 6).  Otherwise large ones live in pinned host memory from the library's
     pool (osc_host_alloc), so the read-back is one DMA with no host copy behind it; the block returns to the pool when
     the array (and every view of it) is gone.  Pinning is slow (~55 ms for 300 MB, ~0.4 s for 1.2 GB; a pageable read-back
     of those takes 20 / 150 ms), so the FIRST read-back of a size in a process gets a plain `np.empty` (a one-shot script
@@ -134,7 +136,7 @@ def result_array(shape) -> np.ndarray:
 
     n = int(np.prod(shape))
     mode = os.environ.get("OSC_PINNED_RESULTS", "1")
-    if n * 4 < _PINNED_MIN_BYTES or mode == "0":
+    if n * 4 < _PINNED_MIN_BYTES or mode == "0" or not pinned:
         return np.empty(shape, dtype=np.float32)
     seen = _result_sizes_seen.get(n, 0)
     _result_sizes_seen[n] = seen + 1

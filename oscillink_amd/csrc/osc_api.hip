@@ -499,27 +499,26 @@ void* host_pool_alloc(size_t bytes) {
   return p;
 }
 bool host_pool_free(void* p) {
-  size_t cap = 0;
-  {
+  std::vector<void*> release;  // unpinned OUTSIDE the lock: hipHostFree can take milliseconds, and g_pool_mu also guards the
+  {                            // stream and staging pools of every handle
     std::lock_guard<std::mutex> lk(g_pool_mu);
     auto it = g_host_live.find(p);
     if (it == g_host_live.end()) return false;
-    cap = it->second;
+    const size_t cap = it->second;
     g_host_live.erase(it);
     if (cap <= kHostParkBytes) {  // park it; the blocks parked longest make room (a workload's current size class stays)
-      std::vector<void*> evict;
       while (g_host_parked_bytes + cap > kHostParkBytes && !g_host_parked.empty()) {
-        evict.push_back(g_host_parked.front().p);
+        release.push_back(g_host_parked.front().p);
         g_host_parked_bytes -= g_host_parked.front().bytes;
         g_host_parked.erase(g_host_parked.begin());
       }
       g_host_parked.push_back(HostBlock{p, cap});
       g_host_parked_bytes += cap;
-      for (void* q : evict) (void)hipHostFree(q);
-      return true;
+    } else {
+      release.push_back(p);
     }
   }
-  (void)hipHostFree(p);
+  for (void* q : release) (void)hipHostFree(q);
   return true;
 }
 bool host_pool_owns(const void* p, size_t bytes) {  // [p, p + bytes) lies inside a block this pool handed out
@@ -986,7 +985,19 @@ void build_graph(L& h) {
   constexpr int panel_min = 8193;  // (up to 8192 rows: the dense route)
   // (a hit entry packs the column index into 25 bits, next to its two side flags)
   // (D > 768: the same route on the tile core, k_tile_thr -- half sweep only, so single-process builds only)
-  const bool sym_ok = h.knn_sym && parts == 1;
+  bool sym_ok = h.knn_sym && parts == 1;
+  if (sym_ok && prefilter && N >= panel_min && N < (1 << 25)) {
+    // The half sweep delivers every hit to a bucket per 32 receiving rows: (npad / 32) x bucket_cap entries of 8 bytes --
+    // 2.9 GB of temporaries at N = 1M (config 4), growing with N x the threshold sample's hit bound (the full sweep's
+    // lists: 0.2-0.5 GB).  Beyond a budget, or where the device cannot spare it, the build takes the full sweep (D <= 768)
+    // or the tile prefilter (D > 768) instead of failing in the allocator.
+    const KnnPanelPlan sp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, false, true, h.knn_tune);
+    const double bucket_bytes = (double)(sp.npad / 32) * (double)sp.bucket_cap * 8.0;
+    size_t mem_free = 0, mem_total = 0;
+    HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
+    constexpr double kSymBucketBudget = 12.0 * 1024 * 1024 * 1024;
+    if (sp.ok && (bucket_bytes > kSymBucketBudget || bucket_bytes > 0.5 * (double)mem_free)) sym_ok = false;
+  }
   const bool depth_ok = knn_panel_nkt(h.D) != 0 || (sym_ok && knn_tile_nkt(h.D) != 0);
   bool panel = prefilter && depth_ok && N >= panel_min && N < (1 << 25) &&
                knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, false, sym_ok, h.knn_tune).ok;
@@ -1010,7 +1021,7 @@ void build_graph(L& h) {
     // single-process builds sweep only the column tiles J >= I of every row block (knn_gemm.hip: symmetric half sweep);
     // a sharded build's ranks own row blocks and would have to exchange the column-side hits, so they keep the full sweep
     // (OSC_KNN_PANEL_SCATTER=0 / OSC_KNN_PANEL_SYM=0: A/B and tests)
-    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, h.knn_scatter && parts == 1, h.knn_sym && parts == 1, h.knn_tune);
+    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, h.knn_scatter && parts == 1, sym_ok, h.knn_tune);
     p_img.alloc((size_t)(pp.npad + 128) * pp.ldh / 2);  // (+ one zero tile: k_tile_thr2 sweeps row blocks and column tiles in pairs)
     HIP_CHECK(hipMemsetAsync(p_img.p + (size_t)pp.npad * pp.ldh / 2, 0, (size_t)128 * pp.ldh * 2, h.stream));
     p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
@@ -2160,12 +2171,17 @@ bool row_mode(const L& h) { return h.shard_mode == 1 && (h.comm != nullptr || h.
 // The ONE place the per-handle OSC_* switches are read (osc_create, osc_rebuild_graph).  Process-wide ones are read where
 // the process-wide object is made: OSC_POOL_MB (device memory pool), OSC_PINNED_DL / OSC_COPY_THREADS (read-back staging),
 // OSC_LOOPBACK_TIMEOUT_S / OSC_RCCL_PROXY (communicator backends, comm.hip), OSC_LD (osc_create, before the arrays are sized).
-void read_env(L& h) {
-  auto num = [](const char* name, int& out) {
-    const char* e = getenv(name);
-    if (e) out = atoi(e);
-    return e != nullptr;
-  };
+bool env_num(const char* name, int& out) {
+  const char* e = getenv(name);
+  if (e) out = atoi(e);
+  return e != nullptr;
+}
+
+// The switches a handle reads ONCE, at creation: how its solves run and how it is sharded.  They stay what they were when
+// the graph is rebuilt (osc_rebuild_graph): the column window, the halo plan and the communicator were laid out for them
+// (a handle whose OSC_SHARD changed under it would solve over a partial window).
+void read_env_solver(L& h) {
+  auto num = env_num;
   int v = 0;
   if (num("OSC_SPMM_SLAB", v)) h.spmm_slab = v < 0 ? -1 : (v / 4) * 4;
   if (num("OSC_SPMM_XS", v)) h.spmm_xs = v != 0 ? 1 : 0;
@@ -2187,8 +2203,6 @@ void read_env(L& h) {
     h.x_last_form = v == 1;
   }
   if (num("OSC_SMALL_PATH", v)) h.small_path = v != 0;
-  if (num("OSC_REORDER", v)) h.reorder = v != 0 ? 1 : 0;
-  else h.reorder = -1;
   if (const char* e = getenv("OSC_SHARD")) h.shard_mode = !strcmp(e, "row") ? 1 : 0;
   if (num("OSC_ROW_FAKE_SHARDS", v)) h.fake_row_shards = std::max(0, v);
   h.fake_col_w = 0;
@@ -2196,7 +2210,14 @@ void read_env(L& h) {
     int r = 0, w = 1;
     if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) h.fake_col_r = r, h.fake_col_w = w;
   }
-  // the lattice build
+}
+
+// The switches of the lattice build: read at creation and again by every rebuild.
+void read_env_build(L& h) {
+  auto num = env_num;
+  int v = 0;
+  if (num("OSC_REORDER", v)) h.reorder = v != 0 ? 1 : 0;
+  else h.reorder = -1;
   h.knn_mode = 0;
   if (const char* e = getenv("OSC_KNN_MODE")) h.knn_mode = !strcmp(e, "exact") ? 1 : !strcmp(e, "prefilter") ? 2 : !strcmp(e, "panel") ? 3 : 0;
   h.knn_fake_shards = 0;
@@ -2215,6 +2236,11 @@ void read_env(L& h) {
   h.bfs_host = num("OSC_BFS_HOST", v) && v != 0;
   h.halo_force = 0;
   if (const char* e = getenv("OSC_HALO")) h.halo_force = !strcmp(e, "full") ? 1 : !strcmp(e, "lists") ? 2 : 0;
+}
+
+void read_env(L& h) {
+  read_env_solver(h);
+  read_env_build(h);
 }
 
 void require_graph(L& h) {
@@ -2388,7 +2414,7 @@ int osc_destroy(osc_handle h) {
 int osc_rebuild_graph(osc_handle h, int32_t k, float row_cap, int32_t deterministic, int64_t seed) {
   return guarded(h, [&](L& l) {
     if (k < 1) throw Invalid("kneighbors must be >= 1");
-    read_env(l);
+    read_env_build(l);  // (the build's switches only: solver and sharding switches are fixed at creation)
     l.k_eff = (int32_t)std::min<int64_t>(k, std::max<int64_t>(1, l.N - 1));
     l.row_cap = row_cap;
     l.deterministic = deterministic;

@@ -140,7 +140,8 @@ class OscillinkLattice:
     @property
     def Y(self) -> np.ndarray:
         if self._Y_host is None:
-            out = nat.result_array((self.N, self.D))
+            # (kept for the lattice's lifetime: ordinary pageable memory, like the reference's own copy of Y)
+            out = nat.result_array((self.N, self.D), pinned=False)
             self._call("osc_get_Y", nat.f32(out))
             self._Y_host = out
         return self._Y_host

@@ -1106,6 +1106,7 @@ def test_constructor_parameter_fixtures_on_the_multi_kernel_paths(amd, name, pat
     if path == "blocked":
         monkeypatch.setenv("OSC_SPMM_XS", "1")
         monkeypatch.setenv("OSC_SPMM_BLOCKED", "3")
+        monkeypatch.setenv("OSC_LD", "64")  # (the slab-major search direction needs a pitch of whole 32-column slabs; D = 48 / 40)
     case = load_case(name)
     rc = case["recipe"]
     Y, psi = make_inputs(rc)
