@@ -226,8 +226,8 @@ int osc_dynamics(osc_handle h, const float* U_prev_or_null, const float* U_next_
  * the shader cycles a gathering wave spent (mean over the waves, summed over the stamped launches) in all / in its gather
  * rounds / at the workgroup barrier / in its epilogues, 12..13 the list wave's cycles fetching slot rows / at the barrier,
  * and *launches = the stamped launches.  which = 14: *launches = the kernel shape the last blocked matvec ran with
- * (0 = two 8-wave workgroups per CU, one gather round in flight; 1..3 = one workgroup per CU, four rounds in flight,
- * 20 / 24 / 28 row groups per wave; OSC_BLK_VARIANT forces one), *total_ms = 0. */
+ * (0 = two 8-wave workgroups per CU, one gather round in flight; 1..6 = one workgroup per CU, four rounds in flight,
+ * 8 / 12 / 16 / 20 / 24 / 28 row groups per wave; OSC_BLK_VARIANT forces one), *total_ms = 0. */
 int osc_profile_enable(osc_handle h, int32_t on);
 int osc_profile_reset(osc_handle h);
 int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* total_ms);

@@ -1159,20 +1159,31 @@ void launch_blocked_fill(const int32_t* col, const float* w, const int32_t* deg,
 // The shapes of k_apply_blocked the library holds: {row groups per gathering wave, gathering waves per workgroup, gather
 // rounds in flight per wave, waves per SIMD}.  0: rounds 2-4 (two 8-wave workgroups per CU, one round in flight, tests per
 // group).  1-3 (round 5, "wide"): ONE 8-wave workgroup per CU at two waves per SIMD, four rounds in flight, test-free
-// straight-line rounds -- so the group count is a template constant and there are three of them (blocked_shape_for picks
-// the smallest that holds the lattice's groups).
+// straight-line rounds -- so the group count is a template constant and there are six of them, 8 to 28 groups
+// (blocked_shape_for picks the smallest that holds the lattice's groups).
 struct BlkShape {
   int gm, cw, pd, wpe;
 };
-constexpr BlkShape kBlkShapes[] = {{kBlkGroups, kBlkGatherWaves, 1, 4}, {20, 7, 4, 2}, {24, 7, 4, 2}, {28, 7, 4, 2}};
+constexpr BlkShape kBlkShapes[] = {{kBlkGroups, kBlkGatherWaves, 1, 4}, {8, 7, 4, 2},  {12, 7, 4, 2}, {16, 7, 4, 2},
+                                   {20, 7, 4, 2},                       {24, 7, 4, 2}, {28, 7, 4, 2}};
 constexpr int kBlkShapeCount = (int)(sizeof(kBlkShapes) / sizeof(kBlkShapes[0]));
 #define OSC_BLK_SHAPE_SWITCH(v, CALL) \
   switch (v) {                        \
     case 0: CALL(kBlkGroups, kBlkGatherWaves, 1, 4); break; \
-    case 1: CALL(20, 7, 4, 2); break; \
-    case 2: CALL(24, 7, 4, 2); break; \
-    case 3: CALL(28, 7, 4, 2); break; \
+    case 1: CALL(8, 7, 4, 2); break;  \
+    case 2: CALL(12, 7, 4, 2); break; \
+    case 3: CALL(16, 7, 4, 2); break; \
+    case 4: CALL(20, 7, 4, 2); break; \
+    case 5: CALL(24, 7, 4, 2); break; \
+    case 6: CALL(28, 7, 4, 2); break; \
     default: throw std::runtime_error("blocked apply: unknown kernel shape"); \
+  }
+// the cycle-stamping instantiations (diagnostics): the round-4 shape and the widest one
+#define OSC_BLK_STAMP_SWITCH(v, CALL) \
+  switch (v) {                        \
+    case 0: CALL(kBlkGroups, kBlkGatherWaves, 1, 4); break; \
+    case 6: CALL(28, 7, 4, 2); break; \
+    default: throw std::runtime_error("blocked apply: no stamping instantiation of this kernel shape (OSC_BLK_VARIANT=0 or 6)"); \
   }
 static const BlkShape& blk_shape(int variant) {
   if (variant < 0 || variant >= kBlkShapeCount) throw std::runtime_error("blocked apply: unknown kernel shape");
@@ -1229,7 +1240,7 @@ void launch_apply_blocked(const BlkArgs& a, int grid, hipStream_t s, const BlkIn
     BlkInit st{};
     st.R = reinterpret_cast<float*>(stamps);
 #define CALL(G, W, P, E) hipLaunchKernelGGL((k_apply_blocked<G, W, false, P, E, true>), dim3(grid), dim3((W + 1) * 64), 0, s, a, st)
-    OSC_BLK_SHAPE_SWITCH(variant, CALL);
+    OSC_BLK_STAMP_SWITCH(variant, CALL);
 #undef CALL
   } else {
 #define CALL(G, W, P, E) hipLaunchKernelGGL((k_apply_blocked<G, W, false, P, E>), dim3(grid), dim3((W + 1) * 64), 0, s, a, BlkInit{})

@@ -1287,19 +1287,22 @@ int blocked_resident(const L& h, int shape) {
 
 // Kernel shape of the blocked matvec for a window cut into xg slab groups (cg_kernels.hip: kBlkShapes).  The wide shapes
 // (one workgroup per CU, four gather rounds in flight, no tests in the rounds) carry their group count as a template
-// constant and gather padding for the groups a lattice does not fill, so they are taken where the lattice fills at least
-// 17 of the smallest one's 20 -- in practice N >= ~60k rows per slab group -- and the smallest that fits is used.
+// constant -- the smallest that holds the lattice's groups is used -- and are taken from 96 000 rows on, where they win
+// at every width measured except one slab per XCD below 150k rows; below 96k rows they are within +-2 % of shape 0 with
+// single wins and losses of 5-7 % either way, so shape 0 stays there.
 int blocked_shape_for(const L& h, int xg, int grid) {
   if (h.blk_variant >= 0) return h.blk_variant;
   const int wide_last = blocked_variants() - 1;
   const host::BlockedGeom g = host::blocked_geometry(h.N, xg, grid, blocked_resident(h, wide_last), blocked_groups_max(wide_last),
                                                      blocked_gather_waves(wide_last));
-  // Measured against shape 0 (profiles/r05_blk_shape_sweep.txt, per AP launch): 40k x 768 +5.5 %, 60k x 768 +6.0 %, 80k x 768
-  // +2.2 %, 100k x 768 -4.6 %, 100k x 384 k 16 -4.8 %, 100k x 1024 k 48 -4.0 %, 160k x 768 -10.9 %, 200k x 768 -9.6 %, 260k x 512
-  // -15.0 %, 400k x 384 k 16 -7.1 %; one slab per XCD (130k x 256) +3.6 %: there the wide shapes wait for N = 150k.
+  // Measured against shape 0 (profiles/r05_blk_shape_sweep.txt, per AP launch, exact-fit group counts): 20k x 768 -7.5 %, 20k x
+  // 128 k 16 +5.8 %, 30k-80k x 768 -0.8 ... +2.7 %, 100k x 768 -4.6 %, 100k x 384 k 16 -4.8 %, 100k x 1024 k 48 -4.0 %, 100k x
+  // 96 (rank 0 of 8's window of config 3) -10.9 %, 100k x 192 -2.7 %, 160k x 768 -10.9 %, 200k x 768 -9.6 %, 200k x 64 -13.0 %,
+  // 260k x 512 -15.0 %, 400k x 384 k 16 -7.1 %; one slab per XCD: 100k x 64 k 16 +5.0 %, 100k x 128 k 16 +1.4 %, 130k x 256
+  // +1.4 ... +3.6 % -- there the wide shapes wait for N = 150k.
   const int64_t min_rows = h.blk_wide_min_rows > 0 ? h.blk_wide_min_rows : 96000;
   const int slabs_per_group = ((h.c1 - h.c0 + 31) / 32 + xg - 1) / std::max(1, xg);
-  if (h.N < min_rows || g.groups < 17 || (h.blk_wide_min_rows <= 0 && slabs_per_group < 2 && h.N < 150000)) return 0;
+  if (h.N < min_rows || (h.blk_wide_min_rows <= 0 && slabs_per_group < 2 && h.N < 150000)) return 0;
   for (int v = 1; v <= wide_last; ++v)
     if (g.groups <= blocked_groups_max(v)) return v;
   return 0;

@@ -9,7 +9,7 @@ os.environ["OSC_BLK_STAMP"] = "1"
 from oscillink_amd import Oscillink  # noqa: E402
 
 N, D, k = [int(t) for t in sys.argv[1:4]]
-variants = sys.argv[4:] or ["0", "1"]
+variants = sys.argv[4:] or ["0", "6"]
 rng = np.random.default_rng(0)
 Y = rng.standard_normal((N, D), dtype=np.float32)
 psi = Y[:32].mean(0); psi = (psi / np.linalg.norm(psi)).astype(np.float32)

@@ -1153,12 +1153,12 @@ def test_rebuild_graph_with_another_cap_against_the_oracle(amd, orc):
     assert all(np.array_equal(x, y) for x, y in zip(first, again))
 
 
-@pytest.mark.parametrize("shape", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("shape", ["0", "1", "2", "3", "4", "5", "6"])
 def test_blocked_apply_kernel_shapes_against_the_plain_one(amd, shape, monkeypatch):
     """OSC_BLK_VARIANT forces one kernel shape of the blocked matvec (cg_kernels.hip: kBlkShapes; 0 = two workgroups per CU,
-    one gather round in flight, tests per group; 1-3 = one workgroup per CU, four rounds in flight, 20 / 24 / 28 test-free
-    groups per wave -- chosen by geometry from N = 96k on, so a 36 000-row lattice fills only part of their groups and
-    exercises the padding).  Settle, U* solve, a chain prior (fix-up launch) and ragged shapes (N not a multiple of the
+    one gather round in flight, tests per group; 1-6 = one workgroup per CU, four rounds in flight, 8 / 12 / 16 / 20 / 24 /
+    28 test-free groups per wave -- chosen by geometry from N = 96k on; a 36 000-row lattice needs three destination slices
+    under the 8-group shape and fills only part of the larger ones' groups, which exercises the padding).  Settle, U* solve, a chain prior (fix-up launch) and ragged shapes (N not a multiple of the
     row groups, D = 200: a partial last slab): same iteration counts, states equal to summation-order noise."""
     monkeypatch.delenv("OSC_SPMM_XS", raising=False)
     monkeypatch.delenv("OSC_REORDER", raising=False)
