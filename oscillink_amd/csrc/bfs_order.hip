@@ -180,6 +180,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const int32_t* in, 
     run += x[j];
   }
 }
+}  // namespace
 size_t scan_blocks(int64_t n) { return (size_t)((n + kScanTile - 1) / kScanTile); }
 // out may alias in; sums: scan_blocks(n) int32 of scratch
 void exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* sums, hipStream_t s) {
@@ -188,7 +189,9 @@ void exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* sum
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(kScanThreads), 0, s, in, n, sums);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums, (int32_t)nb);
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanThreads), 0, s, in, n, sums, out);
+  HIP_CHECK(hipGetLastError());
 }
+namespace {
 
 // ---- stable LSD radix sort of (64-bit key, int32 value) pairs, 8 bits per pass -----------------------------------------
 // One wave per tile of 1024 pairs.  Histogram pass: hist[digit][tile]; its exclusive scan gives every (digit, tile) its

@@ -110,6 +110,9 @@ struct PanelArgs {
   int32_t bucket_cap;
   int32_t* flags;        // [c]: an LDS list of chunk c overflowed (hits of its tiles' rows were lost); zeroed by the caller
   int32_t set0, nset;    // k_tile_thr2: the sets of two row blocks this launch sweeps (a group whose image rows stay in the Infinity Cache)
+  // half sweep of a SHARDED build: this rank sweeps the work items item_offset, item_offset + item_stride, ... (items of
+  // one chunk stay neighbours in every rank's sequence); 1 / 0 otherwise
+  int32_t item_stride, item_offset;
 };
 
 // LDS-DMA of one 1 KiB piece: M0 = LDS destination - K offset, the K offset rides in the immediate
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float* const s_tc = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + PANEL_LDS + (size_t)4 * HB_CAP_SYM * 20);
   for (;;) {
     if (tid == 0) {
-      const int it = (int)atomicAdd(a.queue, 1u);
+      const int it = (int)atomicAdd(a.queue, 1u) * a.item_stride + a.item_offset;
       s_item = it;
       if constexpr (SYM) {  // chunks are queued from the last (every row block sweeps it) to the first (T row blocks): the
         int c = a.nchunks - 1, first = 0;  // short diagonal items come last and fill the tail of the persistent grid
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_thr(const PanelArgs a, const in
   };
   for (;;) {
     if (tid == 0) {
-      const int it = (int)atomicAdd(a.queue, 1u);
+      const int it = (int)atomicAdd(a.queue, 1u) * a.item_stride + a.item_offset;
       s_item = it;
       if constexpr (MODE == 1) {
         int c = a.nchunks - 1, first = 0;
@@ -931,14 +934,14 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
   const int rows_here = 32 / nsub, rl0 = sub * rows_here;  // local rows [rl0, rl0 + rows_here) of the wave's 32
   const int row_base = (rb_begin + rbi) * 128 + 32 * w;
   if (tid < 32) hist[tid] = 0;
-  if (tid == 0) s_bad = sy.on && sy.flags[rbi / sy.T] != 0;  // lost column-side hits of this row block's rows
+  if (tid == 0) s_bad = sy.on && sy.flags[(rb_begin + rbi) / sy.T] != 0;  // lost column-side hits of this row block's rows
   __syncthreads();
   // the segments that hold this (row block, wave)'s entries: (list, entries, raw count)
   const int seg0 = 0;
   const int nseg = sy.on ? 1 : S;
   auto segment = [&](int sg, int& n, int& raw) -> const uint2* {
     if (sy.on) {
-      const int b = rbi * 4 + w;
+      const int b = (rb_begin + rbi) * 4 + w;  // (buckets are indexed by absolute row block: a sharded build selects per rank)
       raw = sy.bucket_cnt[b];
       n = min(raw, sy.bucket_cap);
       return sy.bucket_ent + (size_t)b * sy.bucket_cap;
@@ -1093,7 +1096,7 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
   };
   for (;;) {
     if (tid == 0) {
-      const int it = (int)atomicAdd(a.queue, 1u);
+      const int it = (int)atomicAdd(a.queue, 1u) * a.item_stride + a.item_offset;
       int c = a.nchunks - 1, first = 0;
       if (it < nitems)
         while (it >= first + chunk_sets(c)) first += chunk_sets(c), --c;
@@ -1612,6 +1615,7 @@ void launch_panel_tilemax(const void* Yh, const void* Ys, const KnnPanelPlan& p,
   a.group_tiles = p.group_tiles;
   a.ngroups = p.sample_groups;
   a.tmax = tmax;
+  a.item_stride = 1;
   a.queue = queue;
   HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
   if (p.tile_core) {
@@ -1629,9 +1633,16 @@ void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float
 }
 
 void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count, const float* tau,
-                         void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s, const KnnPanelSymDev* sd) {
+                         void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s, const KnnPanelSymDev* sd,
+                         int shard, int shards) {
   if (rb_count <= 0) return;
   PanelArgs a{};
+  a.item_stride = 1;
+  if (shards > 1) {
+    if (!p.sym || shard < 0 || shard >= shards) throw std::runtime_error("launch_panel_filter: only the half sweep is cut by work items");
+    a.item_stride = shards;
+    a.item_offset = shard;
+  }
   if (p.sym) {
     if (!sd || rb_begin != 0 || rb_count != p.nrb) throw std::runtime_error("launch_panel_filter: the half sweep covers all row blocks");
     a.T = p.T;
@@ -1702,6 +1713,66 @@ void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int3
   hipLaunchKernelGGL(k_panel_select, dim3((unsigned)(rb_count * 4 * nsub)), dim3(256), 0, s,
                      static_cast<const uint2*>(hit_list), hit_cnt, p.hit_cap, p.S, rb_begin, rb_count, nsub, p.keep, N, p.scatter, cval, cidx,
                      fail_rows, fail_count, sy);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- sharded half sweep: the ranks' partial buckets -> complete buckets of each rank's own rows ---------------------------
+// Every rank has swept its share of the work items into buckets of ALL rows.  Rank q selects for the buckets [b0(q), b0(q + 1))
+// of its row blocks, so it needs every other rank's entries of those buckets: counts all-gathered, entries packed per
+// destination (the bucket ranges are contiguous and in rank order: one prefix sum), exchanged, appended.
+__global__ void k_bucket_clamp(const int32_t* cnt, int32_t nb, int32_t cap, int32_t* clamped) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) clamped[b] = min(cnt[b], cap);
+}
+// one wave per bucket: entries [0, min(cnt, cap)) -> out[off[b] ...]
+__global__ __launch_bounds__(256) void k_bucket_pack(const uint2* ent, const int32_t* cnt, const int32_t* off, int32_t nb, int32_t cap,
+                                                     uint2* out) {
+  const int b = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (b >= nb) return;
+  const int n = min(cnt[b], cap);
+  for (int e = lane; e < n; e += 64) out[(size_t)off[b] + e] = ent[(size_t)b * cap + e];
+}
+// one wave per (bucket of my range, source rank): the source's entries of that bucket go behind what the bucket holds
+// already -- mine, then the lower ranks' -- up to the bucket's capacity; the last source leaves the summed RAW count (an
+// overflow anywhere, or of the sum, stays visible to the select as count > capacity).
+// all_cnt [ranks][nb_all] raw counts, src_off [ranks][nb_mine] = offset of (source, bucket) inside that source's segment,
+// seg_off [ranks] = start of each source's segment in recv
+__global__ __launch_bounds__(256) void k_bucket_merge(uint2* ent, int32_t* cnt, const int32_t* all_cnt, const int32_t* src_off,
+                                                      const int64_t* seg_off, const uint2* recv, int32_t b0, int32_t nb_mine,
+                                                      int32_t nb_all, int32_t cap, int32_t me, int32_t ranks) {
+  const int w = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (w >= nb_mine) return;
+  const int b = b0 + w;
+  int have = min(all_cnt[(size_t)me * nb_all + b], cap);
+  long long raw = all_cnt[(size_t)me * nb_all + b];
+  for (int p = 0; p < ranks; ++p) {
+    if (p == me) continue;
+    const int n = min(all_cnt[(size_t)p * nb_all + b], cap);
+    raw += all_cnt[(size_t)p * nb_all + b];
+    const uint2* src = recv + seg_off[p] + src_off[(size_t)p * nb_mine + w];
+    for (int e = lane; e < n; e += 64)
+      if (have + e < cap) ent[(size_t)b * cap + have + e] = src[e];
+    have += n;  // (may pass cap: those entries are lost and the raw count says so)
+  }
+  if (lane == 0) cnt[b] = (int32_t)min(raw, (long long)0x7fffffff);
+}
+void launch_bucket_clamp(const int32_t* cnt, int32_t nb, int32_t cap, int32_t* clamped, hipStream_t s) {
+  if (nb <= 0) return;
+  hipLaunchKernelGGL(k_bucket_clamp, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, cnt, nb, cap, clamped);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_bucket_pack(const void* ent, const int32_t* cnt, const int32_t* off, int32_t nb, int32_t cap, void* out, hipStream_t s) {
+  if (nb <= 0) return;
+  hipLaunchKernelGGL(k_bucket_pack, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s, static_cast<const uint2*>(ent), cnt, off, nb, cap,
+                     static_cast<uint2*>(out));
+  HIP_CHECK(hipGetLastError());
+}
+void launch_bucket_merge(void* ent, int32_t* cnt, const int32_t* all_cnt, const int32_t* src_off, const int64_t* seg_off,
+                         const void* recv, int32_t b0, int32_t nb_mine, int32_t nb_all, int32_t cap, int32_t me, int32_t ranks,
+                         hipStream_t s) {
+  if (nb_mine <= 0) return;
+  hipLaunchKernelGGL(k_bucket_merge, dim3((unsigned)((nb_mine + 3) / 4)), dim3(256), 0, s, static_cast<uint2*>(ent), cnt, all_cnt, src_off,
+                     seg_off, static_cast<const uint2*>(recv), b0, nb_mine, nb_all, cap, me, ranks);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -86,9 +86,17 @@ void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float
 // phase B: every (row, column) with fp16 score > tau[row] (diagonal excluded) is appended to the hit list of its
 // (column split, row block, wave): hit_list [(list * 4 + wave) * hit_cap + e] = 8-byte entries {local row << 27 | column,
 // score bits}, hit_cnt [list * 4 + wave] (may exceed hit_cap: overflow); list = split * rb_count + (row block - rb_begin)
+// shards > 1 (half sweep of a sharded build): this call sweeps the work items shard, shard + shards, ... only
 void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count, const float* tau,
                          void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s,
-                         const KnnPanelSymDev* sd = nullptr);
+                         const KnnPanelSymDev* sd = nullptr, int shard = 0, int shards = 1);
+// sharded half sweep: min(cnt, cap) per bucket; a rank's buckets packed behind one another (off = exclusive scan of the
+// clamped counts); the other ranks' entries appended to the buckets [b0, b0 + nb_mine) (knn_gemm.hip: k_bucket_merge)
+void launch_bucket_clamp(const int32_t* cnt, int32_t nb, int32_t cap, int32_t* clamped, hipStream_t s);
+void launch_bucket_pack(const void* ent, const int32_t* cnt, const int32_t* off, int32_t nb, int32_t cap, void* out, hipStream_t s);
+void launch_bucket_merge(void* ent, int32_t* cnt, const int32_t* all_cnt, const int32_t* src_off, const int64_t* seg_off,
+                         const void* recv, int32_t b0, int32_t nb_mine, int32_t nb_all, int32_t cap, int32_t me, int32_t ranks,
+                         hipStream_t s);
 // per row: `keep` candidates holding the keep best fp16 scores (unsorted, the minimum in the last slot) -> cval / cidx
 // [N][keep]; rows whose candidate set is incomplete (a list overflowed) or too small (< keep) are appended to fail_rows
 // and get an empty list

@@ -920,6 +920,73 @@ void maybe_reorder(L& l) {
   l.reordered = true;
 }
 
+// Sharded half sweep: every rank holds partial buckets of ALL rows; rank q needs the other ranks' entries of the buckets of
+// ITS row blocks, [4 rb_per q, 4 rb_per (q + 1)).  Raw counts all-gathered (they also carry overflow: a count above the
+// capacity stays above it in the sum); each rank packs its buckets behind one another (the ranges are in rank order, so
+// one prefix sum gives every destination's segment), grouped send / recv, then the received entries are appended behind
+// the rank's own, in rank order.  The chunk overflow flags are combined by max.
+void exchange_buckets(L& h, const KnnPanelPlan& pp, const KnnPanelSymDev& sd, int rb_per) {
+  const int G = h.world, me = h.rank;
+  const int32_t nb_all = pp.npad / 32, nbp = rb_per * 4, stride = nbp * G, cap = pp.bucket_cap;
+  auto b0 = [&](int q) { return std::min(nb_all, q * nbp); };
+  DevBuf<int32_t> all_cnt, clamped, off, sums, src_off_d;
+  DevBuf<int64_t> seg_off_d;
+  all_cnt.alloc((size_t)G * stride);
+  HIP_CHECK(hipMemsetAsync(all_cnt.p, 0, (size_t)G * stride * 4, h.stream));
+  HIP_CHECK(hipMemcpyAsync(all_cnt.p + (size_t)me * stride, sd.bucket_cnt, (size_t)nb_all * 4, hipMemcpyDeviceToDevice, h.stream));
+  h.comm->allgather(all_cnt.p, (size_t)stride * 4, h.stream);
+  std::vector<int32_t> cnt((size_t)G * stride);
+  HIP_CHECK(hipMemcpyAsync(cnt.data(), all_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost, h.stream));
+  // my buckets, packed: off[b] = entries before bucket b
+  clamped.alloc((size_t)nb_all);
+  off.alloc((size_t)nb_all);
+  sums.alloc(scan_blocks(nb_all) + 1);
+  launch_bucket_clamp(sd.bucket_cnt, nb_all, cap, clamped.p, h.stream);
+  exclusive_scan_i32(clamped.p, off.p, nb_all, sums.p, h.stream);
+  sync(h);
+  auto held = [&](int p, int b) { return (int64_t)std::min(cnt[(size_t)p * stride + b], cap); };
+  std::vector<int64_t> seg_start((size_t)G + 1, 0);  // my packed buffer: where each destination's segment starts
+  for (int q = 0; q < G; ++q) {
+    int64_t n = 0;
+    for (int b = b0(q); b < b0(q + 1); ++b) n += held(me, b);
+    seg_start[(size_t)q + 1] = seg_start[(size_t)q] + n;
+  }
+  const int32_t nb_mine = b0(me + 1) - b0(me);
+  std::vector<int64_t> seg_off((size_t)G + 1, 0);                    // the receive buffer: one segment per source rank
+  std::vector<int32_t> src_off((size_t)G * std::max(1, nb_mine), 0);  // (source, my bucket) -> offset inside that segment
+  for (int p = 0; p < G; ++p) {
+    int64_t n = 0;
+    for (int w = 0; w < nb_mine; ++w) {
+      src_off[(size_t)p * nb_mine + w] = (int32_t)n;
+      if (p != me) n += held(p, b0(me) + w);
+    }
+    if (n >= ((int64_t)1 << 31)) throw Unsupported("sharded half sweep: more than 2^31 hits for one rank's rows from one peer");
+    seg_off[(size_t)p + 1] = seg_off[(size_t)p] + n;
+  }
+  DevBuf<unsigned long long> send, recv;
+  send.alloc((size_t)std::max<int64_t>(1, seg_start[(size_t)G]));
+  recv.alloc((size_t)std::max<int64_t>(1, seg_off[(size_t)G]));
+  launch_bucket_pack(sd.bucket_ent, sd.bucket_cnt, off.p, nb_all, cap, send.p, h.stream);
+  std::vector<CommXfer> sends, recvs;
+  for (int q = 0; q < G; ++q) {
+    if (q == me) continue;
+    const int64_t ns = seg_start[(size_t)q + 1] - seg_start[(size_t)q], nr = seg_off[(size_t)q + 1] - seg_off[(size_t)q];
+    if (ns > 0) sends.push_back(CommXfer{send.p + seg_start[(size_t)q], (size_t)ns * 8, q});
+    if (nr > 0) recvs.push_back(CommXfer{recv.p + seg_off[(size_t)q], (size_t)nr * 8, q});
+  }
+  h.comm->exchange(sends, recvs, h.stream);
+  if (nb_mine > 0) {
+    src_off_d.alloc(src_off.size());
+    seg_off_d.alloc(seg_off.size());
+    HIP_CHECK(hipMemcpyAsync(src_off_d.p, src_off.data(), src_off.size() * 4, hipMemcpyHostToDevice, h.stream));
+    HIP_CHECK(hipMemcpyAsync(seg_off_d.p, seg_off.data(), seg_off.size() * 8, hipMemcpyHostToDevice, h.stream));
+    launch_bucket_merge(sd.bucket_ent, sd.bucket_cnt, all_cnt.p, src_off_d.p, seg_off_d.p, recv.p, b0(me), nb_mine, stride, cap, me, G,
+                        h.stream);
+  }
+  h.comm->allreduce(sd.flags, (size_t)pp.S, COMM_I32, COMM_MAX, h.stream);
+  sync(h);  // the host vectors and the temporaries above are in use until here
+}
+
 void build_graph(L& h) {
   const double t0 = now_ms();
   drop_order(h);  // the build works on the API's row order
@@ -985,7 +1052,10 @@ void build_graph(L& h) {
   constexpr int panel_min = 8193;  // (up to 8192 rows: the dense route)
   // (a hit entry packs the column index into 25 bits, next to its two side flags)
   // (D > 768: the same route on the tile core, k_tile_thr -- half sweep only, so single-process builds only)
-  bool sym_ok = h.knn_sym && parts == 1;
+  // (round 5: the half sweep also under sharding -- the ranks split the work ITEMS of the one sweep and exchange the hits of
+  // each other's rows, below -- so a sharded build issues the single-GPU build's MFMA work, not twice it, and D > 768 keeps
+  // the threshold route instead of falling back to the list-maintaining tile prefilter)
+  bool sym_ok = h.knn_sym;
   if (sym_ok && prefilter && N >= panel_min && N < (1 << 25)) {
     // The half sweep delivers every hit to a bucket per 32 receiving rows: (npad / 32) x bucket_cap entries of 8 bytes --
     // 2.9 GB of temporaries at N = 1M (config 4), growing with N x the threshold sample's hit bound (the full sweep's
@@ -1026,7 +1096,7 @@ void build_graph(L& h) {
     HIP_CHECK(hipMemsetAsync(p_img.p + (size_t)pp.npad * pp.ldh / 2, 0, (size_t)128 * pp.ldh * 2, h.stream));
     p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
     p_tmax.alloc((size_t)pp.npad * pp.sample_groups);
-    p_tau.alloc((size_t)pp.npad);
+    p_tau.alloc(std::max((size_t)pp.npad, (size_t)rb_per * 128 * parts));  // (whole equal chunks for the all-gather of a sharded half sweep)
     p_queue.alloc(1);
     launch_panel_image(Yn.p, ldn, p_img.p, pp, N, h.D, h.stream);
     launch_panel_sample(p_img.p, p_smp.p, pp, N, h.stream);
@@ -1044,6 +1114,36 @@ void build_graph(L& h) {
   }
   // worst-case |fp16-path score - exact score| for unit rows: (2u + u^2) with u = 2^-11, plus fp32 accumulation
   const float delta = 9.8e-4f + 1.2e-7f * (float)h.D;
+  const bool sym_sharded = panel && pp.sym && parts > 1;
+  if (sym_sharded) {
+    // Half sweep of a sharded build (graph.py:35-65 cut over the ranks): thresholds of a rank's own row blocks, all-gathered;
+    // then ONE sweep of the tiles J >= I whose work items the ranks take in turn (item = rank, rank + parts, ...: items of a
+    // chunk stay neighbours), every rank delivering into buckets of ALL rows; then the entries of each rank's own rows travel
+    // to it (exchange_buckets).  OSC_KNN_FAKE_SHARDS runs the ranks' passes one after another into the same buckets.
+    ProfScope ps(h, 3);
+    for (int part = 0; part < parts; ++part) {
+      if (sharded && part != h.rank) continue;
+      const int rb_begin = std::min(all_rb, part * rb_per), rb_count = std::max(0, std::min(rb_per, all_rb - rb_begin));
+      const int nsets = (rb_count + pp.nrg - 1) / pp.nrg;
+      launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
+                           std::max(1, std::min(prop.multiProcessorCount, nsets * pp.SA)), h.stream);
+    }
+    launch_panel_tau(p_tmax.p, pp, N, p_tau.p, h.stream);  // (rows of other ranks' blocks: overwritten by the all-gather)
+    if (sharded) h.comm->allgather(p_tau.p, (size_t)rb_per * 128 * 4, h.stream);
+    const size_t nb = (size_t)pp.npad / 32;
+    p_hits.alloc(nb * pp.bucket_cap);
+    p_hcnt.alloc(nb + (size_t)pp.S);
+    HIP_CHECK(hipMemsetAsync(p_hcnt.p, 0, (nb + (size_t)pp.S) * 4, h.stream));
+    sym_dev.bucket_ent = p_hits.p;
+    sym_dev.bucket_cnt = p_hcnt.p;
+    sym_dev.flags = p_hcnt.p + nb;
+    const int sgrid = std::max(1, std::min(prop.multiProcessorCount, (pp.nitems + parts - 1) / parts));
+    for (int part = 0; part < parts; ++part) {
+      if (sharded && part != h.rank) continue;
+      launch_panel_filter(p_img.p, pp, N, 0, pp.nrb, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, sgrid, h.stream, &sym_dev, part, parts);
+    }
+    if (sharded) exchange_buckets(h, pp, sym_dev, rb_per);
+  }
   for (int part = 0; part < parts; ++part) {
     if (sharded && part != h.rank) continue;
     const int rb_begin = std::min(all_rb, part * rb_per);
@@ -1066,7 +1166,7 @@ void build_graph(L& h) {
       const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true, h.knn_splits);  // row range + keep for the re-scoring
       const int nsets = (rb_count + pp.nrg - 1) / pp.nrg;  // work items per column split (knn_gemm.hip)
       const int grid = std::max(1, std::min(prop.multiProcessorCount, nsets * pp.S));
-      {
+      if (!sym_sharded) {  // (a sharded half sweep has its thresholds and buckets already: above)
         ProfScope ps(h, 3);
         launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
                              std::max(1, std::min(prop.multiProcessorCount, nsets * pp.SA)), h.stream);

@@ -16,6 +16,10 @@ void launch_permute_ell(const int32_t* col_in, const float* a_in, const float* w
 // the device form -- walk it on the host.
 bool device_bfs_order(const int32_t* col, const int32_t* deg, int32_t width, int32_t N, int32_t* perm_out, hipStream_t s);
 
+// exclusive prefix sum of n int32 on the device (bfs_order.hip; out may alias in; sums: scan_blocks(n) int32 of scratch)
+size_t scan_blocks(int64_t n);
+void exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* sums, hipStream_t s);
+
 void launch_clustering_sample(const int32_t* col, const int32_t* deg, int32_t width, int64_t N, int32_t nsample,
                               unsigned long long* counts, hipStream_t s);
 

@@ -409,14 +409,21 @@ def test_sharded_build_with_kneighbors_above_128(amd, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_panel_prefilter_build_on_loopback_ranks(amd, world, monkeypatch):
-    """The default build route of the benchmark sizes (panel prefilter, N >= 16384 at D <= 768) under a communicator:
-    every rank runs the sample sweep, thresholds, main sweep, select and re-scoring for ITS row blocks only, the lists are
-    all-gathered -- the lattice must equal the single-handle build's, edge for edge."""
+@pytest.mark.parametrize("shape", [(16500, 300, 16, "1"), (16500, 300, 16, "0"), (9000, 1536, 24, "1"), (20001, 200, 40, "1")],
+                         ids=["panel-half", "panel-full", "tile-core-half", "ragged-k40-half"])
+def test_sharded_panel_prefilter_build_on_loopback_ranks(amd, world, shape, monkeypatch):
+    """The default build route of the benchmark sizes (thresholds-and-hits prefilter) under a communicator.  Round 5: the
+    ranks share ONE half sweep -- each takes every world-th work item of the tiles J >= I, delivers into buckets of all
+    rows, and the entries of a rank's own rows travel to it (counts all-gathered, packed segments exchanged, appended in
+    rank order: osc_api.hip exchange_buckets); thresholds, select and re-scoring stay per row block and the lists are
+    all-gathered.  D = 1536 takes the same route on the tile core (it used to fall back to the list-maintaining tile
+    prefilter when sharded); OSC_KNN_PANEL_SYM=0 keeps the full sweep per rank.  The lattice must equal the single-handle
+    build's, edge for edge."""
+    N, D, k, sym = shape
     monkeypatch.delenv("OSC_SHARD", raising=False)
     monkeypatch.delenv("OSC_KNN_MODE", raising=False)
+    monkeypatch.setenv("OSC_KNN_PANEL_SYM", sym)
     rng = np.random.default_rng(17)
-    N, D, k = 16500, 300, 16
     Y = rng.standard_normal((N, D), dtype=np.float32)
     single = amd.Oscillink(Y, kneighbors=k)
     assert single.build_info()["prefilter"] == 2
@@ -424,10 +431,11 @@ def test_sharded_panel_prefilter_build_on_loopback_ranks(amd, world, monkeypatch
 
     def rank_fn(rank, comm):
         lat = amd.Oscillink(Y, kneighbors=k, comm=comm)
-        return lat.build_info()["prefilter"], lat.graph_csr()
+        info = lat.build_info()
+        return info["prefilter"], info["fallback_rows"], lat.graph_csr()
 
-    for route, (rp, col, a, w, sd) in _ranks(world, rank_fn):
-        assert route == 2
+    for route, fallback, (rp, col, a, w, sd) in _ranks(world, rank_fn):
+        assert route == 2 and fallback <= 64
         assert np.array_equal(rp, want[0]) and np.array_equal(col, want[1]) and np.array_equal(a, want[2])
 
 
