@@ -383,7 +383,7 @@ def main():
         lat._call("osc_comm_info", C.byref(c_rank), C.byref(c_world), C.byref(c_mode), c_kind, 32)
         info = {"kind": c_kind.value.decode(), "world": int(c_world.value), "rank": int(c_rank.value),
                 "shard": "row" if c_mode.value == 1 else "column"}
-        ov = os.environ.get("OSC_COMM_OVERLAP")  # where the stop test's all-reduce runs (DESIGN.md section 6; default: by world size)
+        ov = os.environ.get("OSC_COMM_OVERLAP")  # where the stop test's all-reduce runs (DESIGN.md section 7; default: by world size)
         info["stop_test"] = ("none" if info["kind"] == "none" else
                              "second stream" if (ov not in (None, "0") or (ov is None and info["world"] >= 4)) else "solve's stream")
         ver = C.c_int32(0)
@@ -505,7 +505,7 @@ def main():
     mine["frac"] = mine["achieved_GBs"] / HBM_PEAK_GBS
     per_rank = [mine] if not launched else [json.loads(b.decode()) for b in rdzv.gather("rank_stats", json.dumps(mine).encode())]
 
-    # The same launch against the bound that applies to a gather (profiles/r02_gather_bench.txt):
+    # The same launch against the bound that applies to a gather (profiles/r02_gather_bench.txt, r05_inflight_bench.txt):
     # a CU retires one random 128-byte row per N clocks depending on the footprint an XCD gathers from -- measured with
     # scripts/exp/gather_bench.hip on this part, no index loads; 256 CUs at 2.4 GHz.  Two yardsticks: the whole 32-column
     # slab (N x 128 B: what the plain apply gathers from) and an L2-resident source (what source blocking aims at).

@@ -576,7 +576,7 @@ __global__ __launch_bounds__((CW + 1) * 64) __attribute__((amdgpu_waves_per_eu(W
       // Own rows / gates / rest descriptors of EC groups at a time (these loads miss).  Loads and stores of a wave retire
       // in issue order, so the loads of batch k + 1 are issued BEFORE the stores of batch k: otherwise every batch would
       // also wait for the previous batch's stores to be acknowledged.
-      constexpr int EC = INIT ? 1 : WPE <= 2 ? 4 : 2, NBATCH = (GM + EC - 1) / EC;  // (INIT: the y rows take the second group's registers; two groups: 72 spills)
+      constexpr int EC = WPE <= 2 ? 4 : INIT ? 1 : 2, NBATCH = (GM + EC - 1) / EC;  // (INIT: the y rows take the second group's registers; two groups: 72 spills)
       float4 xs[2][EC];
       float4 ys[2][INIT ? EC : 1];
       int2 rr[2][EC];

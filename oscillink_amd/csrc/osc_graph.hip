@@ -1,0 +1,573 @@
+// Lattice build orchestration, chain prior and internal row order of liboscillink_hip.so (see osc_internal.hpp).
+#include "osc_internal.hpp"
+
+// ---- graph build --------------------------------------------------------------------------------
+void graph_counts(L& h) {
+  std::vector<int32_t> d((size_t)h.N);
+  HIP_CHECK(hipMemcpyAsync(d.data(), h.deg.p, (size_t)h.N * 4, hipMemcpyDeviceToHost, h.stream));
+  sync(h);
+  int64_t nnz = 0;
+  int32_t mx = 0;
+  for (auto v : d) {
+    nnz += v;
+    mx = std::max(mx, v);
+  }
+  h.nnz = nnz;
+  h.max_deg = mx;
+}
+
+void alloc_ell(L& h, int32_t width) {
+  h.ell_t_ready = false;
+  h.blk_nb = 0;
+  ++h.graph_epoch;
+  h.width = std::max<int32_t>(1, width);
+  const size_t n = (size_t)h.N * h.width;
+  h.ell_col.alloc(n);
+  h.ell_a.alloc(n);
+  h.ell_w.alloc(n);
+  h.deg.alloc((size_t)h.N);
+  h.sqrt_deg.alloc((size_t)h.N);
+  HIP_CHECK(hipMemsetAsync(h.ell_col.p, 0, n * 4, h.stream));
+  HIP_CHECK(hipMemsetAsync(h.ell_a.p, 0, n * 4, h.stream));
+  HIP_CHECK(hipMemsetAsync(h.ell_w.p, 0, n * 4, h.stream));
+  HIP_CHECK(hipMemsetAsync(h.deg.p, 0, (size_t)h.N * 4, h.stream));
+}
+
+bool permuted(const L& h) { return !h.perm_h.empty(); }
+
+// path Laplacian structures from the stored chain (graph.py:96-111), in the handle's current row order
+void install_chain(L& l) {
+  ++l.graph_epoch;
+  if (!l.chain_present) return;
+  const int32_t len = (int32_t)l.chain_nodes.size();
+  auto id = [&](int32_t v) { return permuted(l) ? l.inv_h[(size_t)v] : v; };
+  // path adjacency, duplicate edges keep the max weight (graph.py:102-109)
+  std::map<std::pair<int32_t, int32_t>, float> adj;
+  for (int t = 0; t + 1 < len; ++t) {
+    const int32_t i = id(l.chain_nodes[(size_t)t]), j = id(l.chain_nodes[(size_t)t + 1]);
+    const float w = l.chain_w.empty() ? 1.0f : l.chain_w[(size_t)t];
+    auto put = [&](int32_t r, int32_t c) {
+      auto it = adj.find({r, c});
+      if (it == adj.end()) adj[{r, c}] = std::max(0.0f, w);
+      else it->second = std::max(it->second, w);
+    };
+    put(i, j);
+    put(j, i);
+  }
+  // normalized_laplacian(A_path) (graph.py:86-93): only rows that own an entry differ from identity
+  std::map<int32_t, float> dsum;
+  for (auto& kv : adj) dsum[kv.first.first] += kv.second;
+  std::map<int32_t, int32_t> slot;
+  for (auto& kv : dsum) slot.emplace(kv.first, (int32_t)slot.size());
+  std::map<int32_t, int32_t> cnt;
+  int32_t pwidth = 1;
+  for (auto& kv : adj) pwidth = std::max(pwidth, ++cnt[kv.first.first]);
+  const int32_t prows = (int32_t)slot.size();
+  std::vector<int32_t> hslot((size_t)l.N, -1), hcol((size_t)prows * pwidth, 0), hdeg((size_t)prows, 0);
+  std::vector<float> hw((size_t)prows * pwidth, 0.f);
+  auto sd = [&](int32_t r) {
+    auto it = dsum.find(r);
+    return std::sqrt(std::max(it == dsum.end() ? 0.0f : it->second, 1e-12f));
+  };
+  std::vector<int32_t> hprow((size_t)prows, 0);
+  for (auto& kv : slot) hslot[(size_t)kv.first] = kv.second, hprow[(size_t)kv.second] = kv.first;
+  for (auto& kv : adj) {
+    const int32_t r = kv.first.first, c = kv.first.second, sl = slot[r];
+    const int32_t e = hdeg[(size_t)sl]++;
+    hcol[(size_t)sl * pwidth + e] = c;
+    hw[(size_t)sl * pwidth + e] = (kv.second * (1.0f / sd(r))) * (1.0f / sd(c));
+  }
+  l.path_slot.alloc((size_t)l.N);
+  l.pcol.alloc(hcol.size());
+  l.pw.alloc(hw.size());
+  l.pdeg.alloc(hdeg.size());
+  l.prow.alloc(hprow.size());
+  HIP_CHECK(hipMemcpyAsync(l.prow.p, hprow.data(), hprow.size() * 4, hipMemcpyHostToDevice, l.stream));
+  HIP_CHECK(hipMemcpyAsync(l.path_slot.p, hslot.data(), hslot.size() * 4, hipMemcpyHostToDevice, l.stream));
+  HIP_CHECK(hipMemcpyAsync(l.pcol.p, hcol.data(), hcol.size() * 4, hipMemcpyHostToDevice, l.stream));
+  HIP_CHECK(hipMemcpyAsync(l.pw.p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, l.stream));
+  HIP_CHECK(hipMemcpyAsync(l.pdeg.p, hdeg.data(), hdeg.size() * 4, hipMemcpyHostToDevice, l.stream));
+  sync(l);
+  l.prows = prows;
+  l.pwidth = pwidth;
+}
+
+// move every row-indexed device array between two row orders: new row i takes old row from[i]; ids -> relabel[id]
+void move_state(L& l, const int32_t* from_d, const int32_t* relabel_d) {
+  const size_t n = (size_t)l.N * l.ld;
+  for (DevBuf<float>* b : {&l.Y, &l.U}) {  // AP is scratch between solves
+    launch_move_rows(l.AP.p, b->p, from_d, l.N, l.ld, false, l.stream);
+    HIP_CHECK(hipMemcpyAsync(b->p, l.AP.p, n * 4, hipMemcpyDeviceToDevice, l.stream));
+  }
+  DevBuf<float> t1;
+  t1.alloc((size_t)l.N);
+  for (DevBuf<float>* b : {&l.B, &l.sqrt_deg}) {
+    launch_move_f32(t1.p, b->p, from_d, l.N, false, l.stream);
+    HIP_CHECK(hipMemcpyAsync(b->p, t1.p, (size_t)l.N * 4, hipMemcpyDeviceToDevice, l.stream));
+  }
+  const size_t ne = (size_t)l.N * l.width;
+  DevBuf<int32_t> col2, deg2;
+  DevBuf<float> a2, w2;
+  col2.alloc(ne);
+  a2.alloc(ne);
+  w2.alloc(ne);
+  deg2.alloc((size_t)l.N);
+  launch_permute_ell(l.ell_col.p, l.ell_a.p, l.ell_w.p, l.deg.p, from_d, relabel_d, l.width, l.N, col2.p, a2.p, w2.p,
+                     deg2.p, l.stream);
+  sync(l);
+  l.ell_col.swap(col2);
+  l.ell_a.swap(a2);
+  l.ell_w.swap(w2);
+  l.deg.swap(deg2);
+  l.ell_t_ready = false;
+  l.blk_nb = 0;
+  l.have_ustar = false;
+  l.u_sharded = false;
+  ++l.graph_epoch;
+}
+
+void drop_order(L& l) {  // back to the API's row order
+  if (!permuted(l)) return;
+  move_state(l, l.inv_d.p, l.perm_d.p);
+  l.perm_h.clear();
+  l.inv_h.clear();
+  install_chain(l);
+}
+
+void apply_order(L& l, const std::vector<int32_t>& perm) {  // perm[new] = old ; state must be in API order
+  l.perm_h = perm;
+  l.inv_h.assign((size_t)l.N, 0);
+  for (int64_t i = 0; i < l.N; ++i) l.inv_h[(size_t)perm[(size_t)i]] = (int32_t)i;
+  l.perm_d.alloc((size_t)l.N);
+  l.inv_d.alloc((size_t)l.N);
+  HIP_CHECK(hipMemcpyAsync(l.perm_d.p, l.perm_h.data(), (size_t)l.N * 4, hipMemcpyHostToDevice, l.stream));
+  HIP_CHECK(hipMemcpyAsync(l.inv_d.p, l.inv_h.data(), (size_t)l.N * 4, hipMemcpyHostToDevice, l.stream));
+  move_state(l, l.perm_d.p, l.inv_d.p);
+  install_chain(l);
+}
+
+// breadth-first order over the lattice graph (components in order of their smallest node): neighbours end up
+// within a narrow band of rows, which is what the XCD-local L2 of the operator apply can hold
+std::vector<int32_t> bfs_order(L& l) {
+  const size_t ne = (size_t)l.N * l.width;
+  std::vector<int32_t> col(ne), deg((size_t)l.N);
+  HIP_CHECK(hipMemcpyAsync(col.data(), l.ell_col.p, ne * 4, hipMemcpyDeviceToHost, l.stream));
+  HIP_CHECK(hipMemcpyAsync(deg.data(), l.deg.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+  sync(l);
+  std::vector<int32_t> order;
+  order.reserve((size_t)l.N);
+  std::vector<char> seen((size_t)l.N, 0);
+  for (int64_t start = 0; start < l.N; ++start) {
+    if (seen[(size_t)start]) continue;
+    seen[(size_t)start] = 1;
+    size_t head = order.size();
+    order.push_back((int32_t)start);
+    while (head < order.size()) {
+      const int32_t u = order[head++];
+      const int32_t* cu = col.data() + (size_t)u * l.width;
+      for (int e = 0; e < deg[(size_t)u]; ++e) {
+        const int32_t v = cu[e];
+        if (!seen[(size_t)v]) {
+          seen[(size_t)v] = 1;
+          order.push_back(v);
+        }
+      }
+    }
+  }
+  return order;
+}
+
+// Re-order the rows when it pays: the BFS + state move cost a few ms at N = 100k and buy ~1.5x on the operator apply
+// of a clustered lattice, nothing on an unstructured one.  Auto mode decides on a sampled clustering coefficient.
+void maybe_reorder(L& l) {
+  l.reordered = false;
+  l.clustering = 0.0;
+  // under a communicator only the row-sharded CG re-orders (every rank holds the same graph and takes the same
+  // deterministic decision and order; the halo lists shrink with locality); the column-sharded default keeps API order
+  if (l.reorder == 0 || (l.comm != nullptr && l.shard_mode != 1) || l.N < 2) return;
+  if (l.reorder < 0) {
+    if (l.N < 8192 || l.nnz == 0) return;  // small lattices run out of LDS / L2 anyway
+    DevBuf<unsigned long long> cnt;
+    cnt.alloc(2);
+    HIP_CHECK(hipMemsetAsync(cnt.p, 0, 16, l.stream));
+    launch_clustering_sample(l.ell_col.p, l.deg.p, l.width, l.N, 1024, cnt.p, l.stream);
+    unsigned long long hc[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(hc, cnt.p, 16, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+    l.clustering = hc[1] ? (double)hc[0] / (double)hc[1] : 0.0;
+    if (l.clustering < 0.05) return;
+  }
+  // the order itself: on the device (bfs_order.hip; the same order as the host walk below it, OSC_BFS_HOST=1 forces that)
+  bool on_device = false;
+  if (!l.bfs_host) {
+    DevBuf<int32_t> perm;
+    perm.alloc((size_t)l.N);
+    if (device_bfs_order(l.ell_col.p, l.deg.p, l.width, (int32_t)l.N, perm.p, l.stream)) {
+      std::vector<int32_t> ph((size_t)l.N);
+      HIP_CHECK(hipMemcpyAsync(ph.data(), perm.p, (size_t)l.N * 4, hipMemcpyDeviceToHost, l.stream));
+      sync(l);
+      apply_order(l, ph);
+      on_device = true;
+    }
+  }
+  if (!on_device) apply_order(l, bfs_order(l));
+  l.reordered = true;
+}
+
+// Sharded half sweep: every rank holds partial buckets of ALL rows; rank q needs the other ranks' entries of the buckets of
+// ITS row blocks, [4 rb_per q, 4 rb_per (q + 1)).  Raw counts all-gathered (they also carry overflow: a count above the
+// capacity stays above it in the sum); each rank packs its buckets behind one another (the ranges are in rank order, so
+// one prefix sum gives every destination's segment), grouped send / recv, then the received entries are appended behind
+// the rank's own, in rank order.  The chunk overflow flags are combined by max.
+void exchange_buckets(L& h, const KnnPanelPlan& pp, const KnnPanelSymDev& sd, int rb_per) {
+  const int G = h.world, me = h.rank;
+  const int32_t nb_all = pp.npad / 32, nbp = rb_per * 4, stride = nbp * G, cap = pp.bucket_cap;
+  auto b0 = [&](int q) { return std::min(nb_all, q * nbp); };
+  DevBuf<int32_t> all_cnt, clamped, off, sums, src_off_d;
+  DevBuf<int64_t> seg_off_d;
+  all_cnt.alloc((size_t)G * stride);
+  HIP_CHECK(hipMemsetAsync(all_cnt.p, 0, (size_t)G * stride * 4, h.stream));
+  HIP_CHECK(hipMemcpyAsync(all_cnt.p + (size_t)me * stride, sd.bucket_cnt, (size_t)nb_all * 4, hipMemcpyDeviceToDevice, h.stream));
+  h.comm->allgather(all_cnt.p, (size_t)stride * 4, h.stream);
+  std::vector<int32_t> cnt((size_t)G * stride);
+  HIP_CHECK(hipMemcpyAsync(cnt.data(), all_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost, h.stream));
+  // my buckets, packed: off[b] = entries before bucket b
+  clamped.alloc((size_t)nb_all);
+  off.alloc((size_t)nb_all);
+  sums.alloc(scan_blocks(nb_all) + 1);
+  launch_bucket_clamp(sd.bucket_cnt, nb_all, cap, clamped.p, h.stream);
+  exclusive_scan_i32(clamped.p, off.p, nb_all, sums.p, h.stream);
+  sync(h);
+  auto held = [&](int p, int b) { return (int64_t)std::min(cnt[(size_t)p * stride + b], cap); };
+  std::vector<int64_t> seg_start((size_t)G + 1, 0);  // my packed buffer: where each destination's segment starts
+  for (int q = 0; q < G; ++q) {
+    int64_t n = 0;
+    for (int b = b0(q); b < b0(q + 1); ++b) n += held(me, b);
+    seg_start[(size_t)q + 1] = seg_start[(size_t)q] + n;
+  }
+  const int32_t nb_mine = b0(me + 1) - b0(me);
+  std::vector<int64_t> seg_off((size_t)G + 1, 0);                    // the receive buffer: one segment per source rank
+  std::vector<int32_t> src_off((size_t)G * std::max(1, nb_mine), 0);  // (source, my bucket) -> offset inside that segment
+  for (int p = 0; p < G; ++p) {
+    int64_t n = 0;
+    for (int w = 0; w < nb_mine; ++w) {
+      src_off[(size_t)p * nb_mine + w] = (int32_t)n;
+      if (p != me) n += held(p, b0(me) + w);
+    }
+    if (n >= ((int64_t)1 << 31)) throw Unsupported("sharded half sweep: more than 2^31 hits for one rank's rows from one peer");
+    seg_off[(size_t)p + 1] = seg_off[(size_t)p] + n;
+  }
+  DevBuf<unsigned long long> send, recv;
+  send.alloc((size_t)std::max<int64_t>(1, seg_start[(size_t)G]));
+  recv.alloc((size_t)std::max<int64_t>(1, seg_off[(size_t)G]));
+  launch_bucket_pack(sd.bucket_ent, sd.bucket_cnt, off.p, nb_all, cap, send.p, h.stream);
+  std::vector<CommXfer> sends, recvs;
+  for (int q = 0; q < G; ++q) {
+    if (q == me) continue;
+    const int64_t ns = seg_start[(size_t)q + 1] - seg_start[(size_t)q], nr = seg_off[(size_t)q + 1] - seg_off[(size_t)q];
+    if (ns > 0) sends.push_back(CommXfer{send.p + seg_start[(size_t)q], (size_t)ns * 8, q});
+    if (nr > 0) recvs.push_back(CommXfer{recv.p + seg_off[(size_t)q], (size_t)nr * 8, q});
+  }
+  h.comm->exchange(sends, recvs, h.stream);
+  if (nb_mine > 0) {
+    src_off_d.alloc(src_off.size());
+    seg_off_d.alloc(seg_off.size());
+    HIP_CHECK(hipMemcpyAsync(src_off_d.p, src_off.data(), src_off.size() * 4, hipMemcpyHostToDevice, h.stream));
+    HIP_CHECK(hipMemcpyAsync(seg_off_d.p, seg_off.data(), seg_off.size() * 8, hipMemcpyHostToDevice, h.stream));
+    launch_bucket_merge(sd.bucket_ent, sd.bucket_cnt, all_cnt.p, src_off_d.p, seg_off_d.p, recv.p, b0(me), nb_mine, stride, cap, me, G,
+                        h.stream);
+  }
+  h.comm->allreduce(sd.flags, (size_t)pp.S, COMM_I32, COMM_MAX, h.stream);
+  sync(h);  // the host vectors and the temporaries above are in use until here
+}
+
+void build_graph(L& h) {
+  const double t0 = now_ms();
+  drop_order(h);  // the build works on the API's row order
+  const int32_t N = (int32_t)h.N;
+  h.k_eff = std::min<int32_t>(h.k_eff, std::max<int32_t>(1, N - 1));  // lattice.py:60
+  h.have_ustar = false;
+  if (N <= 1) {  // graph.py:30-32
+    alloc_ell(h, 1);
+    const float one_em6 = 1e-6f;  // sqrt(max(0, 1e-12))
+    std::vector<float> sd((size_t)h.N, one_em6);
+    HIP_CHECK(hipMemcpyAsync(h.sqrt_deg.p, sd.data(), sd.size() * 4, hipMemcpyHostToDevice, h.stream));
+    sync(h);
+    h.knn_k = 0;
+    h.have_graph = true;
+    h.nnz = 0;
+    h.max_deg = 0;
+    h.build_ms = now_ms() - t0;
+    return;
+  }
+  const int32_t k = h.k_eff;
+  // k <= 128: register-resident streaming lists (exact / prefilter / small-dense routes below).  Larger k (the
+  // reference takes any k <= N - 1, lattice.py:60): dense similarity rows in chunks + a radix select per row.
+  const bool any_k = k > 128;
+  const int32_t ldn = ((h.D + 31) / 32) * 32;
+  DevBuf<float> Yn;
+  Yn.alloc((size_t)h.N * ldn);
+  launch_normalize_rows(h.Y.p, h.ld, Yn.p, ldn, h.N, h.D, h.stream);
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, h.device));
+  const int slots = prop.multiProcessorCount * (k <= 64 ? 2 : 1);
+  // multi-GPU: row-block-sharded build -- this rank computes the top-k lists of its 128-row blocks against all
+  // columns, then one all-gather of the (idx, sim) lists; mutual test / cap / Laplacian weights run on every rank.
+  const int all_rb = (N + 127) / 128;
+  // OSC_KNN_FAKE_SHARDS=G (test hook): run the G per-rank passes of a sharded build one after another on this GPU
+  const int fake = h.knn_fake_shards;
+  const bool sharded = h.comm != nullptr && h.world > 1;
+  const int parts = sharded ? h.world : (fake > 1 ? fake : 1);
+  const int rb_per = (all_rb + parts - 1) / parts;
+  const size_t list_rows = parts > 1 ? (size_t)rb_per * 128 * parts : (size_t)h.N;
+  h.knn_val.alloc(list_rows * k);
+  h.knn_idx.alloc(list_rows * k);
+  h.knn_k = k;
+  HIP_CHECK(hipMemsetAsync(h.knn_val.p, 0, list_rows * k * 4, h.stream));
+  HIP_CHECK(hipMemsetAsync(h.knn_idx.p, 0xFF, list_rows * k * 4, h.stream));
+  // Two ways to the per-row top-k lists (identical results):
+  //  exact     : fp32 MFMA similarity tiles + running top-k.
+  //  prefilter : fp16 MFMA tiles keep the best KC >= k+16 candidates per row, exact fp32 re-scoring picks the k;
+  //              a row is accepted only if the worst-case fp16 error bound proves no left-out column can belong
+  //              to its top-k, otherwise the row is redone by the exact kernel.
+  // kept candidates per row: k plus a margin; rows whose margin turns out too thin are redone exactly
+  const int keep_f = std::min(96, k + std::max(12, k / 2));
+  constexpr bool dense_small = true;
+  constexpr int dense_max = 8192;
+  // small lattices go through the dense similarity matrix (below); beyond that the fp16 prefilter pays
+  bool prefilter = (keep_f >= k + 8) && N >= 4096 && !(dense_small && parts == 1 && N <= dense_max);
+  // OSC_KNN_MODE = exact | prefilter | panel: force one route (tests, A/B)
+  if (h.knn_mode == 1) prefilter = false;
+  if (h.knn_mode == 2) prefilter = (keep_f >= k + 8);
+  if (any_k) prefilter = false;
+  // The prefilter's GEMM has two shapes: "panel" (knn_gemm.hip: query panel in registers, thresholds from a column
+  // sample, hits appended -- D <= 768 and enough row blocks for the sample) and the older 128 x 128 tile with
+  // register-resident sorted lists (k_knn_pref), which serves everything else.
+  constexpr int panel_min = 8193;  // (up to 8192 rows: the dense route)
+  // (a hit entry packs the column index into 25 bits, next to its two side flags)
+  // (D > 768: the same route on the tile core, k_tile_thr -- half sweep only, so single-process builds only)
+  // (round 5: the half sweep also under sharding -- the ranks split the work ITEMS of the one sweep and exchange the hits of
+  // each other's rows, below -- so a sharded build issues the single-GPU build's MFMA work, not twice it, and D > 768 keeps
+  // the threshold route instead of falling back to the list-maintaining tile prefilter)
+  bool sym_ok = h.knn_sym;
+  if (sym_ok && prefilter && N >= panel_min && N < (1 << 25)) {
+    // The half sweep delivers every hit to a bucket per 32 receiving rows: (npad / 32) x bucket_cap entries of 8 bytes --
+    // 2.9 GB of temporaries at N = 1M (config 4), growing with N x the threshold sample's hit bound (the full sweep's
+    // lists: 0.2-0.5 GB).  Beyond a budget, or where the device cannot spare it, the build takes the full sweep (D <= 768)
+    // or the tile prefilter (D > 768) instead of failing in the allocator.
+    const KnnPanelPlan sp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, false, true, h.knn_tune);
+    const double bucket_bytes = (double)(sp.npad / 32) * (double)sp.bucket_cap * 8.0;
+    size_t mem_free = 0, mem_total = 0;
+    HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
+    constexpr double kSymBucketBudget = 12.0 * 1024 * 1024 * 1024;
+    if (sp.ok && (bucket_bytes > kSymBucketBudget || bucket_bytes > 0.5 * (double)mem_free)) sym_ok = false;
+  }
+  const bool depth_ok = knn_panel_nkt(h.D) != 0 || (sym_ok && knn_tile_nkt(h.D) != 0);
+  bool panel = prefilter && depth_ok && N >= panel_min && N < (1 << 25) &&
+               knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, false, sym_ok, h.knn_tune).ok;
+  if (h.knn_mode == 3) panel = prefilter = (keep_f >= k + 8) && !any_k && depth_ok && N >= 6144 && N < (1 << 25);
+  if (h.knn_mode == 2) panel = false;
+  h.knn_panel = panel;
+  DevBuf<float> cand_val, cval;
+  DevBuf<int32_t> cand_idx, cidx, fail_rows, fail_count;
+  DevBuf<float> Yh;  // fp16 image, viewed as float slots
+  const int32_t ldh = ((h.D + 63) / 64) * 64;
+  h.knn_fallback_rows = 0;
+  h.knn_prefilter = prefilter;
+  KnnPanelPlan pp{};
+  DevBuf<float> p_img, p_smp, p_tmax, p_tau;
+  DevBuf<unsigned long long> p_hits;
+  DevBuf<int32_t> p_hcnt;
+  DevBuf<unsigned> p_queue;
+  KnnPanelSymDev sym_dev{};
+  if (panel) {
+    // (image rows scattered over the lattice rows in single-process builds: knn_gemm.hpp, KnnPanelPlan::scatter)
+    // single-process builds sweep only the column tiles J >= I of every row block (knn_gemm.hip: symmetric half sweep);
+    // a sharded build's ranks own row blocks and would have to exchange the column-side hits, so they keep the full sweep
+    // (OSC_KNN_PANEL_SCATTER=0 / OSC_KNN_PANEL_SYM=0: A/B and tests)
+    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, h.knn_scatter && parts == 1, sym_ok, h.knn_tune);
+    p_img.alloc((size_t)(pp.npad + 128) * pp.ldh / 2);  // (+ one zero tile: k_tile_thr2 sweeps row blocks and column tiles in pairs)
+    HIP_CHECK(hipMemsetAsync(p_img.p + (size_t)pp.npad * pp.ldh / 2, 0, (size_t)128 * pp.ldh * 2, h.stream));
+    p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
+    p_tmax.alloc((size_t)pp.npad * pp.sample_groups);
+    p_tau.alloc(std::max((size_t)pp.npad, (size_t)rb_per * 128 * parts));  // (whole equal chunks for the all-gather of a sharded half sweep)
+    p_queue.alloc(1);
+    launch_panel_image(Yn.p, ldn, p_img.p, pp, N, h.D, h.stream);
+    launch_panel_sample(p_img.p, p_smp.p, pp, N, h.stream);
+  }
+  if (prefilter) {
+    if (!panel) {
+      Yh.alloc((size_t)h.N * ldh / 2);
+      launch_to_f16(Yn.p, ldn, Yh.p, ldh, h.N, h.D, h.stream);
+    }
+    cval.alloc((size_t)h.N * keep_f);
+    cidx.alloc((size_t)h.N * keep_f);
+    fail_rows.alloc((size_t)h.N);
+    fail_count.alloc(1);
+    HIP_CHECK(hipMemsetAsync(fail_count.p, 0, 4, h.stream));
+  }
+  // worst-case |fp16-path score - exact score| for unit rows: (2u + u^2) with u = 2^-11, plus fp32 accumulation
+  const float delta = 9.8e-4f + 1.2e-7f * (float)h.D;
+  const bool sym_sharded = panel && pp.sym && parts > 1;
+  if (sym_sharded) {
+    // Half sweep of a sharded build (graph.py:35-65 cut over the ranks): thresholds of a rank's own row blocks, all-gathered;
+    // then ONE sweep of the tiles J >= I whose work items the ranks take in turn (item = rank, rank + parts, ...: items of a
+    // chunk stay neighbours), every rank delivering into buckets of ALL rows; then the entries of each rank's own rows travel
+    // to it (exchange_buckets).  OSC_KNN_FAKE_SHARDS runs the ranks' passes one after another into the same buckets.
+    ProfScope ps(h, 3);
+    for (int part = 0; part < parts; ++part) {
+      if (sharded && part != h.rank) continue;
+      const int rb_begin = std::min(all_rb, part * rb_per), rb_count = std::max(0, std::min(rb_per, all_rb - rb_begin));
+      const int nsets = (rb_count + pp.nrg - 1) / pp.nrg;
+      launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
+                           std::max(1, std::min(prop.multiProcessorCount, nsets * pp.SA)), h.stream);
+    }
+    launch_panel_tau(p_tmax.p, pp, N, p_tau.p, h.stream);  // (rows of other ranks' blocks: overwritten by the all-gather)
+    if (sharded) h.comm->allgather(p_tau.p, (size_t)rb_per * 128 * 4, h.stream);
+    const size_t nb = (size_t)pp.npad / 32;
+    p_hits.alloc(nb * pp.bucket_cap);
+    p_hcnt.alloc(nb + (size_t)pp.S);
+    HIP_CHECK(hipMemsetAsync(p_hcnt.p, 0, (nb + (size_t)pp.S) * 4, h.stream));
+    sym_dev.bucket_ent = p_hits.p;
+    sym_dev.bucket_cnt = p_hcnt.p;
+    sym_dev.flags = p_hcnt.p + nb;
+    const int sgrid = std::max(1, std::min(prop.multiProcessorCount, (pp.nitems + parts - 1) / parts));
+    for (int part = 0; part < parts; ++part) {
+      if (sharded && part != h.rank) continue;
+      launch_panel_filter(p_img.p, pp, N, 0, pp.nrb, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, sgrid, h.stream, &sym_dev, part, parts);
+    }
+    if (sharded) exchange_buckets(h, pp, sym_dev, rb_per);
+  }
+  for (int part = 0; part < parts; ++part) {
+    if (sharded && part != h.rank) continue;
+    const int rb_begin = std::min(all_rb, part * rb_per);
+    const int rb_count = std::max(0, std::min(rb_per, all_rb - rb_begin));
+    if (any_k) {
+      // chunks of up to ~1 GiB of similarity rows (multiple of 128 rows)
+      const int32_t ldS = ((N + 31) / 32) * 32;
+      const int64_t cap_rows = std::max<int64_t>(128, (((int64_t)1 << 28) / ldS) / 128 * 128);
+      const int32_t row_lo = rb_begin * 128, row_hi = std::min(N, (rb_begin + rb_count) * 128);
+      const int32_t chunk = (int32_t)std::min<int64_t>(cap_rows, ((row_hi - row_lo + 127) / 128) * 128);
+      if (row_hi > row_lo) {
+        DevBuf<float> Sm;
+        Sm.alloc((size_t)chunk * ldS);
+        ProfScope ps(h, 3);
+        for (int32_t r = row_lo; r < row_hi; r += chunk)
+          launch_knn_rows_any(Yn.p, ldn, N, k, r, std::min(chunk, row_hi - r), Sm.p, ldS, h.knn_val.p, h.knn_idx.p, h.stream);
+        sync(h);  // Sm goes back to the pool at scope exit
+      }
+    } else if (panel) {
+      const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true, h.knn_splits);  // row range + keep for the re-scoring
+      const int nsets = (rb_count + pp.nrg - 1) / pp.nrg;  // work items per column split (knn_gemm.hip)
+      const int grid = std::max(1, std::min(prop.multiProcessorCount, nsets * pp.S));
+      if (!sym_sharded) {  // (a sharded half sweep has its thresholds and buckets already: above)
+        ProfScope ps(h, 3);
+        launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
+                             std::max(1, std::min(prop.multiProcessorCount, nsets * pp.SA)), h.stream);
+        launch_panel_tau(p_tmax.p, pp, N, p_tau.p, h.stream);
+        if (pp.sym) {
+          const size_t nb = (size_t)pp.npad / 32;
+          p_hits.alloc(nb * pp.bucket_cap);  // one bucket per group of 32 receiving rows
+          p_hcnt.alloc(nb + (size_t)pp.S);   // [bucket counts | chunk flags]
+          HIP_CHECK(hipMemsetAsync(p_hcnt.p, 0, (nb + (size_t)pp.S) * 4, h.stream));
+          sym_dev.bucket_ent = p_hits.p;
+          sym_dev.bucket_cnt = p_hcnt.p;
+          sym_dev.flags = p_hcnt.p + nb;
+          const int sgrid = std::max(1, std::min(prop.multiProcessorCount, pp.nitems));
+          launch_panel_filter(p_img.p, pp, N, rb_begin, rb_count, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, sgrid, h.stream, &sym_dev);
+        } else {
+          p_hits.alloc((size_t)rb_count * pp.S * 4 * pp.hit_cap);  // one list per (work item, wave)
+          p_hcnt.alloc((size_t)rb_count * pp.S * 4);
+          launch_panel_filter(p_img.p, pp, N, rb_begin, rb_count, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, grid, h.stream);
+        }
+      }
+      launch_panel_select(pp, rb_begin, rb_count, N, p_hits.p, p_hcnt.p, cval.p, cidx.p, fail_rows.p, fail_count.p,
+                          h.stream, pp.sym ? &sym_dev : nullptr);
+      launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
+                         fail_count.p, h.stream);
+    } else if (prefilter) {
+      const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true, h.knn_splits);
+      const size_t ncand = (size_t)h.N * plan.S * plan.KC;
+      cand_val.alloc(ncand);
+      cand_idx.alloc(ncand);
+      {
+        ProfScope ps(h, 3);
+        launch_knn_topk(plan, Yh.p, ldh / 2, N, cand_val.p, cand_idx.p, h.stream);
+      }
+      HIP_CHECK(hipMemsetAsync(cidx.p, 0xFF, (size_t)h.N * keep_f * 4, h.stream));
+      launch_knn_merge(plan, cand_val.p, cand_idx.p, N, keep_f, cval.p, cidx.p, 0, h.stream);
+      launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
+                         fail_count.p, h.stream);
+    } else if (parts == 1 && N <= dense_max && dense_small) {
+      // small lattices: dense S + per-row argmax selection (the streaming kernel's first-tile inserts dominate here)
+      const int32_t ldS = ((N + 31) / 32) * 32;
+      DevBuf<float> Sm;
+      Sm.alloc((size_t)N * ldS);
+      ProfScope ps(h, 3);
+      launch_knn_dense(Yn.p, ldn, N, k, Sm.p, ldS, h.knn_val.p, h.knn_idx.p, h.stream);
+      sync(h);  // Sm goes back to the pool at scope exit
+    } else {
+      const KnnPlan plan = knn_plan(N, k, slots, rb_begin, rb_count, false, h.knn_splits);
+      const size_t ncand = (size_t)h.N * plan.S * plan.KC;
+      cand_val.alloc(ncand);
+      cand_idx.alloc(ncand);
+      {
+        ProfScope ps(h, 3);
+        launch_knn_topk(plan, Yn.p, ldn, N, cand_val.p, cand_idx.p, h.stream);
+      }
+      launch_knn_merge(plan, cand_val.p, cand_idx.p, N, k, h.knn_val.p, h.knn_idx.p, 1, h.stream);
+    }
+  }
+  if (prefilter) {
+    int32_t nfail = 0;
+    HIP_CHECK(hipMemcpyAsync(&nfail, fail_count.p, 4, hipMemcpyDeviceToHost, h.stream));
+    sync(h);
+    DevBuf<int32_t> fail_rows2, fail_count2;
+    int32_t* fail_list = fail_rows.p;
+    if (panel && pp.sym && nfail > 0) {  // second-stage proof from the rows' whole buckets (knn_gemm.hip: k_bucket_rescore)
+      fail_rows2.alloc((size_t)nfail);
+      fail_count2.alloc(1);
+      HIP_CHECK(hipMemsetAsync(fail_count2.p, 0, 4, h.stream));
+      launch_bucket_rescore(pp, sym_dev, Yn.p, ldn, N, fail_rows.p, nfail, p_tau.p, k, delta, h.knn_val.p, h.knn_idx.p,
+                            fail_rows2.p, fail_count2.p, h.stream);
+      HIP_CHECK(hipMemcpyAsync(&nfail, fail_count2.p, 4, hipMemcpyDeviceToHost, h.stream));
+      sync(h);
+      fail_list = fail_rows2.p;
+    }
+    h.knn_fallback_rows = nfail;
+    bool few_done = false;
+    if (nfail > 0 && nfail <= 32) {  // a handful of rows: stream the columns once, select per row (0.15 vs 3.9 ms at N = 100k)
+      const int32_t ldS = ((N + 31) / 32) * 32;
+      DevBuf<float> Sm;
+      Sm.alloc((size_t)nfail * ldS);
+      few_done = launch_knn_few_rows(Yn.p, ldn, N, k, fail_list, nfail, Sm.p, ldS, h.knn_val.p, h.knn_idx.p, h.stream);
+      if (few_done) sync(h);  // Sm goes back to the pool at scope exit
+    }
+    if (nfail > 0 && !few_done) {  // redo the unproven rows with the exact kernel (ties / dense clusters of near-equal scores)
+      KnnPlan plan = knn_plan(N, k, slots, 0, (nfail + 127) / 128, false, h.knn_splits);
+      plan.qrows = fail_list;
+      plan.nq = nfail;
+      const size_t ncand = (size_t)h.N * plan.S * plan.KC;
+      cand_val.alloc(ncand);
+      cand_idx.alloc(ncand);
+      launch_knn_topk(plan, Yn.p, ldn, N, cand_val.p, cand_idx.p, h.stream);
+      launch_knn_merge(plan, cand_val.p, cand_idx.p, N, k, h.knn_val.p, h.knn_idx.p, 1, h.stream);
+    }
+  }
+  if (sharded) {
+    const size_t cnt = (size_t)rb_per * 128 * k;  // equal chunk per rank, in place
+    h.comm->allgather(h.knn_val.p, cnt * 4, h.stream);
+    h.comm->allgather(h.knn_idx.p, cnt * 4, h.stream);
+  }
+  alloc_ell(h, k);
+  launch_mutual_ell(h.knn_val.p, h.knn_idx.p, N, k, h.width, h.ell_col.p, h.ell_a.p, h.deg.p, h.stream);
+  DevBuf<float> scale;
+  scale.alloc((size_t)h.N);
+  launch_cap_and_normalize(h.ell_a.p, h.ell_w.p, h.ell_col.p, h.deg.p, h.width, N, h.row_cap, 1, scale.p,
+                           h.sqrt_deg.p, h.stream);
+  graph_counts(h);  // synchronises
+  h.have_graph = true;
+  maybe_reorder(h);
+  h.build_ms = now_ms() - t0;
+}
+

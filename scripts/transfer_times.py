@@ -33,8 +33,6 @@ def child(N, D, k):
         t3 = time.perf_counter()
         ts.append(t1 - t0), tu.append(t2 - t1), tr.append(t3 - t2)
     ok = bool(np.isfinite(U).all() and np.isfinite(Us).all() and abs(float(U[N // 2, 3])) > 0)
-    ref = np.empty_like(U)
-    os.environ["OSC_PINNED_DL_CHECK"] = "1"
     print(f"N={N} D={D} pinned_results={os.environ.get('OSC_PINNED_RESULTS', '1')} pinned_dl={os.environ.get('OSC_PINNED_DL', '1')} threads={os.environ.get('OSC_COPY_THREADS', 'auto')}: "
           f"settle_ms={1e3 * np.median(ts):.2f} U_read_ms={1e3 * np.median(tu[1:]):.2f} (first {1e3 * tu[0]:.1f}) "
           f"refresh_Ustar_ms={1e3 * np.median(tr[1:]):.2f} (solve {lat.last_ustar['solve_ms']:.2f}) finite={ok} "
