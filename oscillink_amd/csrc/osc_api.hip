@@ -66,6 +66,7 @@ void read_env_build(L& h) {
   if (num("OSC_KNN_PANEL_RANK", v)) h.knn_tune.rank = v;
   if (num("OSC_KNN_TILE_WIDE", v)) h.knn_tune.tile_wide = v != 0 ? 1 : 0;
   if (num("OSC_KNN_TILE_GROUP_MB", v)) h.knn_tune.tile_group_mb = v;
+  h.knn_force_exchange = num("OSC_KNN_FORCE_EXCHANGE", v) && v != 0;
   h.bfs_host = num("OSC_BFS_HOST", v) && v != 0;
   h.halo_force = 0;
   if (const char* e = getenv("OSC_HALO")) h.halo_force = !strcmp(e, "full") ? 1 : !strcmp(e, "lists") ? 2 : 0;

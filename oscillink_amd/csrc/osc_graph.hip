@@ -408,7 +408,10 @@ void build_graph(L& h) {
   }
   // worst-case |fp16-path score - exact score| for unit rows: (2u + u^2) with u = 2^-11, plus fp32 accumulation
   const float delta = 9.8e-4f + 1.2e-7f * (float)h.D;
-  const bool sym_sharded = panel && pp.sym && parts > 1;
+  // (OSC_KNN_FORCE_EXCHANGE: the same flow with its collectives under a one-rank communicator -- the only form in which the
+  // RCCL backend's all-gather / grouped send-recv / int32 max all-reduce of this path can run on a one-GPU box)
+  const bool exchange = sharded || (h.knn_force_exchange && h.comm != nullptr);
+  const bool sym_sharded = panel && pp.sym && (parts > 1 || exchange);
   if (sym_sharded) {
     // Half sweep of a sharded build (graph.py:35-65 cut over the ranks): thresholds of a rank's own row blocks, all-gathered;
     // then ONE sweep of the tiles J >= I whose work items the ranks take in turn (item = rank, rank + parts, ...: items of a
@@ -423,7 +426,7 @@ void build_graph(L& h) {
                            std::max(1, std::min(prop.multiProcessorCount, nsets * pp.SA)), h.stream);
     }
     launch_panel_tau(p_tmax.p, pp, N, p_tau.p, h.stream);  // (rows of other ranks' blocks: overwritten by the all-gather)
-    if (sharded) h.comm->allgather(p_tau.p, (size_t)rb_per * 128 * 4, h.stream);
+    if (exchange) h.comm->allgather(p_tau.p, (size_t)rb_per * 128 * 4, h.stream);
     const size_t nb = (size_t)pp.npad / 32;
     p_hits.alloc(nb * pp.bucket_cap);
     p_hcnt.alloc(nb + (size_t)pp.S);
@@ -436,7 +439,7 @@ void build_graph(L& h) {
       if (sharded && part != h.rank) continue;
       launch_panel_filter(p_img.p, pp, N, 0, pp.nrb, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, sgrid, h.stream, &sym_dev, part, parts);
     }
-    if (sharded) exchange_buckets(h, pp, sym_dev, rb_per);
+    if (exchange) exchange_buckets(h, pp, sym_dev, rb_per);
   }
   for (int part = 0; part < parts; ++part) {
     if (sharded && part != h.rank) continue;

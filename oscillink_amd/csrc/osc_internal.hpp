@@ -135,6 +135,7 @@ struct osc_lattice {
   int knn_splits = 0;          // OSC_KNN_SPLITS (tile / exact routes: column splits)
   bool knn_scatter = true;     // OSC_KNN_PANEL_SCATTER
   bool knn_sym = true;         // OSC_KNN_PANEL_SYM
+  bool knn_force_exchange = false;  // OSC_KNN_FORCE_EXCHANGE=1 (test hook): run the sharded half sweep's collectives under a ONE-rank communicator too
   KnnPanelTune knn_tune{};     // OSC_KNN_PANEL_NRG / _RHO / _T / _RANK
   int halo_force = 0;          // OSC_HALO: 1 full, 2 lists
   bool bfs_host = false;       // OSC_BFS_HOST=1: the breadth-first row order is walked on the host (A/B, tests)

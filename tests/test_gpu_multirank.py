@@ -439,6 +439,26 @@ def test_sharded_panel_prefilter_build_on_loopback_ranks(amd, world, shape, monk
         assert np.array_equal(rp, want[0]) and np.array_equal(col, want[1]) and np.array_equal(a, want[2])
 
 
+def test_sharded_half_sweep_collectives_on_the_rccl_backend_of_one_rank(amd, monkeypatch):
+    """The collectives of the sharded half sweep (threshold all-gather, count all-gather, grouped send / recv, int32 max
+    all-reduce of the chunk flags: osc_graph.hip exchange_buckets) on the RCCL backend itself, with the one rank a one-GPU
+    box allows (OSC_KNN_FORCE_EXCHANGE=1 keeps the sharded flow at world 1): the lattice equals the plain build's."""
+    from oscillink_amd.sharding import rccl_unique_id
+
+    monkeypatch.delenv("OSC_SHARD", raising=False)
+    monkeypatch.delenv("OSC_KNN_MODE", raising=False)
+    rng = np.random.default_rng(3)
+    for N, D, k in ((16600, 200, 12), (9000, 900, 20)):
+        Y = rng.standard_normal((N, D), dtype=np.float32)
+        monkeypatch.delenv("OSC_KNN_FORCE_EXCHANGE", raising=False)
+        want = amd.Oscillink(Y, kneighbors=k).graph_csr()
+        monkeypatch.setenv("OSC_KNN_FORCE_EXCHANGE", "1")
+        lat = amd.Oscillink(Y, kneighbors=k, comm=(rccl_unique_id(), 0, 1))
+        assert lat.build_info()["prefilter"] == 2
+        got = lat.graph_csr()
+        assert all(np.array_equal(a, b) for a, b in zip(want[:3], got[:3]))
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_column_sharded_solves_with_the_blocked_matvec(amd, world, monkeypatch):
     """The source-blocked CG matvec inside a column-sharded solve: forced onto a fixture (per-rank windows of 64 / 32
