@@ -48,7 +48,9 @@ struct KnnPanelPlan {
   // clusters x 100 rows in cluster order, N = 100k: 100 000 fallback rows, build 190 ms against 39 ms for the same
   // anchors shuffled).  Scattered, neighbouring image rows are unrelated lattice rows whatever the caller's order.  Only
   // the prefilter stage works on image rows; k_panel_select hands lattice ids (rows and candidate columns) to the
-  // re-scoring.  Single-process builds only (a sharded build's ranks own contiguous LATTICE row blocks).
+  // re-scoring.  Single-process builds and sharded builds that share the half sweep (their ranks own IMAGE row blocks and
+  // assemble the lists by all-reduce: osc_graph.hip); a sharded build with a full sweep per rank (OSC_KNN_PANEL_SYM=0) keeps
+  // the identity, because its ranks own contiguous LATTICE row blocks.
   int32_t scatter;
 };
 // image row -> lattice row of a plan (rows >= N are padding and map to themselves)

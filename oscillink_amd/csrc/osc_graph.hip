@@ -385,7 +385,9 @@ void build_graph(L& h) {
     // single-process builds sweep only the column tiles J >= I of every row block (knn_gemm.hip: symmetric half sweep);
     // a sharded build's ranks own row blocks and would have to exchange the column-side hits, so they keep the full sweep
     // (OSC_KNN_PANEL_SCATTER=0 / OSC_KNN_PANEL_SYM=0: A/B and tests)
-    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, h.knn_scatter && parts == 1, sym_ok, h.knn_tune);
+    // (round 5: the row scatter also under a SHARED half sweep -- a rank then owns image row blocks, i.e. lattice rows spread
+    // over the whole lattice, and the ranks' lists are combined by sums instead of an all-gather, below)
+    pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, h.knn_scatter && (parts == 1 || sym_ok), sym_ok, h.knn_tune);
     p_img.alloc((size_t)(pp.npad + 128) * pp.ldh / 2);  // (+ one zero tile: k_tile_thr2 sweeps row blocks and column tiles in pairs)
     HIP_CHECK(hipMemsetAsync(p_img.p + (size_t)pp.npad * pp.ldh / 2, 0, (size_t)128 * pp.ldh * 2, h.stream));
     p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
@@ -487,7 +489,7 @@ void build_graph(L& h) {
       launch_panel_select(pp, rb_begin, rb_count, N, p_hits.p, p_hcnt.p, cval.p, cidx.p, fail_rows.p, fail_count.p,
                           h.stream, pp.sym ? &sym_dev : nullptr);
       launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
-                         fail_count.p, h.stream);
+                         fail_count.p, h.stream, pp.scatter);
     } else if (prefilter) {
       const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true, h.knn_splits);
       const size_t ncand = (size_t)h.N * plan.S * plan.KC;
@@ -557,7 +559,13 @@ void build_graph(L& h) {
       launch_knn_merge(plan, cand_val.p, cand_idx.p, N, k, h.knn_val.p, h.knn_idx.p, 1, h.stream);
     }
   }
-  if (sharded) {
+  if (sharded && panel && pp.scatter != 1) {
+    // a rank's rows are spread over the lattice (image row blocks): every row has exactly one writer, the others hold the
+    // initial pattern (0.0f / -1), so a sum of the similarities and a max of the indices assemble the lists exactly
+    const size_t cnt = (size_t)N * k;
+    h.comm->allreduce(h.knn_val.p, cnt, COMM_F32, COMM_SUM, h.stream);
+    h.comm->allreduce(h.knn_idx.p, cnt, COMM_I32, COMM_MAX, h.stream);
+  } else if (sharded) {
     const size_t cnt = (size_t)rb_per * 128 * k;  // equal chunk per rank, in place
     h.comm->allgather(h.knn_val.p, cnt * 4, h.stream);
     h.comm->allgather(h.knn_idx.p, cnt * 4, h.stream);
