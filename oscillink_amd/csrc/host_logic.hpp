@@ -191,14 +191,22 @@ inline int xs_groups(int32_t ncols, int cap = 8) {
 // below min_reduced groups (the plain slab apply loses to the general path under 4 groups -- config 5's shape 56.4 ms
 // general, 54.2 at 4 groups, 57.1 at 2, 60.7 at 1 --, the blocked matvec still wins at 2: xs_plan in osc_api.hip; config
 // 4's shape loses at every count)
+// Round 5: beyond that budget (N > 524 288) the mode survives only under the wide blocked matvec -- what it gathers from at one
+// time is a source BLOCK, not a slab, so the slabs in flight need not fit anything -- with at most four slab groups and
+// windows of at least four slabs (profiles/r05_large_n_blocked.txt, per settle against the plain slab apply: 600k x 768 k 32
+// 62.1 -> 45.6 ms, 700k x 384 k 16 21.8 -> 20.9, 800k x 256 16.2 -> 15.6, 1M x 384 31.5 -> 29.6, 1M x 128 10.06 -> 9.98, 1.5M x
+// 256 34.1 -> 32.5; eight groups lose to four: 600k x 768 47.5 vs 45.6; 1M x 64 k 8 loses: 3.70 vs 3.64).  The caller
+// (xs_plan) keeps the mode there only when the blocked matvec can run.
+constexpr int64_t kXsBudgetRows = 524288;
 inline int xs_groups_for(int64_t N, int32_t ncols, int cap, int min_reduced = 4) {
   const int natural = xs_groups(ncols, cap);
   int g = natural;
   const double cap_bytes = 128.0 * 1024 * 1024;
   while (g > 1 && (double)g * (double)N * 128.0 > cap_bytes) g >>= 1;
-  if ((double)g * (double)N * 128.0 > cap_bytes) return 0;
-  if (g != natural && g < min_reduced) return 0;
-  return g;
+  const bool fits = (double)g * (double)N * 128.0 <= cap_bytes && !(g != natural && g < min_reduced);
+  if (fits) return g;
+  if (N > kXsBudgetRows && ncols >= 128) return std::min(natural, 4);
+  return 0;
 }
 // Work decomposition of k_apply_blocked: xs workgroups per XCD take part; the XCDs form xs_groups slab groups, the
 // 8 / xs_groups XCDs of a group split the rows; a gathering wave holds `groups` row groups (of 8 rows) per slice, the
@@ -254,7 +262,9 @@ inline double blocked_edges_per_block(int64_t N) { return N <= 140000 ? 3.3 : 2.
 // pipeline (scripts/exp/nb_sweep.py, profiles/r05_nb_sweep.txt, per AP launch): 100k x 768 k 32 8 blocks 0.554 ms / 9 0.557
 // / 12 0.627; k 16 4-5 blocks; k 64 16-18; 160k and 200k x 768 k 32 9 blocks (200k: 1.220 against 1.303 at the 12 the old
 // rule gives); 260k 10; 200k x 1536 k 64 16-18 blocks 4.03 ms against 4.59 at 24.
-inline double blocked_edges_per_block_wide(int64_t N) { return N <= 140000 ? 3.5 : N <= 220000 ? 3.2 : 2.9; }
+// Beyond 450k rows (round 5, profiles/r05_large_n_blocked.txt): 2.2 -- 500k x 384 k 16 7 blocks 14.27 ms per settle against 14.66
+// at 5, 600k x 768 k 32 12 blocks 45.6 against 50.1 at 9 and 49.2 at 14, 1M x 384 k 16 6 blocks 29.6 against 30.0 at 5.
+inline double blocked_edges_per_block_wide(int64_t N) { return N <= 140000 ? 3.5 : N <= 220000 ? 3.2 : N <= 450000 ? 2.9 : 2.2; }
 inline int blocked_block_count(double mean_deg, double edges_per_block, int max_blocks) {
   const int nb = (int)std::max(2.0, std::floor(mean_deg / edges_per_block + 0.5));
   return std::min(nb, max_blocks);

@@ -91,6 +91,8 @@ int xs_plan(const L& h, int32_t ncols, int grid) {
   if (h.N < 16384 && (double)h.nnz < 10.0 * (double)h.N) return 0;
   const int xg = xs_groups_for(h, ncols);
   if (xg == 0) return 0;
+  // beyond the Infinity-Cache budget only the (wide) blocked matvec keeps the mode: host_logic.hpp, xs_groups_for
+  if (h.N > host::kXsBudgetRows && blocked_plan(h, false) == 0) return 0;
   // Two slab groups (262k < N <= 524k: four XCDs share a slab) pay only under the blocked matvec -- measured in round 3
   // against the general path: 300k x 768 k 32 25.96 -> 22.33 ms per settle, 400k x 512 k 32 22.70 -> 19.10, 300k x 768 k 64
   // 43.1 -> 36.3, 500k x 384 k 16 a tie; the plain slab apply at two groups loses (config 5's shape: 57.1 vs 56.4 ms) and one

@@ -304,11 +304,19 @@ int main(int argc, char** argv) {
       if (N <= 3000) check_blk_place(g);
     }
   }
-  // xs group counts: divisors of 8, slabs in flight within 128 MiB
-  for (int64_t N : {1000, 16384, 100000, 131072, 131073, 200000, 262144, 300000, 1000000})
+  // xs group counts: divisors of 8; slabs in flight within 128 MiB up to kXsBudgetRows rows, beyond that (the wide blocked
+  // matvec's regime: its working set is a source block) at most four groups and only for windows of >= 4 slabs
+  for (int64_t N : {1000, 16384, 100000, 131072, 131073, 200000, 262144, 300000, 524288, 524289, 1000000, 3000000})
     for (int32_t ncols : {32, 96, 128, 192, 256, 384, 768, 1000, 1536, 2048}) {
       const int g = xs_groups_for(N, ncols, 8);
-      CHECK(g == 0 || (8 % g == 0 && (double)g * (double)N * 128.0 <= 128.0 * 1024 * 1024), "N %lld ncols %d groups %d", (long long)N, ncols, g);
+      const bool in_budget = (double)g * (double)N * 128.0 <= 128.0 * 1024 * 1024;
+      CHECK(g == 0 || (8 % g == 0 && (in_budget || (N > kXsBudgetRows && ncols >= 128 && g <= 4 && g <= xs_groups(ncols, 8)))),
+            "N %lld ncols %d groups %d", (long long)N, ncols, g);
+    }
+  for (double deg : {1.0, 13.8, 28.8, 59.5})
+    for (int64_t N : {96000, 140000, 220000, 450000, 450001, 2000000}) {
+      const int nb = blocked_block_count(deg, blocked_edges_per_block_wide(N), 32);
+      CHECK(nb >= 2 && nb <= 32, "wide deg %g", deg);
     }
   for (double deg : {0.0, 1.0, 6.5, 13.8, 28.8, 59.5, 128.0})
     for (int64_t N : {1000, 100000, 140000, 140001, 1000000}) {
