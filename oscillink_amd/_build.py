@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liboscillink_hip.so")
 SOURCES = ["osc_api.hip", "osc_runtime.hip", "osc_graph.hip", "osc_solve.hip", "cg_kernels.hip", "knn_kernels.hip", "receipt_kernels.hip", "small_kernels.hip", "perm_kernels.hip", "comm.hip", "dynamics_kernels.hip", "knn_gemm.hip", "bfs_order.hip"]
-HEADERS = ["osc_internal.hpp", "common.hpp", "host_logic.hpp", "loop_group.hpp", "knn.hpp", "receipts.hpp", "small.hpp", "perm.hpp", "comm.hpp", "dynamics.hpp", "knn_gemm.hpp", os.path.join("..", "..", "include", "oscillink_hip.h")]
+HEADERS = ["osc_internal.hpp", "common.hpp", "host_logic.hpp", "loop_group.hpp", "knn.hpp", "knn_rowmap.hpp", "receipts.hpp", "small.hpp", "perm.hpp", "comm.hpp", "dynamics.hpp", "knn_gemm.hpp", os.path.join("..", "..", "include", "oscillink_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # kernel A/B experiments: OSC_BUILD_DEFINES="FOO BAR=1" adds -DFOO -DBAR=1 (part of the stamp)
 FLAGS += [f"-D{d}" for d in os.environ.get("OSC_BUILD_DEFINES", "").split()]

@@ -113,6 +113,9 @@ struct PanelArgs {
   // half sweep of a SHARDED build: this rank sweeps the work items item_offset, item_offset + item_stride, ... (items of
   // one chunk stay neighbours in every rank's sequence); 1 / 0 otherwise
   int32_t item_stride, item_offset;
+  // k_panel's half sweep only: the launch takes the work items [item_begin, item_end) of the queue's order (item_end = 0: all)
+  // -- the items of some column chunks, launched by the streamed create as the rows those chunks need arrive
+  int32_t item_begin, item_end;
 };
 
 // LDS-DMA of one 1 KiB piece: M0 = LDS destination - K offset, the K offset rides in the immediate
@@ -162,9 +165,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   unsigned* const s_hdr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + PANEL_LDS);
   v4f* const s_sc = reinterpret_cast<v4f*>(reinterpret_cast<char*>(lds) + PANEL_LDS + (size_t)4 * HB_CAP_SYM * 4);
   float* const s_tc = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + PANEL_LDS + (size_t)4 * HB_CAP_SYM * 20);
+  if constexpr (SYM) {
+    if (a.item_end > 0) nitems = min(nitems, a.item_end);
+  }
   for (;;) {
     if (tid == 0) {
-      const int it = (int)atomicAdd(a.queue, 1u) * a.item_stride + a.item_offset;
+      const int it = (SYM ? a.item_begin : 0) + (int)atomicAdd(a.queue, 1u) * a.item_stride + a.item_offset;
       s_item = it;
       if constexpr (SYM) {  // chunks are queued from the last (every row block sweeps it) to the first (T row blocks): the
         int c = a.nchunks - 1, first = 0;  // short diagonal items come last and fill the tail of the persistent grid
@@ -847,14 +853,14 @@ __global__ __launch_bounds__(256, 2) void k_tile_thr(const PanelArgs a, const in
   }
 }
 
-// fp32 unit rows -> fp16 image of 16 * Yn, zero beyond (N, D)
-__global__ void k_panel_image(const float* Yn, int32_t ldn, _Float16* Yh, int32_t ldh, int32_t npad, int32_t N, int32_t D,
-                              int32_t scatter) {
+// fp32 unit rows -> fp16 image of 16 * Yn, zero beyond (N, D); image rows [r0, r1)
+__global__ void k_panel_image(const float* Yn, int32_t ldn, _Float16* Yh, int32_t ldh, int32_t r0, int32_t r1, int32_t N, int32_t D,
+                              int32_t mapped, KnnRowMap map) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 halfs
   const int per_row = ldh / 8;
-  if (i >= (int64_t)npad * per_row) return;
-  const int row = (int)(i / per_row), c0 = (int)(i % per_row) * 8;
-  const int64_t src = row < N ? ((int64_t)row * scatter) % N : 0;  // KnnPanelPlan::scatter
+  if (i >= (int64_t)(r1 - r0) * per_row) return;
+  const int row = r0 + (int)(i / per_row), c0 = (int)(i % per_row) * 8;
+  const int64_t src = row < N ? (mapped ? knn_map_lattice_row(map, N, row) : row) : 0;  // KnnPanelPlan::map
   half8 v;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -925,8 +931,8 @@ struct SelectSym {
 };
 __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, const int32_t* hit_cnt, int32_t hit_cap, int32_t S,
                                                       int32_t rb_begin, int32_t rb_count, int32_t nsub, int32_t keep,
-                                                      int32_t N, int32_t scatter, float* cval, int32_t* cidx, int32_t* fail_rows,
-                                                      int32_t* fail_count, const SelectSym sy) {
+                                                      int32_t N, int32_t mapped, KnnRowMap map, float* cval, int32_t* cidx,
+                                                      int32_t* fail_rows, int32_t* fail_count, const SelectSym sy) {
   __shared__ uint2 sorted[SORT_CAP];
   __shared__ int hist[32], start[33], cursor[32], s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -992,7 +998,7 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
   for (int rl = rl0 + wave; rl < rl0 + rows_here; rl += 4) {
     const int irow = row_base + rl;  // image row
     if (irow >= N) continue;
-    const int row = (int)(((int64_t)irow * scatter) % N);  // lattice row (KnnPanelPlan::scatter)
+    const int row = mapped ? knn_map_lattice_row(map, N, irow) : irow;  // lattice row (KnnPanelPlan::map)
     const int m = bad ? 0 : hist[rl];
     float* ov = cval + (size_t)row * keep;
     int32_t* oi = cidx + (size_t)row * keep;
@@ -1012,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
       bits[q] = 0u;
       if (e < m) {
         const uint2 v = ent[e];
-        col[q] = (unsigned)(((int64_t)v.x * scatter) % N);  // image column -> lattice column
+        col[q] = mapped ? (unsigned)knn_map_lattice_row(map, N, (int)v.x) : v.x;  // image column -> lattice column
         bits[q] = v.y;
         key[q] = order_key(v.y);
       }
@@ -1322,7 +1328,7 @@ constexpr int WIDE_CAP = 1024;  // candidates of one row (= SEL_CAP)
 __global__ __launch_bounds__(256) void k_bucket_rescore(const float* __restrict__ Yn, int32_t ldn, int32_t N, const int32_t* rows_in,
                                                         int32_t nrows, const uint2* bucket_ent, const int32_t* bucket_cnt,
                                                         int32_t bucket_cap, const int32_t* flags, int32_t T, const float* tau,
-                                                        int32_t scatter, int64_t scatter_inv, int32_t k, float delta,
+                                                        int32_t mapped, KnnRowMap map, int32_t k, float delta,
                                                         float* out_val, int32_t* out_idx, int32_t* fail_rows, int32_t* fail_count) {
   __shared__ int s_idx[4][WIDE_CAP];
   __shared__ float s_sc[4][WIDE_CAP];
@@ -1333,7 +1339,7 @@ __global__ __launch_bounds__(256) void k_bucket_rescore(const float* __restrict_
   auto give_up = [&]() {
     if (lane == 0) fail_rows[atomicAdd(fail_count, 1)] = row;
   };
-  const int irow = (int)(((int64_t)row * scatter_inv) % N);  // image row of this lattice row (KnnPanelPlan::scatter)
+  const int irow = mapped ? knn_map_image_row(map, N, row) : row;  // image row of this lattice row (KnnPanelPlan::map)
   const int b = irow >> 5, rl = irow & 31;
   const int raw = bucket_cnt[b];
   if (raw > bucket_cap || flags[(irow >> 7) / T] != 0) {  // hits of this row were lost: nothing can be concluded from the bucket
@@ -1349,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_bucket_rescore(const float* __restrict_
     const bool mine = (x & ROW_SIDE) != 0u && (int)(x >> 27) == rl;
     const unsigned long long m = __ballot(mine);
     const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-    if (mine && pos < WIDE_CAP) s_idx[wave][pos] = (int)(((int64_t)(x & COL_MASK) * scatter) % N);
+    if (mine && pos < WIDE_CAP) s_idx[wave][pos] = mapped ? knn_map_lattice_row(map, N, (int)(x & COL_MASK)) : (int)(x & COL_MASK);
     n += __popcll(m);
   }
   if (n < k || n > WIDE_CAP) {
@@ -1448,24 +1454,16 @@ int knn_panel_nkt(int32_t D) { return D <= 384 ? 6 : D <= 768 ? 12 : 0; }
 // K steps of the tile core (both operands through LDS): any depth; used beyond 768 columns, up to 4096
 int knn_tile_nkt(int32_t D) { return (D > 768 && D <= 4096) ? (D + 63) / 64 : 0; }
 
+void knn_panel_set_pieces(KnnPanelPlan& p, int32_t N, const int32_t* starts, int npieces) {
+  p.map = knn_row_map(N, starts, npieces, p.scatter != 1);
+}
+
 KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows, bool sym,
                             const KnnPanelTune& tune) {
   KnnPanelPlan p{};
   p.sym = sym;
-  p.scatter = 1;
-  if (scatter_rows && N > 2) {  // ~ N / golden ratio, made coprime to N: consecutive image rows are far-apart lattice rows
-    auto gcd = [](int64_t a, int64_t b) {
-      while (b) {
-        const int64_t t = a % b;
-        a = b;
-        b = t;
-      }
-      return a;
-    };
-    int64_t a = (int64_t)((double)N * 0.6180339887498949) | 1;
-    while (a < N && gcd(a, N) != 1) a += 2;
-    if (a < N) p.scatter = (int32_t)a;
-  }
+  p.map = knn_row_map(N, nullptr, 1, scatter_rows);
+  p.scatter = p.map.a[0];
   p.nkt = knn_panel_nkt(D);
   p.tile_core = false;
   if (p.nkt == 0 && sym && knn_tile_nkt(D) != 0) {  // D > 768: the tile core under the same thresholds / buckets / select
@@ -1584,10 +1582,21 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
   return p;
 }
 
-void launch_panel_image(const float* Yn, int32_t ldn, void* Yh, const KnnPanelPlan& p, int32_t N, int32_t D, hipStream_t s) {
-  const int64_t n = (int64_t)p.npad * (p.ldh / 8);
-  hipLaunchKernelGGL(k_panel_image, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Yn, ldn,
-                     static_cast<_Float16*>(Yh), p.ldh, p.npad, N, D, p.scatter);
+void launch_panel_image(const float* Yn, int32_t ldn, void* Yh, const KnnPanelPlan& p, int32_t N, int32_t D, hipStream_t s, int32_t r0,
+                        int32_t r1) {
+  if (r1 < 0) r1 = p.npad;
+  if (r0 < 0 || r1 > p.npad || r1 <= r0) return;
+  const int64_t n = (int64_t)(r1 - r0) * (p.ldh / 8);
+  hipLaunchKernelGGL(k_panel_image, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Yn, ldn, static_cast<_Float16*>(Yh), p.ldh, r0, r1,
+                     N, D, p.scatter != 1 ? 1 : 0, p.map);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_panel_sample_rows(const float* Yn_rows, int32_t ldn, void* Ys, const KnnPanelPlan& p, int32_t rows, int32_t D, hipStream_t s) {
+  if (rows != p.sample_tiles * 128) throw std::runtime_error("launch_panel_sample_rows: one unit row per sample row");
+  const int64_t n = (int64_t)rows * (p.ldh / 8);
+  hipLaunchKernelGGL(k_panel_image, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Yn_rows, ldn, static_cast<_Float16*>(Ys), p.ldh, 0,
+                     rows, rows, D, 0, knn_row_map(rows, nullptr, 1, false));
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1625,19 +1634,34 @@ void launch_panel_tilemax(const void* Yh, const void* Ys, const KnnPanelPlan& p,
   launch_panel<0>(a, p.nkt, p.nrg, false, grid, s);
 }
 
-void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float* tau, hipStream_t s) {
-  hipLaunchKernelGGL(k_panel_tau, dim3((unsigned)((p.npad + 3) / 4)), dim3(256), 0, s, tmax, p.sample_groups, p.sample_rank,
-                     p.npad, tau);
+void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float* tau, hipStream_t s, int32_t r0, int32_t r1) {
+  if (r1 < 0) r1 = p.npad;
+  if (r0 < 0 || r1 > p.npad || r1 <= r0) return;
+  hipLaunchKernelGGL(k_panel_tau, dim3((unsigned)((r1 - r0 + 3) / 4)), dim3(256), 0, s, tmax + (size_t)r0 * p.sample_groups, p.sample_groups,
+                     p.sample_rank, r1 - r0, tau + r0);
   (void)N;
   HIP_CHECK(hipGetLastError());
 }
 
 void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count, const float* tau,
                          void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s, const KnnPanelSymDev* sd,
-                         int shard, int shards) {
+                         int shard, int shards, int chunk_lo, int chunk_hi) {
   if (rb_count <= 0) return;
   PanelArgs a{};
   a.item_stride = 1;
+  if (chunk_hi >= 0) {  // a window of column chunks: the queue walks the chunks from the last to the first
+    if (!p.sym || p.tile_core || chunk_lo < 0 || chunk_hi > p.S || chunk_lo >= chunk_hi)
+      throw std::runtime_error("launch_panel_filter: chunk windows are for the panel core's half sweep");
+    auto sets = [&](int c) { return (std::min(p.nrb, (c + 1) * p.T) + p.nrg - 1) / p.nrg; };
+    int begin = 0, end = 0;
+    for (int c = p.S - 1; c >= chunk_lo; --c) {
+      if (c >= chunk_hi) begin += sets(c);
+      end += sets(c);
+    }
+    a.item_begin = begin;
+    a.item_end = end;
+    grid = std::max(1, std::min(grid, (end - begin + std::max(1, shards) - 1) / std::max(1, shards)));
+  }
   if (shards > 1) {
     if (!p.sym || shard < 0 || shard >= shards) throw std::runtime_error("launch_panel_filter: only the half sweep is cut by work items");
     a.item_stride = shards;
@@ -1711,8 +1735,8 @@ void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int3
   int nsub = 1;
   while (nsub < 32 && p.hit_bound * (32 / nsub) > 0.75 * SORT_CAP) nsub *= 2;
   hipLaunchKernelGGL(k_panel_select, dim3((unsigned)(rb_count * 4 * nsub)), dim3(256), 0, s,
-                     static_cast<const uint2*>(hit_list), hit_cnt, p.hit_cap, p.S, rb_begin, rb_count, nsub, p.keep, N, p.scatter, cval, cidx,
-                     fail_rows, fail_count, sy);
+                     static_cast<const uint2*>(hit_list), hit_cnt, p.hit_cap, p.S, rb_begin, rb_count, nsub, p.keep, N, p.scatter != 1 ? 1 : 0,
+                     p.map, cval, cidx, fail_rows, fail_count, sy);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1780,21 +1804,8 @@ void launch_bucket_rescore(const KnnPanelPlan& p, const KnnPanelSymDev& sd, cons
                            const int32_t* rows_in, int32_t nrows, const float* tau, int32_t k, float delta, float* out_val,
                            int32_t* out_idx, int32_t* fail_rows, int32_t* fail_count, hipStream_t s) {
   if (nrows <= 0) return;
-  // inverse of the row scatter modulo N (extended Euclid; scatter is coprime to N, 1 = identity)
-  int64_t inv = 1;
-  if (p.scatter != 1) {
-    int64_t t = 0, nt = 1, r = N, nr = p.scatter % N;
-    while (nr != 0) {
-      const int64_t q = r / nr;
-      std::swap(t, nt);
-      nt -= q * t;
-      std::swap(r, nr);
-      nr -= q * r;
-    }
-    inv = ((t % N) + N) % N;
-  }
   hipLaunchKernelGGL(k_bucket_rescore, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, Yn, ldn, N, rows_in, nrows,
-                     static_cast<const uint2*>(sd.bucket_ent), sd.bucket_cnt, p.bucket_cap, sd.flags, p.T, tau, p.scatter, inv, k,
+                     static_cast<const uint2*>(sd.bucket_ent), sd.bucket_cnt, p.bucket_cap, sd.flags, p.T, tau, p.scatter != 1 ? 1 : 0, p.map, k,
                      delta, out_val, out_idx, fail_rows, fail_count);
   HIP_CHECK(hipGetLastError());
 }

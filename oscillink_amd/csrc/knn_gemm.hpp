@@ -3,6 +3,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "knn.hpp"
 
 namespace osc {
 
@@ -52,11 +53,14 @@ struct KnnPanelPlan {
   // assemble the lists by all-reduce: osc_graph.hip); a sharded build with a full sweep per rank (OSC_KNN_PANEL_SYM=0) keeps
   // the identity, because its ranks own contiguous LATTICE row blocks.
   int32_t scatter;
+  // ... and the general form every kernel reads (knn.hpp: KnnRowMap): one piece with multiplier `scatter` as planned;
+  // knn_panel_set_pieces cuts the image into pieces that are permuted separately (the streamed create)
+  KnnRowMap map;
 };
 // image row -> lattice row of a plan (rows >= N are padding and map to themselves)
-inline int32_t knn_panel_row(const KnnPanelPlan& p, int32_t N, int32_t r) {
-  return r < N ? (int32_t)(((int64_t)r * p.scatter) % N) : r;
-}
+inline int32_t knn_panel_row(const KnnPanelPlan& p, int32_t N, int32_t r) { return r < N ? knn_map_lattice_row(p.map, N, r) : r; }
+// pieces starting at the given image rows, each holding ITS lattice rows (scattered within the piece iff the plan scatters)
+void knn_panel_set_pieces(KnnPanelPlan& p, int32_t N, const int32_t* starts, int npieces);
 // A/B overrides of the planner (OSC_KNN_PANEL_NRG / _RHO / _T / _RANK, read by the caller; 0 = the planner's own choice)
 struct KnnPanelTune {
   int nrg = 0;     // 1: one row group per wave also at K depth 6
@@ -75,23 +79,33 @@ struct KnnPanelSymDev {
   int32_t* flags;        // [S], zeroed by the caller
 };
 
-// fp32 unit rows -> fp16 image of 16 * Yn with pitch plan.ldh, rows [N, npad) zero
-void launch_panel_image(const float* Yn, int32_t ldn, void* Yh, const KnnPanelPlan& p, int32_t N, int32_t D, hipStream_t s);
+// fp32 unit rows -> fp16 image of 16 * Yn with pitch plan.ldh, rows [N, npad) zero; image rows [r0, r1) only (r1 < 0: npad)
+void launch_panel_image(const float* Yn, int32_t ldn, void* Yh, const KnnPanelPlan& p, int32_t N, int32_t D, hipStream_t s,
+                        int32_t r0 = 0, int32_t r1 = -1);
+// the streamed create's column sample: `rows` unit rows (pitch ldn), already in sample order -> the sample image
+void launch_panel_sample_rows(const float* Yn_rows, int32_t ldn, void* Ys, const KnnPanelPlan& p, int32_t rows, int32_t D, hipStream_t s);
+// which image row the sample's row t copies (launch_panel_sample)
+inline int32_t knn_panel_sample_row(const KnnPanelPlan& p, int32_t N, int32_t t) {
+  const int64_t m = (int64_t)p.sample_tiles * 128, src = (int64_t)t * N / m;
+  return (int32_t)(src < (int64_t)N - 1 ? src : (int64_t)N - 1);
+}
 // the column sample: row t of the sample image = row min(N - 1, t * stride) of the query image
 void launch_panel_sample(const void* Yh, void* Ys, const KnnPanelPlan& p, int32_t N, hipStream_t s);
 // phase A: per (query row, group of sample tiles) maximum fp16 score -> tmax [npad][sample_groups], for the query row
 // blocks [rb_begin, rb_begin + rb_count)
 void launch_panel_tilemax(const void* Yh, const void* Ys, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count,
                           float* tmax, unsigned* queue, int grid, hipStream_t s);
-// threshold per row = sample_rank-th largest of its tile maxima
-void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float* tau, hipStream_t s);
+// threshold per row = sample_rank-th largest of its tile maxima; image rows [r0, r1) only (r1 < 0: npad)
+void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float* tau, hipStream_t s, int32_t r0 = 0, int32_t r1 = -1);
 // phase B: every (row, column) with fp16 score > tau[row] (diagonal excluded) is appended to the hit list of its
 // (column split, row block, wave): hit_list [(list * 4 + wave) * hit_cap + e] = 8-byte entries {local row << 27 | column,
 // score bits}, hit_cnt [list * 4 + wave] (may exceed hit_cap: overflow); list = split * rb_count + (row block - rb_begin)
 // shards > 1 (half sweep of a sharded build): this call sweeps the work items shard, shard + shards, ... only
+// chunk_hi >= 0 (half sweep on the panel core): only the column chunks [chunk_lo, chunk_hi) -- what the streamed create
+// launches as the rows of those chunks arrive; `grid` is then capped by the items of the window
 void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int rb_begin, int rb_count, const float* tau,
                          void* hit_list, int32_t* hit_cnt, unsigned* queue, int grid, hipStream_t s,
-                         const KnnPanelSymDev* sd = nullptr, int shard = 0, int shards = 1);
+                         const KnnPanelSymDev* sd = nullptr, int shard = 0, int shards = 1, int chunk_lo = 0, int chunk_hi = -1);
 // sharded half sweep: min(cnt, cap) per bucket; a rank's buckets packed behind one another (off = exclusive scan of the
 // clamped counts); the other ranks' entries appended to the buckets [b0, b0 + nb_mine) (knn_gemm.hip: k_bucket_merge)
 void launch_bucket_clamp(const int32_t* cnt, int32_t nb, int32_t cap, int32_t* clamped, hipStream_t s);

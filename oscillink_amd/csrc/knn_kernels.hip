@@ -817,14 +817,14 @@ __global__ __launch_bounds__(256) void k_knn_rescore(const float* __restrict__ Y
                                                      int32_t row_begin, int32_t row_end, const int32_t* cidx,
                                                      const float* cval, int32_t KC, int32_t k, float delta,
                                                      float* out_val, int32_t* out_idx, int32_t* fail_rows,
-                                                     int32_t* fail_count, int32_t scatter) {
+                                                     int32_t* fail_count, int32_t mapped, KnnRowMap map) {
   constexpr int EU = 4;  // candidates in flight
   const int lane = threadIdx.x & 63;
-  // [row_begin, row_end) are rows of the prefilter IMAGE (KnnPanelPlan::scatter: image row r holds lattice row r * scatter
-  // mod N; 1 = identity): a rank of a sharded build re-scores the lattice rows of its image row blocks
+  // [row_begin, row_end) are rows of the prefilter IMAGE when `mapped` (KnnRowMap: which lattice row an image row holds):
+  // a rank of a sharded build re-scores the lattice rows of its image row blocks
   const int irow = row_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
   if (irow >= row_end) return;
-  const int row = scatter == 1 ? irow : (int)(((int64_t)irow * scatter) % N);
+  const int row = mapped ? knn_map_lattice_row(map, N, irow) : irow;
   const float* yi = Yn + (size_t)row * ldn;
   float4 yr[NCH > 0 ? NCH : 1];
   if constexpr (NCH > 0) {
@@ -1299,14 +1299,16 @@ void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* ca
 
 void launch_knn_rescore(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t D, int32_t N, const int32_t* cidx,
                         const float* cval, int32_t k, float delta, float* out_val, int32_t* out_idx, int32_t* fail_rows,
-                        int32_t* fail_count, hipStream_t s, int32_t scatter) {
+                        int32_t* fail_count, hipStream_t s, const KnnRowMap* map) {
   const int row_begin = p.rb_begin * BM, row_end = std::min(N, (p.rb_begin + p.rb_count) * BM);
+  const int32_t mapped = map != nullptr ? 1 : 0;
+  const KnnRowMap rm = map != nullptr ? *map : knn_row_map(N, nullptr, 1, false);
   if (row_end <= row_begin) return;
   const dim3 grid((unsigned)((row_end - row_begin + 3) / 4)), block(256);
   const int nch = (ldn + 255) / 256;
 #define OSC_RESCORE(NN)                                                                                              \
   hipLaunchKernelGGL(k_knn_rescore<NN>, grid, block, 0, s, Yn, ldn, D, N, row_begin, row_end, cidx, cval, p.keep, k, \
-                     delta, out_val, out_idx, fail_rows, fail_count, scatter)
+                     delta, out_val, out_idx, fail_rows, fail_count, mapped, rm)
   if (nch <= 1) OSC_RESCORE(1);
   else if (nch == 2) OSC_RESCORE(2);
   else if (nch == 3) OSC_RESCORE(3);

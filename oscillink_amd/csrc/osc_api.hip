@@ -59,6 +59,7 @@ void read_env_build(L& h) {
   if (num("OSC_KNN_SPLITS", v)) h.knn_splits = std::max(1, v);
   h.knn_scatter = !(num("OSC_KNN_PANEL_SCATTER", v) && v == 0);
   h.knn_sym = !(num("OSC_KNN_PANEL_SYM", v) && v == 0);
+  h.create_stream = !(num("OSC_CREATE_STREAM", v) && v == 0);
   h.knn_tune = KnnPanelTune{};
   if (num("OSC_KNN_PANEL_NRG", v)) h.knn_tune.nrg = v;
   if (const char* e = getenv("OSC_KNN_PANEL_RHO")) h.knn_tune.rho = atof(e);
@@ -203,17 +204,22 @@ int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, i
     }
     const size_t n = (size_t)N * h->ld;
     for (DevBuf<float>* b : {&h->Y, &h->U, &h->X, &h->R, &h->P, &h->AP, &h->Ustar}) b->alloc(n);
-    HIP_CHECK(hipMemsetAsync(h->Y.p, 0, n * 4, h->stream));
-    upload_rows(*h, h->Y.p, Y);
-    HIP_CHECK(hipMemcpyAsync(h->U.p, h->Y.p, n * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (h->ld != D) HIP_CHECK(hipMemsetAsync(h->Y.p, 0, n * 4, h->stream));  // (the padding columns; the anchors follow below)
     for (DevBuf<float>* b : {&h->X, &h->R, &h->P, &h->AP, &h->Ustar}) HIP_CHECK(hipMemsetAsync(b->p, 0, n * 4, h->stream));
     h->B.alloc((size_t)N);
     std::vector<float> ones((size_t)N, 1.0f);
     HIP_CHECK(hipMemcpyAsync(h->B.p, ones.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
     h->psi.alloc((size_t)h->ld);
     HIP_CHECK(hipMemsetAsync(h->psi.p, 0, (size_t)h->ld * 4, h->stream));
+    // The anchors' way to the device (Y, and U = Y: lattice.py:56-58).  With a build to follow it is the build's business:
+    // where it can it takes them piece by piece and works on what has arrived (osc_graph.hip: stream_pieces).
+    if (build) {
+      build_graph(*h, Y);
+    } else {
+      upload_rows(*h, h->Y.p, Y);
+      HIP_CHECK(hipMemcpyAsync(h->U.p, h->Y.p, n * 4, hipMemcpyDeviceToDevice, h->stream));
+    }
     sync(*h);
-    if (build) build_graph(*h);
   } catch (const Unsupported& e) {
     g_create_error = e.what();
     return OSC_E_UNSUPPORTED;
@@ -1196,6 +1202,11 @@ int osc_profile_reset(osc_handle h) {
 }
 int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* total_ms) {
   return guarded(h, [&](L& l) {
+    if (which == 15) {  // pieces the last build received its anchors in (0: they were on the device before it started)
+      if (launches) *launches = l.create_pieces;
+      if (total_ms) *total_ms = 0.0;
+      return;
+    }
     if (which == 14) {  // the kernel shape of the last blocked matvec
       if (launches) *launches = l.blk_shape_last;
       if (total_ms) *total_ms = 0.0;

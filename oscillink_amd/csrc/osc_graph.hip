@@ -281,13 +281,169 @@ void exchange_buckets(L& h, const KnnPanelPlan& pp, const KnnPanelSymDev& sd, in
   sync(h);  // the host vectors and the temporaries above are in use until here
 }
 
-void build_graph(L& h) {
+// The streamed create (osc_create -> build_graph(host_Y)).  In the reference's production shape -- one lattice per request,
+// cloud/app/main.py:887-947 -- the anchors' way over the bus (6 ms at config 3) used to precede a 14 ms build that needs,
+// for most of its work, only part of them: column chunk c of the half sweep reads the image rows below (c + 1) T 128.  So:
+//   * the anchors travel in `pieces` of whole column chunks on a second stream (pageable source: the call returns when the
+//     piece is on its way; an event per piece);
+//   * the column SAMPLE the thresholds come from -- sample row t = image row t N / m, lattice rows spread over the whole
+//     array -- is gathered on the host into pinned memory by a few threads while piece 0 travels, and follows it;
+//   * behind piece j the build stream runs: U's rows, unit rows, image rows (the piece's own permutation: KnnRowMap), the
+//     sample sweep and thresholds of the piece's row blocks, and the main sweep's work items of the piece's column chunks.
+// What is left when the last piece has landed is that piece's share of the sweep plus select / re-scoring / graph assembly.
+// The lists are those of the whole-array build bit for bit (they are exact top-k lists under one total order; thresholds
+// and candidate sets differ with the image's row order, as they do between scatter on and off).
+void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts, const KnnPanelPlan& pp, float* Yn, int32_t ldn, float* p_img,
+                   float* p_smp, float* p_tmax, float* p_tau, unsigned* p_queue, const KnnPanelSymDev& sym_dev, int cus, DevBuf<float>& smp_raw,
+                   DevBuf<float>& smp_n) {
+  const int32_t N = (int32_t)h.N, D = h.D;
+  const int pieces = (int)starts.size();
+  if (pieces < 1 || pieces > 16) throw std::runtime_error("streamed create: 1 to 16 pieces");  // (p_queue: four counters per piece)
+  auto row0 = [&](int j) { return j < pieces ? starts[(size_t)j] : N; };
+  const int32_t m_s = pp.sample_tiles * 128, chunk_rows = pp.T * 128;
+  const size_t row_bytes = (size_t)D * 4;
+  static const int threads = [] {
+    const char* e = getenv("OSC_COPY_THREADS");
+    const int hw = (int)std::thread::hardware_concurrency();
+    return e ? std::max(1, atoi(e)) : std::max(1, std::min(8, hw / 2));
+  }();
+  // Two build streams take the pieces in turn: a sweep launch is a persistent grid of one workgroup per CU, and on ONE stream
+  // piece j + 1's kernels would wait for the last straggler of piece j's sweep.
+  hipStream_t up = acquire_stream(h.device), second = acquire_stream(h.device);
+  hipStream_t cs[2] = {h.stream, second};
+  const StagePair sp = acquire_stage(h.device);
+  // events: [j] piece j has landed, [pieces + j] the thresholds of all rows up to piece j's are written, then: everything
+  // the caller queued before this call is done / the sample image is written / the second stream has drained
+  std::vector<hipEvent_t> ev((size_t)2 * pieces + 3, nullptr);
+  hipEvent_t &ev_start = ev[(size_t)2 * pieces], &ev_sample = ev[(size_t)2 * pieces + 1], &ev_done = ev[(size_t)2 * pieces + 2];
+  // The host side: a copy from pageable memory returns when the data has left, so the calling thread issues the transfers
+  // one by one and queues a piece's kernels behind each; a few threads gather the sample's rows into pinned memory
+  // meanwhile (started first: the sample is what the first threshold waits for), and the sample follows the second piece.
+  // (Issuing the transfers from a thread of their own closed the 0.08 ms gaps between them and cost 0.4 ms at the start --
+  // a new thread's first HIP call -- for a build that is bound by the kernels from the third piece on: not kept.)
+  std::vector<std::thread> workers;
+  auto cleanup = [&](bool wait) {
+    for (auto& t : workers)
+      if (t.joinable()) t.join();
+    if (wait) {
+      (void)hipStreamSynchronize(up);
+      (void)hipStreamSynchronize(second);
+      (void)hipStreamSynchronize(h.stream);
+    }
+    for (auto e : ev)
+      if (e) (void)hipEventDestroy(e);
+    release_stage(h.device, sp);
+    release_stream(h.device, up);
+    release_stream(h.device, second);
+  };
+  try {
+    float* pinned = static_cast<float*>(sp.buf[0]);
+    const int nthr = std::max(1, std::min(threads, 8));
+    for (int t = 0; t < nthr; ++t)
+      workers.emplace_back([=, &pp] {
+        for (int32_t r = (int32_t)((int64_t)m_s * t / nthr); r < (int32_t)((int64_t)m_s * (t + 1) / nthr); ++r) {
+          const int32_t irow = knn_panel_sample_row(pp, N, r);
+          const int32_t row = pp.scatter != 1 ? knn_map_lattice_row(pp.map, N, irow) : irow;
+          std::memcpy(pinned + (size_t)r * D, host_Y + (size_t)row * D, row_bytes);
+        }
+      });
+    for (auto& e : ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ev_start, h.stream));
+    HIP_CHECK(hipStreamWaitEvent(second, ev_start, 0));
+    auto send_piece = [&](int j) {
+      const int32_t r0 = row0(j), r1 = row0(j + 1);
+      HIP_CHECK(hipMemcpyAsync(h.Y.p + (size_t)r0 * h.ld, host_Y + (size_t)r0 * D, (size_t)(r1 - r0) * row_bytes, hipMemcpyHostToDevice, up));
+      HIP_CHECK(hipEventRecord(ev[(size_t)j], up));
+    };
+    // behind piece j's arrival: U's rows, unit rows, image rows
+    auto queue_rows = [&](int j) {
+      hipStream_t s = cs[j & 1];
+      const int32_t r0 = row0(j), r1 = row0(j + 1);
+      HIP_CHECK(hipStreamWaitEvent(s, ev[(size_t)j], 0));
+      HIP_CHECK(hipMemcpyAsync(h.U.p + (size_t)r0 * h.ld, h.Y.p + (size_t)r0 * h.ld, (size_t)(r1 - r0) * h.ld * 4, hipMemcpyDeviceToDevice, s));
+      launch_normalize_rows(h.Y.p + (size_t)r0 * h.ld, h.ld, Yn + (size_t)r0 * ldn, ldn, r1 - r0, D, s);
+      launch_panel_image(Yn, ldn, p_img, pp, N, D, s, r0, j + 1 == pieces ? pp.npad : r1);
+    };
+    // ... and, once the sample image exists: the thresholds of the piece's row blocks and the sweep of its column chunks
+    auto queue_sweep = [&](int j) {
+      hipStream_t s = cs[j & 1];
+      unsigned* q = p_queue + 4 * j;
+      const int32_t r0 = row0(j), r1 = row0(j + 1);
+      const bool last = j + 1 == pieces;
+      if (j & 1) HIP_CHECK(hipStreamWaitEvent(s, ev_sample, 0));  // (the sample image was written on the first stream)
+      const int rb0 = r0 / 128, rb1 = last ? pp.nrb : r1 / 128;
+      KnnPanelPlan pj = pp;  // (splits of the sample sweep chosen for THIS many row blocks)
+      const int nsets = (rb1 - rb0 + pp.nrg - 1) / pp.nrg;
+      double best = 1e30;
+      for (int S = 1; S <= 6 && S <= pp.sample_groups; ++S) {
+        const double rounds = (double)nsets * S / std::max(1, cus);
+        const double cost = std::ceil(rounds) / rounds * (1.0 + 0.03 * S);
+        if (cost < best - 1e-9) {
+          best = cost;
+          pj.SA = S;
+        }
+      }
+      pj.sample_tiles_per_split = ((pp.sample_groups + pj.SA - 1) / pj.SA) * pp.group_tiles;
+      launch_panel_tilemax(p_img, p_smp, pj, N, rb0, rb1 - rb0, p_tmax, q, std::max(1, std::min(cus, nsets * pj.SA)), s);
+      launch_panel_tau(p_tmax, pp, N, p_tau, s, rb0 * 128, rb1 * 128);
+      // (the sweep reads the image rows and thresholds of ALL pieces up to this one: the other stream wrote piece j - 1's)
+      if (j > 0) HIP_CHECK(hipStreamWaitEvent(s, ev[(size_t)pieces + j - 1], 0));
+      HIP_CHECK(hipEventRecord(ev[(size_t)pieces + j], s));
+      const int c0 = r0 / chunk_rows, c1 = last ? pp.S : r1 / chunk_rows;
+      if (c1 > c0)
+        launch_panel_filter(p_img, pp, N, 0, pp.nrb, p_tau, sym_dev.bucket_ent, sym_dev.bucket_cnt, q + 1, cus, s, &sym_dev, 0, 1, c0, c1);
+    };
+    const int lead = 1;  // pieces that travel while the sample is being gathered (25 MB in ~0.5 ms: one piece's time on the bus)
+    for (int j = 0; j < lead; ++j) {
+      send_piece(j);
+      queue_rows(j);
+    }
+    smp_raw.alloc((size_t)m_s * D);
+    smp_n.alloc((size_t)m_s * ldn);
+    for (auto& t : workers) t.join();
+    workers.clear();
+    HIP_CHECK(hipMemcpyAsync(smp_raw.p, pinned, (size_t)m_s * row_bytes, hipMemcpyHostToDevice, up));
+    HIP_CHECK(hipEventRecord(sp.ev[0], up));
+    HIP_CHECK(hipStreamWaitEvent(h.stream, sp.ev[0], 0));  // the sample image: unit rows of the gathered anchors, in sample order
+    launch_normalize_rows(smp_raw.p, D, smp_n.p, ldn, m_s, D, h.stream);
+    launch_panel_sample_rows(smp_n.p, ldn, p_smp, pp, m_s, D, h.stream);
+    HIP_CHECK(hipEventRecord(ev_sample, h.stream));
+    for (int j = 0; j < lead; ++j) queue_sweep(j);
+    for (int j = lead; j < pieces; ++j) {
+      send_piece(j);
+      queue_rows(j);
+      queue_sweep(j);
+    }
+    HIP_CHECK(hipEventRecord(ev_done, second));
+    HIP_CHECK(hipStreamWaitEvent(h.stream, ev_done, 0));
+    HIP_CHECK(hipStreamSynchronize(up));  // (the caller's array is free again; the pinned buffer and the events go back)
+    HIP_CHECK(hipStreamSynchronize(second));
+  } catch (...) {
+    cleanup(true);
+    throw;
+  }
+  cleanup(false);
+  h.create_pieces = pieces;
+}
+
+// host_Y (osc_create only): the caller's anchors, not on the device yet -- the build brings them there, either whole before
+// anything else or, where the half sweep on the panel core builds the lists (one process, D <= 768), piece by piece on a
+// second stream while the kernels work on the pieces that have arrived (stream_pieces below).
+void build_graph(L& h, const float* host_Y) {
   const double t0 = now_ms();
+  h.create_pieces = 0;
+  auto upload_all = [&] {
+    if (host_Y == nullptr) return;
+    upload_rows(h, h.Y.p, host_Y);
+    HIP_CHECK(hipMemcpyAsync(h.U.p, h.Y.p, (size_t)h.N * h.ld * 4, hipMemcpyDeviceToDevice, h.stream));
+    host_Y = nullptr;
+  };
   drop_order(h);  // the build works on the API's row order
   const int32_t N = (int32_t)h.N;
   h.k_eff = std::min<int32_t>(h.k_eff, std::max<int32_t>(1, N - 1));  // lattice.py:60
   h.have_ustar = false;
   if (N <= 1) {  // graph.py:30-32
+    upload_all();
     alloc_ell(h, 1);
     const float one_em6 = 1e-6f;  // sqrt(max(0, 1e-12))
     std::vector<float> sd((size_t)h.N, one_em6);
@@ -307,7 +463,6 @@ void build_graph(L& h) {
   const int32_t ldn = ((h.D + 31) / 32) * 32;
   DevBuf<float> Yn;
   Yn.alloc((size_t)h.N * ldn);
-  launch_normalize_rows(h.Y.p, h.ld, Yn.p, ldn, h.N, h.D, h.stream);
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, h.device));
   const int slots = prop.multiProcessorCount * (k <= 64 ? 2 : 1);
@@ -380,6 +535,8 @@ void build_graph(L& h) {
   DevBuf<int32_t> p_hcnt;
   DevBuf<unsigned> p_queue;
   KnnPanelSymDev sym_dev{};
+  std::vector<int32_t> piece_starts;  // not empty: the streamed create (below); first image row of each piece
+  DevBuf<float> smp_raw, smp_n;  // ... its column sample: anchors as gathered, unit rows
   if (panel) {
     // (image rows scattered over the lattice rows in single-process builds: knn_gemm.hpp, KnnPanelPlan::scatter)
     // single-process builds sweep only the column tiles J >= I of every row block (knn_gemm.hip: symmetric half sweep);
@@ -393,9 +550,34 @@ void build_graph(L& h) {
     p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
     p_tmax.alloc((size_t)pp.npad * pp.sample_groups);
     p_tau.alloc(std::max((size_t)pp.npad, (size_t)rb_per * 128 * parts));  // (whole equal chunks for the all-gather of a sharded half sweep)
-    p_queue.alloc(1);
-    launch_panel_image(Yn.p, ldn, p_img.p, pp, N, h.D, h.stream);
-    launch_panel_sample(p_img.p, p_smp.p, pp, N, h.stream);
+    p_queue.alloc(64);  // (one counter per launch in flight: the streamed create runs consecutive pieces on two streams)
+    // Anchors still on the host (osc_create) and the half sweep on the panel core ahead: cut the image into equal pieces of
+    // whole column chunks, >= 24 MB of anchors each and at most 16 of them, each permuted within itself
+    // (knn_panel_set_pieces) -- the sweep's chunk c needs the image rows below (c + 1) T 128 and nothing else, i.e. the
+    // pieces up to its own.  (Schedules tried at config 3 / 200k x 384 clustered, create in ms: 11 equal pieces 16.5 / 28.6;
+    // 1, 1, 2, 2, 3, 4, 6, 8 chunks 16.7 / 30.3 -- the kernels run dry while the last large pieces travel --; 1, 1, 2, 2 then
+    // threes 16.7 / 32.3 -- sixteen short sample sweeps fill the CUs badly.  From the third piece on the kernels are the
+    // slower side, so nothing is gained by small first pieces either.)
+    if (host_Y != nullptr && h.create_stream && parts == 1 && h.comm == nullptr && pp.sym && !pp.tile_core && h.ld == h.D) {
+      const int64_t row_bytes = (int64_t)h.D * 4, chunk_rows = (int64_t)pp.T * 128;
+      const int64_t smp_bytes = (int64_t)pp.sample_tiles * 128 * row_bytes;
+      int64_t m = std::max<int64_t>(1, (((int64_t)24 << 20) / row_bytes + chunk_rows - 1) / chunk_rows);
+      m = std::max<int64_t>(m, (pp.S + 15) / 16);
+      const int64_t rows = m * chunk_rows, pieces = (N + rows - 1) / rows;
+      if (pieces >= 3 && (int64_t)N * row_bytes >= ((int64_t)64 << 20) && smp_bytes <= (int64_t)kStageBytes) {
+        for (int64_t j = 0; j < pieces; ++j) piece_starts.push_back((int32_t)(j * rows));
+        knn_panel_set_pieces(pp, N, piece_starts.data(), (int)piece_starts.size());
+      }
+    }
+  }
+  const bool streamed = !piece_starts.empty();
+  if (!streamed) {
+    upload_all();
+    launch_normalize_rows(h.Y.p, h.ld, Yn.p, ldn, h.N, h.D, h.stream);
+    if (panel) {
+      launch_panel_image(Yn.p, ldn, p_img.p, pp, N, h.D, h.stream);
+      launch_panel_sample(p_img.p, p_smp.p, pp, N, h.stream);
+    }
   }
   if (prefilter) {
     if (!panel) {
@@ -465,7 +647,19 @@ void build_graph(L& h) {
       const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true, h.knn_splits);  // row range + keep for the re-scoring
       const int nsets = (rb_count + pp.nrg - 1) / pp.nrg;  // work items per column split (knn_gemm.hip)
       const int grid = std::max(1, std::min(prop.multiProcessorCount, nsets * pp.S));
-      if (!sym_sharded) {  // (a sharded half sweep has its thresholds and buckets already: above)
+      if (streamed) {
+        ProfScope ps(h, 3);
+        const size_t nb = (size_t)pp.npad / 32;
+        p_hits.alloc(nb * pp.bucket_cap);
+        p_hcnt.alloc(nb + (size_t)pp.S);
+        HIP_CHECK(hipMemsetAsync(p_hcnt.p, 0, (nb + (size_t)pp.S) * 4, h.stream));
+        sym_dev.bucket_ent = p_hits.p;
+        sym_dev.bucket_cnt = p_hcnt.p;
+        sym_dev.flags = p_hcnt.p + nb;
+        stream_pieces(h, host_Y, piece_starts, pp, Yn.p, ldn, p_img.p, p_smp.p, p_tmax.p, p_tau.p, p_queue.p, sym_dev, prop.multiProcessorCount,
+                      smp_raw, smp_n);
+        host_Y = nullptr;
+      } else if (!sym_sharded) {  // (a sharded half sweep has its thresholds and buckets already: above)
         ProfScope ps(h, 3);
         launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
                              std::max(1, std::min(prop.multiProcessorCount, nsets * pp.SA)), h.stream);
@@ -489,7 +683,7 @@ void build_graph(L& h) {
       launch_panel_select(pp, rb_begin, rb_count, N, p_hits.p, p_hcnt.p, cval.p, cidx.p, fail_rows.p, fail_count.p,
                           h.stream, pp.sym ? &sym_dev : nullptr);
       launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
-                         fail_count.p, h.stream, pp.scatter);
+                         fail_count.p, h.stream, pp.scatter != 1 ? &pp.map : nullptr);
     } else if (prefilter) {
       const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true, h.knn_splits);
       const size_t ncand = (size_t)h.N * plan.S * plan.KC;

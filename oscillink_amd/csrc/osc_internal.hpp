@@ -7,12 +7,14 @@
 //   osc_api.hip     : environment switches and the extern "C" entry points of include/oscillink_hip.h
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -135,6 +137,8 @@ struct osc_lattice {
   int knn_splits = 0;          // OSC_KNN_SPLITS (tile / exact routes: column splits)
   bool knn_scatter = true;     // OSC_KNN_PANEL_SCATTER
   bool knn_sym = true;         // OSC_KNN_PANEL_SYM
+  bool create_stream = true;   // OSC_CREATE_STREAM: osc_create hands the anchors to the build piece by piece (osc_graph.hip)
+  int32_t create_pieces = 0;   // pieces the last build received its anchors in (0: they were on the device before it started)
   bool knn_force_exchange = false;  // OSC_KNN_FORCE_EXCHANGE=1 (test hook): run the sharded half sweep's collectives under a ONE-rank communicator too
   KnnPanelTune knn_tune{};     // OSC_KNN_PANEL_NRG / _RHO / _T / _RANK
   int halo_force = 0;          // OSC_HALO: 1 full, 2 lists
@@ -224,6 +228,7 @@ struct osc_lattice {
 
 using L = osc_lattice;
 
+constexpr size_t kStageBytes = (size_t)32 << 20;  // one pinned staging buffer (two per StagePair)
 struct StagePair {
   void* buf[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -288,7 +293,7 @@ void apply_order(L& l, const std::vector<int32_t>& perm);
 std::vector<int32_t> bfs_order(L& l);
 void maybe_reorder(L& l);
 void exchange_buckets(L& h, const KnnPanelPlan& pp, const KnnPanelSymDev& sd, int rb_per);
-void build_graph(L& h);
+void build_graph(L& h, const float* host_Y = nullptr);
 bool path_active(const L& h);
 OpParams settle_op(const L& h, float dt, int precond);
 OpParams ustar_op(const L& h);

@@ -193,7 +193,6 @@ void upload_rows(L& h, float* dst, const float* src) {  // N x D host -> N x ld 
 // device (parked like the streams; 2 x 32 MiB) take the DMA at PCIe rate while a few host threads copy the previous chunk
 // into the caller's array -- whose pages are usually untouched, so the copy is also what faults them in, and that is what
 // the threads are for.  OSC_PINNED_DL=0 keeps the plain copy.
-constexpr size_t kStageBytes = (size_t)32 << 20;
 std::map<int, std::vector<StagePair>> g_stage_pool;  // guarded by g_pool_mu
 
 StagePair acquire_stage(int device) {

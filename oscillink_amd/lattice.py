@@ -230,12 +230,14 @@ class OscillinkLattice:
         self._call("osc_spmm_plan", C.byref(ln), C.byref(sc), C.byref(xw))
         sb, ba = C.c_int32(0), C.c_int64(0)
         self._call("osc_apply_info", C.byref(sb), C.byref(ba))
-        shape, unused = C.c_int64(0), C.c_double(0.0)
+        shape, pieces, unused = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
         self._call("osc_profile_get", 14, C.byref(shape), C.byref(unused))
+        self._call("osc_profile_get", 15, C.byref(pieces), C.byref(unused))
         return {"prefilter": int(pf.value), "fallback_rows": int(fb.value), "small_solves": int(ss.value),
                 "reordered": int(ro.value), "clustering": float(cc.value), "apply_launches": int(ln.value),
                 "apply_slab_cols": int(sc.value), "apply_xs_workgroups": int(xw.value),
-                "apply_src_blocks": int(sb.value), "blocked_applies": int(ba.value), "apply_blocked_shape": int(shape.value)}
+                "apply_src_blocks": int(sb.value), "blocked_applies": int(ba.value), "apply_blocked_shape": int(shape.value),
+                "create_pieces": int(pieces.value)}
 
     def halo_info(self) -> dict[str, int]:
         """Row-sharded runs (OSC_SHARD=row under a communicator): the rows of the search direction this rank receives

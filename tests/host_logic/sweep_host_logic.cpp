@@ -10,6 +10,7 @@
 #include <set>
 
 #include "../../oscillink_amd/csrc/host_logic.hpp"
+#include "../../oscillink_amd/csrc/knn_rowmap.hpp"
 
 using namespace osc::host;
 
@@ -72,6 +73,51 @@ static Graph random_graph(int64_t N, int k, std::mt19937_64& rng, bool local) {
     g.rowptr[(size_t)i + 1] = (int64_t)g.ccol.size();
   }
   return g;
+}
+
+// the prefilter image's row order (knn_rowmap.hpp): every piece a bijection of ITS rows, the two directions inverse to each
+// other, consecutive image rows of a scattered piece far apart, bad piece tables refused
+static void check_row_map(int32_t N, std::mt19937_64& rng) {
+  for (int pieces : {1, 2, 3, 11, 24}) {
+    if (pieces > N) continue;
+    for (int scatter = 0; scatter < 2; ++scatter) {
+      std::vector<int32_t> starts;
+      if (pieces == 1 || (rng() & 1)) {  // equal pieces (the streamed create's) ...
+        const int32_t rows = (N + pieces - 1) / pieces;
+        for (int32_t r = 0; r < N; r += std::max(1, rows)) starts.push_back(r);
+      } else {  // ... or any ascending table
+        std::set<int32_t> cut{0};
+        while ((int)cut.size() < pieces) cut.insert((int32_t)(rng() % (uint64_t)N));
+        starts.assign(cut.begin(), cut.end());
+      }
+      const osc::KnnRowMap m = osc::knn_row_map(N, starts.data(), (int)starts.size(), scatter != 0);
+      std::vector<char> seen((size_t)N, 0);
+      for (int32_t r = 0; r < N; ++r) {
+        const int32_t row = osc::knn_map_lattice_row(m, N, r);
+        const int j = osc::knn_map_piece(m, r);
+        CHECK(row >= m.start[j] && row < m.start[j + 1], "N %d image row %d leaves its piece", N, r);
+        CHECK(row >= 0 && row < N && !seen[(size_t)row], "N %d image row %d -> lattice row %d twice or out of range", N, r, row);
+        if (row >= 0 && row < N) seen[(size_t)row] = 1;
+        CHECK(osc::knn_map_image_row(m, N, row) == r, "N %d: the inverse of image row %d", N, r);
+        if (!scatter) CHECK(row == r, "N %d: identity map moves row %d", N, r);
+      }
+      for (int j = 0; j < m.npieces && scatter; ++j) {
+        const int32_t n = m.start[j + 1] - m.start[j];
+        if (n >= 64) {  // neighbours in the image are far apart in the lattice
+          const int32_t d = std::abs(osc::knn_map_lattice_row(m, N, m.start[j] + 1) - osc::knn_map_lattice_row(m, N, m.start[j]));
+          CHECK(std::min(d, n - d) >= n / 4, "N %d piece %d: stride %d of %d", N, j, d, n);
+        }
+      }
+    }
+  }
+  bool threw = false;
+  try {
+    const int32_t bad[2] = {0, N};
+    (void)osc::knn_row_map(N, bad, 2, true);
+  } catch (const std::invalid_argument&) {
+    threw = true;
+  }
+  CHECK(threw, "N %d: a piece starting at N accepted", N);
 }
 
 static void check_partitions(int64_t N, int32_t dcols) {
@@ -295,6 +341,7 @@ int main(int argc, char** argv) {
   for (int64_t N : ns) {
     for (int32_t dcols : {4, 8, 52, 96, 128, 768, 1000, 1536}) check_partitions(N, dcols);
     check_blocked(N, rng);
+    if (N >= 2) check_row_map((int32_t)N, rng);
     if (N > 20000) continue;  // graph-building checks: small and mid sizes (seconds under ASan)
     for (int k : {1, 3, 6, 16, 33, 64}) {
       if (N > 3000 && k != 6 && k != 33) continue;
