@@ -310,7 +310,7 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
   // Two build streams take the pieces in turn: a sweep launch is a persistent grid of one workgroup per CU, and on ONE stream
   // piece j + 1's kernels would wait for the last straggler of piece j's sweep.
   hipStream_t up = acquire_stream(h.device), second = acquire_stream(h.device);
-  hipStream_t cs[2] = {h.stream, second};
+  hipStream_t cs[2] = {h.stream, getenv("OSC_CREATE_ONE_STREAM") ? h.stream : second};
   const StagePair sp = acquire_stage(h.device);
   // events: [j] piece j has landed, [pieces + j] the thresholds of all rows up to piece j's are written, then: everything
   // the caller queued before this call is done / the sample image is written / the second stream has drained
@@ -339,11 +339,32 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
   try {
     float* pinned = static_cast<float*>(sp.buf[0]);
     const int nthr = std::max(1, std::min(threads, 8));
+    // WHICH rows the sample holds and in which ORDER matters: a row's threshold is the r-th largest of its maxima over GROUPS
+    // of consecutive sample rows, which estimates the r-th best sample score only if the row's good sample columns -- for
+    // anchors that arrive cluster by cluster: its cluster mates -- fall into at least r different groups.  The whole-array
+    // build samples every rho-th IMAGE row, and its global golden-ratio scatter spreads a cluster's mates evenly over the
+    // image.  With pieces permuted separately that no longer holds (a piece's sample rows are neighbours in image order;
+    // dealing them to the groups by a second multiplicative permutation, or in turn, cured one soak case and failed the
+    // next: 60 000 x 768 k 8 clusters of 300, 217 317 x 96 k 5 clusters of 479, 543 744 x 128 k 62 clusters of 401 -- the
+    // count of DISTINCT groups a cluster's ~17 sampled mates reach was left to chance).  The host gathers the sample anyway,
+    // so here it is defined in LATTICE order: sample t = lattice row floor(t N / m), an even stride whatever the anchors'
+    // order, dealt to the groups in turn (t -> group t mod G): a cluster's mates are consecutive t, hence consecutive groups.
+    std::vector<int32_t> order((size_t)m_s);
+    {
+      const int32_t gsz = pp.group_tiles * 128, G = pp.sample_groups;
+      std::vector<int32_t> fill((size_t)G, 0);
+      int g = 0;
+      for (int32_t t = 0; t < m_s; ++t) {
+        while (fill[(size_t)g] >= std::min(gsz, m_s - g * gsz)) g = (g + 1) % G;  // (the last group may be shorter)
+        order[(size_t)g * gsz + fill[(size_t)g]++] = t;
+        g = (g + 1) % G;
+      }
+    }
+    const int32_t* const order_p = order.data();
     for (int t = 0; t < nthr; ++t)
-      workers.emplace_back([=, &pp] {
+      workers.emplace_back([=] {
         for (int32_t r = (int32_t)((int64_t)m_s * t / nthr); r < (int32_t)((int64_t)m_s * (t + 1) / nthr); ++r) {
-          const int32_t irow = knn_panel_sample_row(pp, N, r);
-          const int32_t row = pp.scatter != 1 ? knn_map_lattice_row(pp.map, N, irow) : irow;
+          const int64_t row = std::min<int64_t>((int64_t)N - 1, (int64_t)order_p[r] * N / m_s);
           std::memcpy(pinned + (size_t)r * D, host_Y + (size_t)row * D, row_bytes);
         }
       });
@@ -429,7 +450,23 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
 // host_Y (osc_create only): the caller's anchors, not on the device yet -- the build brings them there, either whole before
 // anything else or, where the half sweep on the panel core builds the lists (one process, D <= 768), piece by piece on a
 // second stream while the kernels work on the pieces that have arrived (stream_pieces below).
+static bool build_graph_once(L& h, const float* host_Y);
 void build_graph(L& h, const float* host_Y) {
+  const double t0 = now_ms();
+  if (!build_graph_once(h, host_Y)) {
+    // A streamed build that lost more than a few rows to overflowing lists (anchors grouped in runs longer than a piece's
+    // scatter can spread: the rows' chunks are flagged and would go to the all-fp32 kernel, seconds at config 3's size):
+    // the anchors are resident now, so the whole-array build -- whose scatter spreads a group over the whole image -- runs
+    // instead, for one more prefilter pass (14 ms at config 3).
+    const int32_t pieces = h.create_pieces;
+    if (!build_graph_once(h, nullptr)) throw std::runtime_error("build_graph: the whole-array build asked for a retry");
+    h.create_pieces = -pieces;
+  }
+  h.build_ms = now_ms() - t0;
+}
+
+// false: a streamed build gave up before its exact-kernel fallback (see build_graph); Y and U are on the device then
+static bool build_graph_once(L& h, const float* host_Y) {
   const double t0 = now_ms();
   h.create_pieces = 0;
   auto upload_all = [&] {
@@ -454,7 +491,7 @@ void build_graph(L& h, const float* host_Y) {
     h.nnz = 0;
     h.max_deg = 0;
     h.build_ms = now_ms() - t0;
-    return;
+    return true;
   }
   const int32_t k = h.k_eff;
   // k <= 128: register-resident streaming lists (exact / prefilter / small-dense routes below).  Larger k (the
@@ -561,9 +598,18 @@ void build_graph(L& h, const float* host_Y) {
     if (host_Y != nullptr && h.create_stream && parts == 1 && h.comm == nullptr && pp.sym && !pp.tile_core && h.ld == h.D) {
       const int64_t row_bytes = (int64_t)h.D * 4, chunk_rows = (int64_t)pp.T * 128;
       const int64_t smp_bytes = (int64_t)pp.sample_tiles * 128 * row_bytes;
-      int64_t m = std::max<int64_t>(1, (((int64_t)24 << 20) / row_bytes + chunk_rows - 1) / chunk_rows);
+      int64_t m = std::max<int64_t>(1, (((int64_t)h.create_piece_mb << 20) / row_bytes + chunk_rows - 1) / chunk_rows);
       m = std::max<int64_t>(m, (pp.S + 15) / 16);
-      const int64_t rows = m * chunk_rows, pieces = (N + rows - 1) / rows;
+      // A piece's rows are permuted among themselves only, so the hits of anchors that arrive group by group -- up to the
+      // threshold's bound per row, all of them inside the row's own piece -- spread over the piece's column tiles and no
+      // further; a wave's hit list takes 260 / NRG coarse entries from ONE tile (knn_gemm.hip: HB_CAP_SYM), i.e. 32 rows x
+      // bound / tiles must stay below that: pieces of >= 32 x bound rows leave a factor of two.  (An explicit
+      // OSC_CREATE_PIECE_MB overrides this: tests of the retry below.)
+      if (!h.create_piece_mb_set) m = std::max<int64_t>(m, ((int64_t)(32.0 * pp.hit_bound) * pp.nrg + chunk_rows - 1) / chunk_rows);
+      // (what is left over joins the last piece: a piece's rows are permuted among themselves only, so a short piece of
+      // anchors that arrive cluster by cluster packs each cluster into few tiles -- 3072 rows holding 7.7 clusters of 401 gave
+      // every row 17 cluster mates per column tile, more than a wave's hit list takes from one tile)
+      const int64_t rows = m * chunk_rows, pieces = N / rows;
       if (pieces >= 3 && (int64_t)N * row_bytes >= ((int64_t)64 << 20) && smp_bytes <= (int64_t)kStageBytes) {
         for (int64_t j = 0; j < pieces; ++j) piece_starts.push_back((int32_t)(j * rows));
         knn_panel_set_pieces(pp, N, piece_starts.data(), (int)piece_starts.size());
@@ -680,10 +726,45 @@ void build_graph(L& h, const float* host_Y) {
           launch_panel_filter(p_img.p, pp, N, rb_begin, rb_count, p_tau.p, p_hits.p, p_hcnt.p, p_queue.p, grid, h.stream);
         }
       }
+      static const bool knn_debug = getenv("OSC_KNN_DEBUG") != nullptr;  // diagnostic: where the prefilter loses rows
+      auto failed_so_far = [&] {
+        int32_t n = 0;
+        HIP_CHECK(hipMemcpyAsync(&n, fail_count.p, 4, hipMemcpyDeviceToHost, h.stream));
+        sync(h);
+        return n;
+      };
+      if (knn_debug && pp.sym) {
+        const size_t nb = (size_t)pp.npad / 32;
+        std::vector<int32_t> cnt(nb + (size_t)pp.S);
+        std::vector<float> tau((size_t)pp.npad);
+        HIP_CHECK(hipMemcpyAsync(cnt.data(), p_hcnt.p, cnt.size() * 4, hipMemcpyDeviceToHost, h.stream));
+        HIP_CHECK(hipMemcpyAsync(tau.data(), p_tau.p, tau.size() * 4, hipMemcpyDeviceToHost, h.stream));
+        sync(h);
+        int64_t sum = 0, over = 0, flagged = 0;
+        int32_t mx = 0;
+        int64_t first_over = -1, first_flag = -1;
+        for (size_t b = 0; b < nb; ++b) {
+          sum += cnt[b], mx = std::max(mx, cnt[b]), over += cnt[b] > pp.bucket_cap;
+          if (cnt[b] > pp.bucket_cap && first_over < 0) first_over = (int64_t)b;
+        }
+        for (int c = 0; c < pp.S; ++c) {
+          flagged += cnt[nb + (size_t)c] != 0;
+          if (cnt[nb + (size_t)c] != 0 && first_flag < 0) first_flag = c;
+        }
+        if (over || flagged) fprintf(stderr, "[knn] first bucket over: %lld (rows from %lld), first chunk flagged: %lld\n", (long long)first_over, (long long)first_over * 32, (long long)first_flag);
+        double tsum = 0.0;
+        float tmin = 3e38f, tmax = -3e38f;
+        for (int32_t r = 0; r < N; ++r) tsum += tau[(size_t)r], tmin = std::min(tmin, tau[(size_t)r]), tmax = std::max(tmax, tau[(size_t)r]);
+        fprintf(stderr, "[knn] pieces %d: buckets %zu, entries per 32 rows mean %.0f max %d (cap %d), %lld buckets over, %lld of %d chunks flagged; tau / 256: mean %.4f min %.4f max %.4f; hit bound %.0f keep %d\n",
+                pp.map.npieces, nb, (double)sum / (double)nb, mx, pp.bucket_cap, (long long)over, (long long)flagged, pp.S, tsum / N / 256.0,
+                tmin / 256.0, tmax / 256.0, pp.hit_bound, pp.keep);
+      }
       launch_panel_select(pp, rb_begin, rb_count, N, p_hits.p, p_hcnt.p, cval.p, cidx.p, fail_rows.p, fail_count.p,
                           h.stream, pp.sym ? &sym_dev : nullptr);
+      if (knn_debug) fprintf(stderr, "[knn] after the select: %d rows without a candidate list\n", failed_so_far());
       launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
                          fail_count.p, h.stream, pp.scatter != 1 ? &pp.map : nullptr);
+      if (knn_debug) fprintf(stderr, "[knn] after the re-scoring: %d rows unproven\n", failed_so_far());
     } else if (prefilter) {
       const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true, h.knn_splits);
       const size_t ncand = (size_t)h.N * plan.S * plan.KC;
@@ -734,6 +815,8 @@ void build_graph(L& h, const float* host_Y) {
       fail_list = fail_rows2.p;
     }
     h.knn_fallback_rows = nfail;
+    // (OSC_CREATE_FORCE_RETRY: test hook -- every streamed build gives up here)
+    if (streamed && (nfail > std::max(64, N / 256) || h.create_force_retry)) return false;
     bool few_done = false;
     if (nfail > 0 && nfail <= 32) {  // a handful of rows: stream the columns once, select per row (0.15 vs 3.9 ms at N = 100k)
       const int32_t ldS = ((N + 31) / 32) * 32;
@@ -774,5 +857,6 @@ void build_graph(L& h, const float* host_Y) {
   h.have_graph = true;
   maybe_reorder(h);
   h.build_ms = now_ms() - t0;
+  return true;
 }
 

@@ -17,7 +17,9 @@ def _anchors(N, D, kind, seed=0):
     rng = np.random.default_rng(seed)
     if kind == "iid":
         return rng.standard_normal((N, D), dtype=np.float32)
-    csize = 100  # clusters of 100 rows IN cluster order: what the image's row scatter exists for (knn_gemm.hpp)
+    # clusters IN cluster order: what the image's row scatter exists for (knn_gemm.hpp); "grouped300": clusters of 300 rows --
+    # more sampled cluster mates than the threshold's rank, the case that needs the sample rows dealt over all groups
+    csize = 300 if kind == "grouped300" else 100
     centers = rng.standard_normal((max(1, N // csize), D)).astype(np.float32)
     return (centers[np.arange(N) // csize % centers.shape[0]] + 0.35 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
 
@@ -46,9 +48,9 @@ def _snapshot(lat, psi):
 
 
 # N, D, k, anchors: >= 64 MB of anchors in >= 3 pieces; K depth 12 and 6 (two row groups per wave), ragged last pieces, a last
-# column chunk of 64 rows (40 000 = 13 chunks of 3072 rows + 64), a lattice that is a whole number of chunks (61 440)
-SHAPES = [(40000, 512, 16, "iid"), (30000, 768, 32, "clustered"), (50000, 384, 12, "iid"), (61440, 320, 8, "clustered"),
-          (100000, 768, 32, "iid")]
+# column chunk of 64 rows (40 000 = 13 chunks of 3072 rows + 64), a lattice that is a whole number of chunks and of pieces (64 512 = 21 x 3072)
+SHAPES = [(40000, 512, 16, "iid"), (30000, 768, 32, "clustered"), (60000, 384, 12, "iid"), (64512, 320, 8, "clustered"),
+          (60269, 768, 8, "grouped300"), (100000, 768, 32, "iid")]
 
 
 @pytest.mark.parametrize("N,D,k,kind", SHAPES)
@@ -90,10 +92,34 @@ def test_lattices_the_streamed_create_does_not_serve_take_the_whole_array_upload
     lat.close()
 
 
+def test_a_streamed_build_that_gives_up_hands_over_to_the_whole_array_build(monkeypatch):
+    """osc_graph.hip: build_graph -- a streamed build whose lists overflowed (anchors grouped in runs a piece's scatter cannot
+    spread) does not send its rows to the all-fp32 kernel: the anchors are resident by then and the whole-array build runs.
+    OSC_CREATE_FORCE_RETRY takes that branch on any lattice; build_info reports the pieces negated."""
+    N, D, k = 40000, 512, 16
+    Y = _anchors(N, D, "clustered", seed=7)
+    psi = Y[:32].mean(0)
+    psi = (psi / np.linalg.norm(psi)).astype(np.float32)
+    whole_lat = _lattice(Y, k, stream=False)
+    whole = _snapshot(whole_lat, psi)
+    whole_lat.close()
+    monkeypatch.setenv("OSC_CREATE_FORCE_RETRY", "1")
+    lat = _lattice(Y, k, stream=True)
+    monkeypatch.delenv("OSC_CREATE_FORCE_RETRY")
+    got = _snapshot(lat, psi)
+    lat.close()
+    assert got["info"]["create_pieces"] <= -3, got["info"]
+    np.testing.assert_array_equal(got["Y"], Y)
+    np.testing.assert_array_equal(got["U0"], Y)
+    for key in ("rowptr", "col", "A", "W", "sd"):
+        np.testing.assert_array_equal(got[key], whole[key], err_msg=key)
+    np.testing.assert_array_equal(got["U"], whole["U"])
+
+
 def test_streamed_creates_from_concurrent_threads():
     """cloud/app/main.py runs independent lattices on a thread pool: two threads, two streamed creates each, side by side (every
     create takes its own copy stream, second build stream and pinned staging pair from the per-device pools)."""
-    N, D, k = 36000, 512, 12
+    N, D, k = 40000, 512, 12
     Ys = [_anchors(N, D, "iid", seed=s) for s in (3, 4)]
     ref = []
     for Y in Ys:
