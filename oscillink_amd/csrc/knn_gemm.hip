@@ -870,13 +870,16 @@ __global__ void k_panel_image(const float* Yn, int32_t ldn, _Float16* Yh, int32_
   *(half8*)(Yh + (size_t)row * ldh + c0) = v;
 }
 
-__global__ void k_panel_sample(const _Float16* Yh, _Float16* Ys, int32_t ldh, int32_t m, int32_t N) {
+__global__ void k_panel_sample(const _Float16* Yh, _Float16* Ys, int32_t ldh, int32_t m, int32_t N, int32_t gsz, int32_t G, int32_t mapped,
+                               KnnRowMap map) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int per_row = ldh / 8;
   if (i >= (int64_t)m * per_row) return;
-  const int t = (int)(i / per_row), c0 = (int)(i % per_row) * 8;
-  const int64_t src = min((int64_t)N - 1, (int64_t)t * N / m);
-  *(half8*)(Ys + (size_t)t * ldh + c0) = *(const half8*)(Yh + (size_t)src * ldh + c0);
+  const int r = (int)(i / per_row), c0 = (int)(i % per_row) * 8;
+  // knn_rowmap.hpp: which lattice row the sample holds at position r; its fp16 row sits at that row's place in the image
+  const int32_t row = knn_sample_lattice_row(knn_sample_index(r, m, gsz, G), m, N);
+  const int64_t src = mapped ? knn_map_image_row(map, N, row) : row;
+  *(half8*)(Ys + (size_t)r * ldh + c0) = *(const half8*)(Yh + (size_t)src * ldh + c0);
 }
 
 // one wave per row: tau = the rank-th largest of the row's ntile (<= 128) tile maxima
@@ -1604,7 +1607,8 @@ void launch_panel_sample(const void* Yh, void* Ys, const KnnPanelPlan& p, int32_
   const int32_t m = p.sample_tiles * 128;
   const int64_t n = (int64_t)m * (p.ldh / 8);
   hipLaunchKernelGGL(k_panel_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                     static_cast<const _Float16*>(Yh), static_cast<_Float16*>(Ys), p.ldh, m, N);
+                     static_cast<const _Float16*>(Yh), static_cast<_Float16*>(Ys), p.ldh, m, N, p.group_tiles * 128, p.sample_groups,
+                     p.scatter != 1 ? 1 : 0, p.map);
   HIP_CHECK(hipGetLastError());
 }
 

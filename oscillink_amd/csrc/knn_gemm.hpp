@@ -84,12 +84,8 @@ void launch_panel_image(const float* Yn, int32_t ldn, void* Yh, const KnnPanelPl
                         int32_t r0 = 0, int32_t r1 = -1);
 // the streamed create's column sample: `rows` unit rows (pitch ldn), already in sample order -> the sample image
 void launch_panel_sample_rows(const float* Yn_rows, int32_t ldn, void* Ys, const KnnPanelPlan& p, int32_t rows, int32_t D, hipStream_t s);
-// which image row the sample's row t copies (launch_panel_sample)
-inline int32_t knn_panel_sample_row(const KnnPanelPlan& p, int32_t N, int32_t t) {
-  const int64_t m = (int64_t)p.sample_tiles * 128, src = (int64_t)t * N / m;
-  return (int32_t)(src < (int64_t)N - 1 ? src : (int64_t)N - 1);
-}
-// the column sample: row t of the sample image = row min(N - 1, t * stride) of the query image
+// the column sample (knn_rowmap.hpp: knn_sample_index / knn_sample_lattice_row): an even stride of LATTICE rows, dealt to the
+// threshold groups in turn -- copied from the rows' places in the query image
 void launch_panel_sample(const void* Yh, void* Ys, const KnnPanelPlan& p, int32_t N, hipStream_t s);
 // phase A: per (query row, group of sample tiles) maximum fp16 score -> tmax [npad][sample_groups], for the query row
 // blocks [rb_begin, rb_begin + rb_count)

@@ -43,6 +43,23 @@ OSC_HD inline int32_t knn_map_image_row(const KnnRowMap& m, int32_t N, int32_t r
   return base + (int32_t)(((int64_t)(row - base) * m.inv[j]) % n);
 }
 
+// The threshold sample (knn_gemm.hpp: KnnPanelPlan): m sample rows in G groups of gsz consecutive rows (the last group may be
+// shorter); a row's threshold is the r-th largest of its maxima over the groups.  Sample index t stands for lattice row
+// floor(t N / m) -- an even stride in LATTICE order whatever order the anchors arrive in -- and the indices are dealt to the
+// groups in turn (t -> group t mod G while every group has room), so the sampled members of any run of consecutive lattice
+// rows (anchors that arrive cluster by cluster: a row's cluster mates) sit in as many different groups as there are.
+// This returns the sample index held at position r of the sample image.
+OSC_HD inline int32_t knn_sample_index(int32_t r, int32_t m, int32_t gsz, int32_t G) {
+  const int32_t g = r / gsz, slot = r - g * gsz;
+  const int32_t last = m - (G - 1) * gsz;  // rows of the last group (1 .. gsz)
+  if (slot < last) return slot * G + g;           // rounds that still reach every group
+  return last * G + (slot - last) * (G - 1) + g;  // ... and those that skip the full last one (g < G - 1 here)
+}
+OSC_HD inline int32_t knn_sample_lattice_row(int32_t t, int32_t m, int32_t N) {
+  const int64_t row = (int64_t)t * N / m;
+  return (int32_t)(row < (int64_t)N - 1 ? row : (int64_t)N - 1);
+}
+
 namespace rowmap_detail {
 inline int64_t gcd64(int64_t a, int64_t b) {
   while (b) {

@@ -339,32 +339,18 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
   try {
     float* pinned = static_cast<float*>(sp.buf[0]);
     const int nthr = std::max(1, std::min(threads, 8));
-    // WHICH rows the sample holds and in which ORDER matters: a row's threshold is the r-th largest of its maxima over GROUPS
-    // of consecutive sample rows, which estimates the r-th best sample score only if the row's good sample columns -- for
-    // anchors that arrive cluster by cluster: its cluster mates -- fall into at least r different groups.  The whole-array
-    // build samples every rho-th IMAGE row, and its global golden-ratio scatter spreads a cluster's mates evenly over the
-    // image.  With pieces permuted separately that no longer holds (a piece's sample rows are neighbours in image order;
-    // dealing them to the groups by a second multiplicative permutation, or in turn, cured one soak case and failed the
-    // next: 60 000 x 768 k 8 clusters of 300, 217 317 x 96 k 5 clusters of 479, 543 744 x 128 k 62 clusters of 401 -- the
-    // count of DISTINCT groups a cluster's ~17 sampled mates reach was left to chance).  The host gathers the sample anyway,
-    // so here it is defined in LATTICE order: sample t = lattice row floor(t N / m), an even stride whatever the anchors'
-    // order, dealt to the groups in turn (t -> group t mod G): a cluster's mates are consecutive t, hence consecutive groups.
-    std::vector<int32_t> order((size_t)m_s);
-    {
-      const int32_t gsz = pp.group_tiles * 128, G = pp.sample_groups;
-      std::vector<int32_t> fill((size_t)G, 0);
-      int g = 0;
-      for (int32_t t = 0; t < m_s; ++t) {
-        while (fill[(size_t)g] >= std::min(gsz, m_s - g * gsz)) g = (g + 1) % G;  // (the last group may be shorter)
-        order[(size_t)g * gsz + fill[(size_t)g]++] = t;
-        g = (g + 1) % G;
-      }
-    }
-    const int32_t* const order_p = order.data();
+    // The sample is defined in lattice terms (knn_rowmap.hpp: an even stride of lattice rows, dealt to the threshold groups
+    // in turn), so it can be put together from the caller's array before a single image row exists -- and it is the very
+    // sample the whole-array build copies out of its image: same thresholds, same hits, same rows proven.  (Its first form
+    // here took every rho-th IMAGE row, as the build did until round 5: with pieces permuted separately a cluster's sampled
+    // mates then sat in the few groups of their own piece, the thresholds of anchors that arrive cluster by cluster fell
+    // to the background level and every row went to the exact kernel -- soak_streamed_create.py, 60 000 x 768, k = 8,
+    // clusters of 300; two permutations of the sample order later the count of distinct groups was still left to chance.)
+    const int32_t gsz = pp.group_tiles * 128, G = pp.sample_groups;
     for (int t = 0; t < nthr; ++t)
       workers.emplace_back([=] {
         for (int32_t r = (int32_t)((int64_t)m_s * t / nthr); r < (int32_t)((int64_t)m_s * (t + 1) / nthr); ++r) {
-          const int64_t row = std::min<int64_t>((int64_t)N - 1, (int64_t)order_p[r] * N / m_s);
+          const int32_t row = knn_sample_lattice_row(knn_sample_index(r, m_s, gsz, G), m_s, N);
           std::memcpy(pinned + (size_t)r * D, host_Y + (size_t)row * D, row_bytes);
         }
       });

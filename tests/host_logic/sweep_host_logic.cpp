@@ -120,6 +120,25 @@ static void check_row_map(int32_t N, std::mt19937_64& rng) {
   CHECK(threw, "N %d: a piece starting at N accepted", N);
 }
 
+// the threshold sample's order (knn_rowmap.hpp): a bijection of the sample indices, G consecutive indices in G different
+// groups (G - 1 once the short last group is full), lattice rows ascending with the index and inside the lattice
+static void check_sample_order(int32_t tiles, int32_t group_tiles, int32_t N) {
+  const int32_t m = tiles * 128, gsz = group_tiles * 128, G = (tiles + group_tiles - 1) / group_tiles;
+  std::vector<int32_t> group_of((size_t)m, -1);
+  for (int32_t r = 0; r < m; ++r) {
+    const int32_t t = osc::knn_sample_index(r, m, gsz, G);
+    CHECK(t >= 0 && t < m && group_of[(size_t)t] < 0, "sample of %d tiles in groups of %d: position %d -> index %d twice or out of range", tiles, group_tiles, r, t);
+    if (t >= 0 && t < m) group_of[(size_t)t] = r / gsz;
+  }
+  for (int32_t t = 0; t + 1 < m; ++t) {
+    const int32_t span = std::min<int32_t>(G - 1, m - t);
+    bool distinct = true;
+    for (int32_t u = 1; u < span; ++u) distinct = distinct && group_of[(size_t)t] != group_of[(size_t)(t + u)];
+    CHECK(distinct, "sample of %d tiles in groups of %d: index %d shares a group with one of the next %d", tiles, group_tiles, t, span - 1);
+    CHECK(osc::knn_sample_lattice_row(t, m, N) <= osc::knn_sample_lattice_row(t + 1, m, N) && osc::knn_sample_lattice_row(t + 1, m, N) < N, "sample rows not ascending at %d", t);
+  }
+}
+
 static void check_partitions(int64_t N, int32_t dcols) {
   for (int world : {1, 2, 3, 4, 5, 8, 16}) {
     int32_t prev = 0;
@@ -351,6 +370,9 @@ int main(int argc, char** argv) {
       if (N <= 3000) check_blk_place(g);
     }
   }
+  for (int32_t tiles : {24, 25, 65, 87, 128, 129, 141, 183, 255, 256, 257, 651})
+    for (int32_t gt : {(tiles + 127) / 128, (tiles + 127) / 128 + 1})
+      check_sample_order(tiles, gt, tiles * 128 * 12 + 77);
   // xs group counts: divisors of 8; slabs in flight within 128 MiB up to kXsBudgetRows rows, beyond that (the wide blocked
   // matvec's regime: its working set is a source block) at most four groups and only for windows of >= 4 slabs
   for (int64_t N : {1000, 16384, 100000, 131072, 131073, 200000, 262144, 300000, 524288, 524289, 1000000, 3000000})
