@@ -310,7 +310,7 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
   // Two build streams take the pieces in turn: a sweep launch is a persistent grid of one workgroup per CU, and on ONE stream
   // piece j + 1's kernels would wait for the last straggler of piece j's sweep.
   hipStream_t up = acquire_stream(h.device), second = acquire_stream(h.device);
-  hipStream_t cs[2] = {h.stream, getenv("OSC_CREATE_ONE_STREAM") ? h.stream : second};
+  hipStream_t cs[2] = {h.stream, second};
   const StagePair sp = acquire_stage(h.device);
   // events: [j] piece j has landed, [pieces + j] the thresholds of all rows up to piece j's are written, then: everything
   // the caller queued before this call is done / the sample image is written / the second stream has drained
