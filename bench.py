@@ -418,6 +418,7 @@ def main():
         info = comm_info_of(lat)
         create_ms = 1000.0 * (time.time() - t_c)
         nnz, max_deg, dev_build_ms = lat.graph_stats()
+        create_pieces = int(lat.build_info().get("create_pieces", 0))
         lat.set_query(psi)
 
         def step():
@@ -444,7 +445,7 @@ def main():
         launches, total_ms = C.c_int64(0), C.c_double(0.0)
         lat._call("osc_profile_get", 0, C.byref(launches), C.byref(total_ms))
         lat._call("osc_profile_enable", 0)
-        return {"seed": seed, "lat": lat, "Y": Y, "psi": psi, "comm": info, "create_ms": create_ms,
+        return {"seed": seed, "lat": lat, "Y": Y, "psi": psi, "comm": info, "create_ms": create_ms, "create_pieces": create_pieces,
                 "inputs_ms": 1000.0 * (t_c - t_in), "nnz": nnz, "max_deg": max_deg, "dev_build_ms": dev_build_ms,
                 "per_step_ms": per_step, "elapsed_s": elapsed, "iters_total": iters_total, "last": last,
                 "apply_launches": int(launches.value), "apply_total_ms": float(total_ms.value), "first": first, "step": step}
@@ -558,6 +559,11 @@ def main():
                                 "ms_per_step_mean = the barrier-bracketed regions / steps (max over ranks)"},
         "comm": comm_info,
         "lattice_create_ms": main_run["create_ms"],  # first call in the process: HIP context + code objects + upload + build
+        # ... and the later seeds' creates (steady state): anchors from pageable host memory -> lattice; create_pieces > 0: the
+        # transfer ran beside the build in that many pieces (OSC_CREATE_STREAM); never part of `value`
+        "host_handover": {"create_ms_steady": (float(np.median([r["create_ms"] for r in runs[1:]])) if len(runs) > 1 else None),
+                          "create_pieces": main_run["create_pieces"],
+                          "anchors_MB": N * D * 4 / 1e6},
         "graph_build_device_ms": main_run["dev_build_ms"],
         "roofline": {"bound": "hbm",
                      "kernel": (f"k_apply_blocked (operator apply / CG matvec; one launch, XCD-affine 32-column slabs, "

@@ -285,6 +285,7 @@ uint32_t* ctrl_segment(L& h, size_t words);
 void ensure_ctrl(L& h, size_t slots);
 void ensure_cg_scratch(L& h, int max_iters);
 int cg_grid(const L& h);
+int blocked_quad_form(L& h, const OpParams& op, const float* x_rows, float* scratch_slab, float* scratch_out, bool with_path);
 GraphView graph_view(L& h, bool with_path);
 void graph_counts(L& h);
 void alloc_ell(L& h, int32_t width);

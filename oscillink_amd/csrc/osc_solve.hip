@@ -328,6 +328,79 @@ bool run_cg_small(L& h, const OpParams& op, const CgBuffers& b, bool with_path, 
 CgResult run_cg_rows(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol);
 bool row_mode(const L& h);
 
+// Arguments of the source-blocked matvec (k_apply_blocked) for the handle's whole column window: X = slab-major input, OUT =
+// row-major output, column sums of X . OUT into h.part0 (grid rows, + the chain fix-up's chunks behind them).  ba.nb stays
+// 0 where the plan says the plain apply serves this lattice (blocked_plan).
+void blocked_setup(L& h, const OpParams& op, const float* X, float* OUT, const float* B, int32_t ld, bool with_path, int grid, BlkArgs& ba,
+                   ChainFixArgs& cf, int& blk_shape) {
+  const int nb = blocked_plan(h, with_path);
+  if (nb == 0) return;
+  const BlockedView bv = blocked_view(h, nb);
+  ba.X = X;
+  ba.OUT = OUT;
+  ba.B = B;
+  ba.part = h.part0.p;
+  ba.slots = bv.slots;
+  ba.rest = bv.rest;
+  ba.over = bv.over;
+  ba.cs_const = op.cs_const;
+  ba.cs_B = op.cs_B;
+  ba.cW = op.cW;
+  ba.N = (int32_t)h.N;
+  ba.ld = ld;
+  ba.c0 = h.c0;
+  ba.c1 = h.c1;
+  ba.nb = nb;
+  // workgroups per XCD (what is resident at once), slab groups, row groups per wave, destination slices
+  const int xg0 = xs_groups_for(h, h.c1 - h.c0), xg = xg0 > 0 ? xg0 : xs_groups(h.c1 - h.c0, h.xs_groups_cap);
+  blk_shape = blocked_shape_for(h, xg, grid);
+  const host::BlockedGeom geom = host::blocked_geometry(h.N, xg, grid, blocked_resident(h, blk_shape), blocked_groups_max(blk_shape),
+                                                       blocked_gather_waves(blk_shape));
+  ba.xs = geom.xs;
+  ba.xs_groups = geom.xs_groups;
+  ba.slices = geom.slices;
+  ba.groups = geom.groups;
+  if (with_path && op.cP != 0.f) {  // the chain prior's few rows: a small launch behind every blocked apply
+    cf.X = X;
+    cf.OUT = OUT;
+    cf.part = h.part0.p;
+    cf.prow = h.prow.p;
+    cf.pcol = h.pcol.p;
+    cf.pw = h.pw.p;
+    cf.pdeg = h.pdeg.p;
+    cf.cP = op.cP;
+    cf.prows = h.prows;
+    cf.pwidth = h.pwidth;
+    cf.N = (int32_t)h.N;
+    cf.ld = ld;
+    cf.c0 = h.c0;
+    cf.c1 = h.c1;
+    cf.part_row0 = grid;
+    cf.chunks = chain_fix_chunks(h.prows);
+  }
+}
+
+// x . (op x) summed per column into h.part0 for a ROW-major x (N x ld, the handle's whole window) through the blocked matvec:
+// x -> slab-major (scratch_slab), one launch (+ the chain fix-up), op x -> scratch_out.  Returns the rows of partial sums
+// h.part0 holds, 0 where the blocked matvec does not serve this lattice (the caller takes the plain apply's DOT form).
+int blocked_quad_form(L& h, const OpParams& op, const float* x_rows, float* scratch_slab, float* scratch_out, bool with_path) {
+  const int grid = cg_grid(h);
+  if (!(h.p_blocked && xs_plan(h, h.c1 - h.c0, grid) > 0 && (h.ld & 31) == 0 && (h.c0 & 31) == 0)) return 0;
+  BlkArgs ba{};
+  ChainFixArgs cf{};
+  int blk_shape = 0;
+  blocked_setup(h, op, scratch_slab, scratch_out, h.B.p, h.ld, with_path, grid, ba, cf, blk_shape);
+  if (ba.nb == 0) return 0;
+  launch_rows_to_slab(x_rows, scratch_slab, h.N, h.ld, h.c0, h.c1, grid, h.stream);
+  ba.gate = nullptr;
+  launch_apply_blocked(ba, grid, h.stream, nullptr, blk_shape);
+  if (cf.chunks > 0) {
+    cf.gate = nullptr;
+    launch_chain_fix(cf, h.stream);
+  }
+  return grid + cf.chunks;
+}
+
 CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, int max_iters, float tol) {
   if (row_mode(h) && b.ld == h.ld) return run_cg_rows(h, op, b, with_path, max_iters, tol);
   {
@@ -399,53 +472,7 @@ CgResult run_cg(L& h, const OpParams& op, const CgBuffers& b, bool with_path, in
   BlkArgs ba{};
   ChainFixArgs cf{};
   int blk_shape = 0;
-  if (pblk && b.c0 == h.c0 && b.c1 == h.c1) {
-    if (const int nb = blocked_plan(h, with_path)) {
-      const BlockedView bv = blocked_view(h, nb);
-      ba.X = b.P;
-      ba.OUT = b.AP;
-      ba.B = b.B;
-      ba.part = h.part0.p;
-      ba.slots = bv.slots;
-      ba.rest = bv.rest;
-      ba.over = bv.over;
-      ba.cs_const = op.cs_const;
-      ba.cs_B = op.cs_B;
-      ba.cW = op.cW;
-      ba.N = (int32_t)h.N;
-      ba.ld = b.ld;
-      ba.c0 = b.c0;
-      ba.c1 = b.c1;
-      ba.nb = nb;
-      // workgroups per XCD (what is resident at once), slab groups, row groups per wave, destination slices
-      const int xg0 = xs_groups_for(h, b.c1 - b.c0), xg = xg0 > 0 ? xg0 : xs_groups(b.c1 - b.c0, h.xs_groups_cap);
-      blk_shape = blocked_shape_for(h, xg, grid);
-      const host::BlockedGeom geom = host::blocked_geometry(h.N, xg, grid, blocked_resident(h, blk_shape), blocked_groups_max(blk_shape),
-                                                           blocked_gather_waves(blk_shape));
-      ba.xs = geom.xs;
-      ba.xs_groups = geom.xs_groups;
-      ba.slices = geom.slices;
-      ba.groups = geom.groups;
-      if (with_path && op.cP != 0.f) {  // the chain prior's few rows: a small launch behind every blocked apply
-        cf.X = b.P;
-        cf.OUT = b.AP;
-        cf.part = h.part0.p;
-        cf.prow = h.prow.p;
-        cf.pcol = h.pcol.p;
-        cf.pw = h.pw.p;
-        cf.pdeg = h.pdeg.p;
-        cf.cP = op.cP;
-        cf.prows = h.prows;
-        cf.pwidth = h.pwidth;
-        cf.N = (int32_t)h.N;
-        cf.ld = b.ld;
-        cf.c0 = b.c0;
-        cf.c1 = b.c1;
-        cf.part_row0 = grid;
-        cf.chunks = chain_fix_chunks(h.prows);
-      }
-    }
-  }
+  if (pblk && b.c0 == h.c0 && b.c1 == h.c1) blocked_setup(h, op, b.P, b.AP, b.B, b.ld, with_path, grid, ba, cf, blk_shape);
 
   // (an inertia start hands over x0 IN the AP array, which the blocked matvec would overwrite with A x0 before
   // init_finish has read x0: such a solve keeps the gathering INIT kernel, which reads x0 completely first)
