@@ -394,6 +394,7 @@ int blocked_quad_form(L& h, const OpParams& op, const float* x_rows, float* scra
   launch_rows_to_slab(x_rows, scratch_slab, h.N, h.ld, h.c0, h.c1, grid, h.stream);
   ba.gate = nullptr;
   launch_apply_blocked(ba, grid, h.stream, nullptr, blk_shape);
+  h.blk_applies += 1;
   if (cf.chunks > 0) {
     cf.gate = nullptr;
     launch_chain_fix(cf, h.stream);

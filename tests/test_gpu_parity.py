@@ -1192,6 +1192,56 @@ def test_blocked_apply_kernel_shapes_against_the_plain_one(amd, shape, monkeypat
     assert relerr(b[1], a[1]) < 1e-6 and relerr(b[2], a[2]) < 1e-6 and relerr(b[5], a[5]) < 1e-6
 
 
+def test_deltaH_through_the_blocked_matvec_against_the_plain_apply_and_the_oracle(amd, orc, monkeypatch):
+    """receipts.py:10-25 (deltaH_trace = sum (U - U*) . M (U - U*)).  Where the blocked matvec serves the lattice, osc_deltaH takes
+    its column sums of x . (M x) (osc_api.hip: quad_form_of_difference -> osc_solve.hip: blocked_quad_form) instead of the
+    plain apply's DOT form: same value to summation-order noise, with and without a chain prior (the fix-up launch adds its
+    rows' partial sums), and within 1e-4 of the sparse oracle on the device-built graph."""
+    monkeypatch.delenv("OSC_SPMM_XS", raising=False)
+    monkeypatch.delenv("OSC_REORDER", raising=False)
+    rng = np.random.default_rng(9)
+    N, D, k = 36001, 200, 20
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    psi = rng.standard_normal(D).astype(np.float32)
+    psi /= np.linalg.norm(psi)
+    gates = rng.uniform(0.1, 1.0, N).astype(np.float32)
+    chain = [5, 1, 36000, 18000, 7, 2]
+    got = {}
+    for mode in ("plain", "blocked"):
+        monkeypatch.setenv("OSC_SPMM_BLOCKED", "0" if mode == "plain" else "6")
+        lat = amd.Oscillink(Y, kneighbors=k)
+        lat.set_query(psi, gates=gates)
+        lat.settle(max_iters=3, tol=1e-9)  # (a state well away from U*: the difference is not rounding noise)
+        lat.refresh_Ustar()
+        before = lat.build_info()["blocked_applies"]
+        dh = lat.receipt()["deltaH_total"]
+        used = lat.build_info()["blocked_applies"] - before
+        lat.add_chain(chain, lamP=0.3)
+        lat.refresh_Ustar()
+        dh_chain = lat.receipt()["deltaH_total"]
+        if mode == "blocked":
+            assert used >= 1, "deltaH did not take the blocked matvec"
+            rowptr, col, A, W, sd = lat.graph_csr()
+            U, Us = lat.U.copy(), lat.solve_Ustar().copy()
+            import scipy.sparse as sp
+            Wm = sp.csr_matrix((W, col, rowptr), shape=(N, N))
+            Wp, _ = orc.normalized_laplacian(orc.path_adjacency(N, chain, dense=False))  # graph.py:96-111: I - Wp over all N rows
+            f32 = np.float32
+
+            def M_mul(X):  # lattice.py:173-182 / receipts.py:21-25 on the device-built graph
+                return (f32(lat.lamG) * X + f32(lat.lamC) * (X - Wm @ X) + f32(lat.lamQ) * gates[:, None] * X
+                        + f32(0.3) * (X - Wp @ X)).astype(f32)
+
+            want = orc.deltaH_trace(U, Us, M_mul)
+            assert abs(dh_chain - want) <= 1e-4 * abs(want), (dh_chain, want)
+        else:
+            assert used == 0
+        got[mode] = (dh, dh_chain)
+        lat.close()
+    for a, b in zip(got["plain"], got["blocked"]):
+        assert abs(a - b) <= 2e-6 * abs(a), got
+
+
 def test_source_blocked_apply_against_the_plain_one(amd, orc, monkeypatch):
     """A lattice inside the automatic window (N = 40000, D = 256: slab 5 MB) with random gates: the blocked matvec and the
     plain one give the same iteration count and the same state to fp32 summation-order noise; rows with more than
