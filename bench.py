@@ -415,8 +415,8 @@ def main():
         Y, psi = make_inputs(seed)
         t_c = time.time()
         lat = make_lattice(Y, f"s{seed}")
-        info = comm_info_of(lat)
         create_ms = 1000.0 * (time.time() - t_c)
+        info = comm_info_of(lat)
         nnz, max_deg, dev_build_ms = lat.graph_stats()
         create_pieces = int(lat.build_info().get("create_pieces", 0))
         lat.set_query(psi)
@@ -561,7 +561,8 @@ def main():
         "lattice_create_ms": main_run["create_ms"],  # first call in the process: HIP context + code objects + upload + build
         # ... and the later seeds' creates (steady state): anchors from pageable host memory -> lattice; create_pieces > 0: the
         # transfer ran beside the build in that many pieces (OSC_CREATE_STREAM); never part of `value`
-        "host_handover": {"create_ms_steady": (float(np.median([r["create_ms"] for r in runs[1:]])) if len(runs) > 1 else None),
+        "host_handover": {"create_ms_later_seeds": [r["create_ms"] for r in runs[1:]],  # (the second seed's lattice is created beside
+                          # the first one's and allocates its arrays anew; from the third on the device blocks are reused)
                           "create_pieces": main_run["create_pieces"],
                           "anchors_MB": N * D * 4 / 1e6},
         "graph_build_device_ms": main_run["dev_build_ms"],
