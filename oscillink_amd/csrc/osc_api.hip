@@ -61,6 +61,7 @@ void read_env_build(L& h) {
   h.knn_sym = !(num("OSC_KNN_PANEL_SYM", v) && v == 0);
   h.create_stream = !(num("OSC_CREATE_STREAM", v) && v == 0);
   h.create_force_retry = num("OSC_CREATE_FORCE_RETRY", v) && v != 0;
+  h.create_min_mb = num("OSC_CREATE_MIN_MB", v) ? std::max(1, v) : 64;
   h.create_piece_mb_set = num("OSC_CREATE_PIECE_MB", v);
   h.create_piece_mb = h.create_piece_mb_set ? std::max(1, std::min(v, 1024)) : 24;
   h.knn_tune = KnnPanelTune{};

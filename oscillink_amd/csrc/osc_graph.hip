@@ -596,7 +596,7 @@ static bool build_graph_once(L& h, const float* host_Y) {
       // anchors that arrive cluster by cluster packs each cluster into few tiles -- 3072 rows holding 7.7 clusters of 401 gave
       // every row 17 cluster mates per column tile, more than a wave's hit list takes from one tile)
       const int64_t rows = m * chunk_rows, pieces = N / rows;
-      if (pieces >= 3 && (int64_t)N * row_bytes >= ((int64_t)64 << 20) && smp_bytes <= (int64_t)kStageBytes) {
+      if (pieces >= 3 && (int64_t)N * row_bytes >= ((int64_t)h.create_min_mb << 20) && smp_bytes <= (int64_t)kStageBytes) {
         for (int64_t j = 0; j < pieces; ++j) piece_starts.push_back((int32_t)(j * rows));
         knn_panel_set_pieces(pp, N, piece_starts.data(), (int)piece_starts.size());
       }

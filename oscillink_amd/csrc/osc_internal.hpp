@@ -140,6 +140,7 @@ struct osc_lattice {
   bool create_stream = true;   // OSC_CREATE_STREAM: osc_create hands the anchors to the build piece by piece (osc_graph.hip)
   int32_t create_piece_mb = 24;  // OSC_CREATE_PIECE_MB: anchors per piece, at least (experiments)
   bool create_piece_mb_set = false;
+  int32_t create_min_mb = 64;  // OSC_CREATE_MIN_MB: anchors below this travel whole (the streamed create's fixed costs)
   bool create_force_retry = false;  // OSC_CREATE_FORCE_RETRY (test hook): a streamed build always hands over to the whole-array one
   int32_t create_pieces = 0;   // pieces the last build received its anchors in (0: they were on the device before it started)
   bool knn_force_exchange = false;  // OSC_KNN_FORCE_EXCHANGE=1 (test hook): run the sharded half sweep's collectives under a ONE-rank communicator too
