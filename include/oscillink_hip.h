@@ -70,7 +70,8 @@ int osc_host_free(void* p);
  * last list place are 1-2 ulp apart (tests/golden/case_seed_*.npz: identical edge sets on Gaussian anchors).
  * build_graph == 0: no graph yet; call osc_set_csr (from_state / parity tests).
  * Y is read until the call returns and not afterwards.  With build_graph != 0 the anchors of a large lattice (>= 64 MB,
- * D <= 768, unpadded rows) travel to the device in pieces WHILE the build runs on the pieces that have arrived (a copy
+ * unpadded rows; beyond 768 columns from ~130 000 rows) travel to the device in pieces WHILE the build runs on the pieces
+ * that have arrived (a copy
  * stream, a second build stream and a few host threads for the duration of the call; OSC_CREATE_STREAM=0: one transfer,
  * then the build): same lattice bit for bit, create 20.8 -> 16.5 ms at N = 100 000, D = 768, k = 32. */
 int osc_create(const float* Y, int64_t N, int32_t D, int32_t k, float row_cap, int32_t deterministic,

@@ -1096,6 +1096,7 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
   auto chunk_sets = [&](int c) { return max(0, min((min(nrb, (c + 1) * a.T) + 1) / 2 - a.set0, a.nset)); };  // sets of this launch that sweep chunk c
   int nitems = 0;
   for (int c = 0; c < a.nchunks; ++c) nitems += chunk_sets(c);
+  if (a.item_end > 0) nitems = min(nitems, a.item_end);  // (a window of column chunks: the streamed create)
   auto glds16 = [&](const _Float16* src, unsigned dst_bytes) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -1105,7 +1106,7 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
   };
   for (;;) {
     if (tid == 0) {
-      const int it = (int)atomicAdd(a.queue, 1u) * a.item_stride + a.item_offset;
+      const int it = a.item_begin + (int)atomicAdd(a.queue, 1u) * a.item_stride + a.item_offset;
       int c = a.nchunks - 1, first = 0;
       if (it < nitems)
         while (it >= first + chunk_sets(c)) first += chunk_sets(c), --c;
@@ -1653,18 +1654,21 @@ void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int r
   if (rb_count <= 0) return;
   PanelArgs a{};
   a.item_stride = 1;
-  if (chunk_hi >= 0) {  // a window of column chunks: the queue walks the chunks from the last to the first
-    if (!p.sym || p.tile_core || chunk_lo < 0 || chunk_hi > p.S || chunk_lo >= chunk_hi)
-      throw std::runtime_error("launch_panel_filter: chunk windows are for the panel core's half sweep");
-    auto sets = [&](int c) { return (std::min(p.nrb, (c + 1) * p.T) + p.nrg - 1) / p.nrg; };
-    int begin = 0, end = 0;
-    for (int c = p.S - 1; c >= chunk_lo; --c) {
-      if (c >= chunk_hi) begin += sets(c);
-      end += sets(c);
+  const bool window = chunk_hi >= 0;
+  if (window) {  // a window of column chunks: the queue walks the chunks from the last to the first
+    if (!p.sym || (p.tile_core && !p.tile_wide) || chunk_lo < 0 || chunk_hi > p.S || chunk_lo >= chunk_hi)
+      throw std::runtime_error("launch_panel_filter: chunk windows are for the half sweep on the panel core or the wide tile core");
+    if (!p.tile_core) {
+      auto sets = [&](int c) { return (std::min(p.nrb, (c + 1) * p.T) + p.nrg - 1) / p.nrg; };
+      int begin = 0, end = 0;
+      for (int c = p.S - 1; c >= chunk_lo; --c) {
+        if (c >= chunk_hi) begin += sets(c);
+        end += sets(c);
+      }
+      a.item_begin = begin;
+      a.item_end = end;
+      grid = std::max(1, std::min(grid, (end - begin + std::max(1, shards) - 1) / std::max(1, shards)));
     }
-    a.item_begin = begin;
-    a.item_end = end;
-    grid = std::max(1, std::min(grid, (end - begin + std::max(1, shards) - 1) / std::max(1, shards)));
   }
   if (shards > 1) {
     if (!p.sym || shard < 0 || shard >= shards) throw std::runtime_error("launch_panel_filter: only the half sweep is cut by work items");
@@ -1702,11 +1706,26 @@ void launch_panel_filter(const void* Yh, const KnnPanelPlan& p, int32_t N, int r
     const int nsets = (p.nrb + 1) / 2, gs = std::max(1, p.tile_group_sets);
     auto go = [&](auto kern) {
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2_LDS_ALL));
+      bool first_launch = true;
       for (int g = 0; g * gs < nsets; ++g) {
-        if (g > 0) HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
         a.set0 = g * gs;
         a.nset = std::min(gs, nsets - g * gs);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), T2_LDS_ALL, s, a, p.nkt);
+        int launch_grid = grid;
+        if (window) {  // this group's items of the chunks [chunk_lo, chunk_hi) (k_tile_thr2: chunk_sets, chunks from the last)
+          auto sets = [&](int c) { return std::max(0, std::min((std::min(p.nrb, (c + 1) * p.T) + 1) / 2 - a.set0, a.nset)); };
+          int begin = 0, end = 0;
+          for (int c = p.S - 1; c >= chunk_lo; --c) {
+            if (c >= chunk_hi) begin += sets(c);
+            end += sets(c);
+          }
+          if (end <= begin) continue;  // (the group's sets lie beyond the rows that have arrived)
+          a.item_begin = begin;
+          a.item_end = end;
+          launch_grid = std::max(1, std::min(grid, end - begin));
+        }
+        if (!first_launch) HIP_CHECK(hipMemsetAsync(queue, 0, 4, s));
+        first_launch = false;
+        hipLaunchKernelGGL(kern, dim3(launch_grid), dim3(512), T2_LDS_ALL, s, a, p.nkt);
       }
     };
     go(&k_tile_thr2);

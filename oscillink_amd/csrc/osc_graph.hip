@@ -337,7 +337,10 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
     release_stream(h.device, second);
   };
   try {
-    float* pinned = static_cast<float*>(sp.buf[0]);
+    // (the sample's rows fill the first staging buffer and, beyond 32 MB, the second one: two transfers)
+    const int32_t half_rows = (int32_t)std::min<int64_t>(m_s, (int64_t)(kStageBytes / row_bytes));
+    float* const pin0 = static_cast<float*>(sp.buf[0]);
+    float* const pin1 = static_cast<float*>(sp.buf[1]);
     const int nthr = std::max(1, std::min(threads, 8));
     // The sample is defined in lattice terms (knn_rowmap.hpp: an even stride of lattice rows, dealt to the threshold groups
     // in turn), so it can be put together from the caller's array before a single image row exists -- and it is the very
@@ -351,7 +354,7 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
       workers.emplace_back([=] {
         for (int32_t r = (int32_t)((int64_t)m_s * t / nthr); r < (int32_t)((int64_t)m_s * (t + 1) / nthr); ++r) {
           const int32_t row = knn_sample_lattice_row(knn_sample_index(r, m_s, gsz, G), m_s, N);
-          std::memcpy(pinned + (size_t)r * D, host_Y + (size_t)row * D, row_bytes);
+          std::memcpy(r < half_rows ? pin0 + (size_t)r * D : pin1 + (size_t)(r - half_rows) * D, host_Y + (size_t)row * D, row_bytes);
         }
       });
     for (auto& e : ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -409,7 +412,9 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
     smp_n.alloc((size_t)m_s * ldn);
     for (auto& t : workers) t.join();
     workers.clear();
-    HIP_CHECK(hipMemcpyAsync(smp_raw.p, pinned, (size_t)m_s * row_bytes, hipMemcpyHostToDevice, up));
+    HIP_CHECK(hipMemcpyAsync(smp_raw.p, pin0, (size_t)half_rows * row_bytes, hipMemcpyHostToDevice, up));
+    if (m_s > half_rows)
+      HIP_CHECK(hipMemcpyAsync(smp_raw.p + (size_t)half_rows * D, pin1, (size_t)(m_s - half_rows) * row_bytes, hipMemcpyHostToDevice, up));
     HIP_CHECK(hipEventRecord(sp.ev[0], up));
     HIP_CHECK(hipStreamWaitEvent(h.stream, sp.ev[0], 0));  // the sample image: unit rows of the gathered anchors, in sample order
     launch_normalize_rows(smp_raw.p, D, smp_n.p, ldn, m_s, D, h.stream);
@@ -581,7 +586,7 @@ static bool build_graph_once(L& h, const float* host_Y) {
     // 1, 1, 2, 2, 3, 4, 6, 8 chunks 16.7 / 30.3 -- the kernels run dry while the last large pieces travel --; 1, 1, 2, 2 then
     // threes 16.7 / 32.3 -- sixteen short sample sweeps fill the CUs badly.  From the third piece on the kernels are the
     // slower side, so nothing is gained by small first pieces either.)
-    if (host_Y != nullptr && h.create_stream && parts == 1 && h.comm == nullptr && pp.sym && !pp.tile_core && h.ld == h.D) {
+    if (host_Y != nullptr && h.create_stream && parts == 1 && h.comm == nullptr && pp.sym && (!pp.tile_core || pp.tile_wide) && h.ld == h.D) {
       const int64_t row_bytes = (int64_t)h.D * 4, chunk_rows = (int64_t)pp.T * 128;
       const int64_t smp_bytes = (int64_t)pp.sample_tiles * 128 * row_bytes;
       int64_t m = std::max<int64_t>(1, (((int64_t)h.create_piece_mb << 20) / row_bytes + chunk_rows - 1) / chunk_rows);
@@ -591,12 +596,15 @@ static bool build_graph_once(L& h, const float* host_Y) {
       // further; a wave's hit list takes 260 / NRG coarse entries from ONE tile (knn_gemm.hip: HB_CAP_SYM), i.e. 32 rows x
       // bound / tiles must stay below that: pieces of >= 32 x bound rows leave a factor of two.  (An explicit
       // OSC_CREATE_PIECE_MB overrides this: tests of the retry below.)
-      if (!h.create_piece_mb_set) m = std::max<int64_t>(m, ((int64_t)(32.0 * pp.hit_bound) * pp.nrg + chunk_rows - 1) / chunk_rows);
+      // (the wide tile core's lists are shorter and its wave tiles taller -- 64 rows, ~96 entries from one tile: 176 x bound rows;
+      // soak_streamed_create.py, 82 785 x 800, k = 16, grouped: pieces of 8192 rows overflowed and the build handed over)
+      const double min_rows = pp.tile_core ? 176.0 * pp.hit_bound : 32.0 * pp.hit_bound * pp.nrg;
+      if (!h.create_piece_mb_set) m = std::max<int64_t>(m, ((int64_t)min_rows + chunk_rows - 1) / chunk_rows);
       // (what is left over joins the last piece: a piece's rows are permuted among themselves only, so a short piece of
       // anchors that arrive cluster by cluster packs each cluster into few tiles -- 3072 rows holding 7.7 clusters of 401 gave
       // every row 17 cluster mates per column tile, more than a wave's hit list takes from one tile)
       const int64_t rows = m * chunk_rows, pieces = N / rows;
-      if (pieces >= 3 && (int64_t)N * row_bytes >= ((int64_t)h.create_min_mb << 20) && smp_bytes <= (int64_t)kStageBytes) {
+      if (pieces >= 3 && (int64_t)N * row_bytes >= ((int64_t)h.create_min_mb << 20) && smp_bytes <= 2 * (int64_t)kStageBytes) {
         for (int64_t j = 0; j < pieces; ++j) piece_starts.push_back((int32_t)(j * rows));
         knn_panel_set_pieces(pp, N, piece_starts.data(), (int)piece_starts.size());
       }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential soak of the STREAMED create (round 5; osc_graph.hip: stream_pieces -- the anchors reach the device in pieces of
 whole column chunks and the build works on what has arrived) against the whole-array create of the same anchors: random shapes
-with 64-400 MB of anchors (N 22k-260k, D 96-768: K depth 6 and 12, ragged and exact multiples of the 3072-row chunk), k 2-64,
+with 64-400 MB of anchors (N 8k-1M, D 96-2048: panel core at K depth 6 and 12, the wide tile core beyond 768 columns; ragged and
+exact multiples of the 3072-row chunk), k 2-64,
 i.i.d. / clustered-shuffled / grouped (cluster by cluster, cluster sizes 20-600) / duplicated-row anchors.  The lattices must be
 equal bit for bit (structure, capped adjacency, weights, sqrt degrees) -- or, where either build sent rows to the exact fp32
 kernel (printed), differ only in float64-proven rank-k near-ties of those routes' different summation orders, as between any
@@ -53,7 +54,7 @@ def create(Y, k, stream):
 
 
 for t in range(count):
-    D = int(rng.choice([96, 128, 200, 256, 320, 384, 385, 448, 512, 640, 700, 768]))
+    D = int(rng.choice([96, 128, 200, 256, 320, 384, 385, 448, 512, 640, 700, 768, 800, 896, 1152, 1280, 1536, 2048]))
     mb = float(rng.uniform(66, 400))
     N = int(mb * 1048576 / (4 * D))
     if t % 3 == 0:

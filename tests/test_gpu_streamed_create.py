@@ -50,7 +50,11 @@ def _snapshot(lat, psi):
 # N, D, k, anchors: >= 64 MB of anchors in >= 3 pieces; K depth 12 and 6 (two row groups per wave), ragged last pieces, a last
 # column chunk of 64 rows (40 000 = 13 chunks of 3072 rows + 64), a lattice that is a whole number of chunks and of pieces (64 512 = 21 x 3072)
 SHAPES = [(40000, 512, 16, "iid"), (30000, 768, 32, "clustered"), (60000, 384, 12, "iid"), (64512, 320, 8, "clustered"),
-          (60269, 768, 8, "grouped300"), (100000, 768, 32, "iid")]
+          (60269, 768, 8, "grouped300"), (100000, 768, 32, "iid"),
+          # D > 768: the wide tile core (k_tile_thr2) takes chunk windows too, in pieces of >= 176 x hit bound rows (42k at k = 12)
+          (140000, 896, 12, "grouped300"),
+          # a threshold sample of more than one staging buffer (35.8 MB: two transfers)
+          (140000, 768, 8, "iid")]
 
 
 @pytest.mark.parametrize("N,D,k,kind", SHAPES)
@@ -81,8 +85,8 @@ def test_streamed_create_builds_the_lattice_of_the_whole_array_build(N, D, k, ki
     lat.close()
 
 
-@pytest.mark.parametrize("N,D,k,why", [(12000, 256, 8, "12 MB of anchors"), (20000, 1024, 16, "padded row pitch, tile core"),
-                                         (24000, 1536, 16, "tile core (D > 768)"), (9000, 768, 160, "k > 128: dense rows + radix select")])
+@pytest.mark.parametrize("N,D,k,why", [(12000, 256, 8, "12 MB of anchors"), (20000, 1024, 16, "padded row pitch"),
+                                         (9000, 768, 160, "k > 128: dense rows + radix select")])
 def test_lattices_the_streamed_create_does_not_serve_take_the_whole_array_upload(N, D, k, why):
     Y = _anchors(N, D, "iid", seed=1)
     lat = _lattice(Y, k, stream=True)
