@@ -286,13 +286,13 @@ void exchange_buckets(L& h, const KnnPanelPlan& pp, const KnnPanelSymDev& sd, in
 // for most of its work, only part of them: column chunk c of the half sweep reads the image rows below (c + 1) T 128.  So:
 //   * the anchors travel in `pieces` of whole column chunks on a second stream (pageable source: the call returns when the
 //     piece is on its way; an event per piece);
-//   * the column SAMPLE the thresholds come from -- sample row t = image row t N / m, lattice rows spread over the whole
-//     array -- is gathered on the host into pinned memory by a few threads while piece 0 travels, and follows it;
+//   * the column SAMPLE the thresholds come from -- an even stride of lattice rows over the whole array (knn_rowmap.hpp) --
+//     is gathered on the host into pinned memory by a few threads while piece 0 travels, and follows it;
 //   * behind piece j the build stream runs: U's rows, unit rows, image rows (the piece's own permutation: KnnRowMap), the
 //     sample sweep and thresholds of the piece's row blocks, and the main sweep's work items of the piece's column chunks.
 // What is left when the last piece has landed is that piece's share of the sweep plus select / re-scoring / graph assembly.
-// The lists are those of the whole-array build bit for bit (they are exact top-k lists under one total order; thresholds
-// and candidate sets differ with the image's row order, as they do between scatter on and off).
+// The lists are those of the whole-array build bit for bit: exact top-k lists under one total order, from the same sample,
+// hence the same thresholds, the same hits and the same rows proven (only the order of a bucket's entries differs).
 void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts, const KnnPanelPlan& pp, float* Yn, int32_t ldn, float* p_img,
                    float* p_smp, float* p_tmax, float* p_tau, unsigned* p_queue, const KnnPanelSymDev& sym_dev, int cus, DevBuf<float>& smp_raw,
                    DevBuf<float>& smp_n) {
@@ -311,14 +311,21 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
   // piece j + 1's kernels would wait for the last straggler of piece j's sweep.
   hipStream_t up = acquire_stream(h.device), second = acquire_stream(h.device);
   hipStream_t cs[2] = {h.stream, second};
-  const StagePair sp = acquire_stage(h.device);
+  StagePair sp;
+  try {
+    sp = acquire_stage(h.device);
+  } catch (...) {
+    release_stream(h.device, up);
+    release_stream(h.device, second);
+    throw;
+  }
   // events: [j] piece j has landed, [pieces + j] the thresholds of all rows up to piece j's are written, then: everything
   // the caller queued before this call is done / the sample image is written / the second stream has drained
   std::vector<hipEvent_t> ev((size_t)2 * pieces + 3, nullptr);
   hipEvent_t &ev_start = ev[(size_t)2 * pieces], &ev_sample = ev[(size_t)2 * pieces + 1], &ev_done = ev[(size_t)2 * pieces + 2];
   // The host side: a copy from pageable memory returns when the data has left, so the calling thread issues the transfers
   // one by one and queues a piece's kernels behind each; a few threads gather the sample's rows into pinned memory
-  // meanwhile (started first: the sample is what the first threshold waits for), and the sample follows the second piece.
+  // meanwhile (started first: the sample is what the first threshold waits for), and the sample follows the first piece.
   // (Issuing the transfers from a thread of their own closed the 0.08 ms gaps between them and cost 0.4 ms at the start --
   // a new thread's first HIP call -- for a build that is bound by the kernels from the third piece on: not kept.)
   std::vector<std::thread> workers;
