@@ -364,19 +364,23 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
           std::memcpy(r < half_rows ? pin0 + (size_t)r * D : pin1 + (size_t)(r - half_rows) * D, host_Y + (size_t)row * D, row_bytes);
         }
       });
-    for (auto& e : ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(ev_start, h.stream));
-    HIP_CHECK(hipStreamWaitEvent(second, ev_start, 0));
+    // (events are made when first used: twenty-odd creations are 0.1 ms the first transfer need not wait for)
+    auto E = [&](hipEvent_t& e) -> hipEvent_t {
+      if (e == nullptr) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      return e;
+    };
+    HIP_CHECK(hipEventRecord(E(ev_start), h.stream));
+    HIP_CHECK(hipStreamWaitEvent(second, E(ev_start), 0));
     auto send_piece = [&](int j) {
       const int32_t r0 = row0(j), r1 = row0(j + 1);
       HIP_CHECK(hipMemcpyAsync(h.Y.p + (size_t)r0 * h.ld, host_Y + (size_t)r0 * D, (size_t)(r1 - r0) * row_bytes, hipMemcpyHostToDevice, up));
-      HIP_CHECK(hipEventRecord(ev[(size_t)j], up));
+      HIP_CHECK(hipEventRecord(E(ev[(size_t)j]), up));
     };
     // behind piece j's arrival: U's rows, unit rows, image rows
     auto queue_rows = [&](int j) {
       hipStream_t s = cs[j & 1];
       const int32_t r0 = row0(j), r1 = row0(j + 1);
-      HIP_CHECK(hipStreamWaitEvent(s, ev[(size_t)j], 0));
+      HIP_CHECK(hipStreamWaitEvent(s, E(ev[(size_t)j]), 0));
       HIP_CHECK(hipMemcpyAsync(h.U.p + (size_t)r0 * h.ld, h.Y.p + (size_t)r0 * h.ld, (size_t)(r1 - r0) * h.ld * 4, hipMemcpyDeviceToDevice, s));
       launch_normalize_rows(h.Y.p + (size_t)r0 * h.ld, h.ld, Yn + (size_t)r0 * ldn, ldn, r1 - r0, D, s);
       launch_panel_image(Yn, ldn, p_img, pp, N, D, s, r0, j + 1 == pieces ? pp.npad : r1);
@@ -387,7 +391,7 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
       unsigned* q = p_queue + 4 * j;
       const int32_t r0 = row0(j), r1 = row0(j + 1);
       const bool last = j + 1 == pieces;
-      if (j & 1) HIP_CHECK(hipStreamWaitEvent(s, ev_sample, 0));  // (the sample image was written on the first stream)
+      if (j & 1) HIP_CHECK(hipStreamWaitEvent(s, E(ev_sample), 0));  // (the sample image was written on the first stream)
       const int rb0 = r0 / 128, rb1 = last ? pp.nrb : r1 / 128;
       KnnPanelPlan pj = pp;  // (splits of the sample sweep chosen for THIS many row blocks)
       const int nsets = (rb1 - rb0 + pp.nrg - 1) / pp.nrg;
@@ -404,8 +408,8 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
       launch_panel_tilemax(p_img, p_smp, pj, N, rb0, rb1 - rb0, p_tmax, q, std::max(1, std::min(cus, nsets * pj.SA)), s);
       launch_panel_tau(p_tmax, pp, N, p_tau, s, rb0 * 128, rb1 * 128);
       // (the sweep reads the image rows and thresholds of ALL pieces up to this one: the other stream wrote piece j - 1's)
-      if (j > 0) HIP_CHECK(hipStreamWaitEvent(s, ev[(size_t)pieces + j - 1], 0));
-      HIP_CHECK(hipEventRecord(ev[(size_t)pieces + j], s));
+      if (j > 0) HIP_CHECK(hipStreamWaitEvent(s, E(ev[(size_t)pieces + j - 1]), 0));
+      HIP_CHECK(hipEventRecord(E(ev[(size_t)pieces + j]), s));
       const int c0 = r0 / chunk_rows, c1 = last ? pp.S : r1 / chunk_rows;
       if (c1 > c0)
         launch_panel_filter(p_img, pp, N, 0, pp.nrb, p_tau, sym_dev.bucket_ent, sym_dev.bucket_cnt, q + 1, cus, s, &sym_dev, 0, 1, c0, c1);
@@ -426,15 +430,15 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
     HIP_CHECK(hipStreamWaitEvent(h.stream, sp.ev[0], 0));  // the sample image: unit rows of the gathered anchors, in sample order
     launch_normalize_rows(smp_raw.p, D, smp_n.p, ldn, m_s, D, h.stream);
     launch_panel_sample_rows(smp_n.p, ldn, p_smp, pp, m_s, D, h.stream);
-    HIP_CHECK(hipEventRecord(ev_sample, h.stream));
+    HIP_CHECK(hipEventRecord(E(ev_sample), h.stream));
     for (int j = 0; j < lead; ++j) queue_sweep(j);
     for (int j = lead; j < pieces; ++j) {
       send_piece(j);
       queue_rows(j);
       queue_sweep(j);
     }
-    HIP_CHECK(hipEventRecord(ev_done, second));
-    HIP_CHECK(hipStreamWaitEvent(h.stream, ev_done, 0));
+    HIP_CHECK(hipEventRecord(E(ev_done), second));
+    HIP_CHECK(hipStreamWaitEvent(h.stream, E(ev_done), 0));
     HIP_CHECK(hipStreamSynchronize(up));  // (the caller's array is free again; the pinned buffer and the events go back)
     HIP_CHECK(hipStreamSynchronize(second));
   } catch (...) {
