@@ -689,15 +689,19 @@ def extras(lat, N, D, args, sharded):
     flops = 2.0 * N * N * D
     tf = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     world = int(os.environ.get("WORLD_SIZE", "1")) if sharded else 1
-    # flops the matrix pipe really issues: the panel route sweeps half the tiles on one GPU (all of them
-    # when the build is sharded) plus the threshold sample, a strided 1 / rho of the columns, rho = (k + 16) / 4
+    # flops the matrix pipe really issues: the panel route's main sweep plus the threshold sample, a
+    # strided 1 / rho of the columns, rho = (k + 16) / 4.  The main sweep's share comes from the library's own record of the
+    # last build (build_info()["knn_sweep"]: 2 = the half sweep, ONE per build at every world size since the ranks of a
+    # sharded build split its work items; 1 = a full sweep), not from WORLD_SIZE
     rho = (args.k + 16) / 4.0
-    executed = flops * ((0.5 if world == 1 else 1.0) + 1.0 / rho) if info["prefilter"] == 2 else flops
+    sweep_share = {2: 0.5, 1: 1.0}.get(info["knn_sweep"], 1.0)
+    executed = flops * (sweep_share + 1.0 / rho) if info["prefilter"] == 2 else flops
     tf_exec = executed / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     knn = {"route": route, "build_device_ms": float(np.median(builds)), "gemm_topk_ms": gemm_ms,
            "flops": flops / world, "achieved": tf / world, "peak": peak, "unit": "TFLOP/s", "frac": tf / world / peak,
            "executed_flops": executed / world, "executed_achieved": tf_exec / world, "executed_frac": tf_exec / world / peak,
-           "bound": "mfma", "fallback_rows": info["fallback_rows"]}
+           "bound": "mfma", "fallback_rows": info["fallback_rows"],
+           "main_sweep": {2: "half", 1: "full"}.get(info["knn_sweep"], "none"), "main_sweep_share_of_tiles": sweep_share}
     ustar = []
     for _ in range(5):
         lat._solve_ustar_device(lat._signature(), 1e-4, 64, True)

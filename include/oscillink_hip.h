@@ -235,7 +235,10 @@ int osc_dynamics(osc_handle h, const float* U_prev_or_null, const float* U_next_
  * (0 = two 8-wave workgroups per CU, one gather round in flight; 1..6 = one workgroup per CU, four rounds in flight,
  * 8 / 12 / 16 / 20 / 24 / 28 row groups per wave; OSC_BLK_VARIANT forces one), *total_ms = 0.  which = 15: *launches = the
  * pieces the last graph build received its anchors in (0: they were resident before it started; negative: a streamed build
- * gave up on overflowing hit lists and the whole-array build ran instead), *total_ms = 0. */
+ * gave up on overflowing hit lists and the whole-array build ran instead), *total_ms = 0.  which = 16: *launches = the main
+ * sweep of the last build's thresholds-and-hits prefilter (0: another route built the lists; 1: every rank swept every column
+ * tile for its row blocks; 2: the symmetric half sweep, ONE per build whatever the world size -- the ranks of a sharded build
+ * split its work items), *total_ms = 0. */
 int osc_profile_enable(osc_handle h, int32_t on);
 int osc_profile_reset(osc_handle h);
 int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* total_ms);

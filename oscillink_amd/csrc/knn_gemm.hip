@@ -118,25 +118,50 @@ struct PanelArgs {
   int32_t item_begin, item_end;
 };
 
-// LDS-DMA of one 1 KiB piece: M0 = LDS destination - K offset, the K offset rides in the immediate
-#define OSC_PIECE(SRC, KT, STAGE, Q)                                                                                  \
-  do {                                                                                                               \
-    unsigned keep_;                                                                                                  \
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0" \
-                 : "=&s"(keep_)                                                                                      \
-                 : "v"(SRC), "s"(fill_base + (unsigned)((STAGE) * STAGE_BYTES + (Q) * 1024) - (unsigned)((KT) * 128)), \
-                   "n"((KT) * 128)                                                                                   \
-                 : "memory");                                                                                        \
-  } while (0)
+// ---- the K loop's instructions, each an asm statement of its own: they issue in the order they are written (round 6) ----
+// Until round 5 a k16 slice was [fragment reads][MFMAs back to back][DMA pieces of five instructions] between scheduling
+// fences: the 24 issue cycles an MFMA leaves free stayed empty and everything else was issued between the groups, where
+// only the last MFMA's tail covers it.  Now every instruction of the loop is placed by hand, at most two single-issue
+// instructions behind an MFMA (MI355X_MICROARCH.md: <= 5 hide per v_mfma_f32_32x32x16 gap); hipcc's own s_waitcnt
+// insertion knows nothing of these loads, so the counted waits are written out too (LDS returns in order: a wait that
+// also covers compiler-issued LDS traffic only waits longer).
+#define OSC_RD(DST, ABASE, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ABASE), "n"(OFF))
+#define OSC_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_))
+#define OSC_VMC(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
+// LDS-DMA of one 1 KiB piece of K step KT: M0 = LDS destination - K offset (ONE s_add; nothing else in the kernel touches
+// M0 -- checked in the disassembly), the K offset rides in the load's immediate, which the hardware adds to the global
+// address AND to the LDS destination.  An MFMA (or the prologue's s_nop) sits between the M0 write and the load.
+#define OSC_SETM0(KT, STG_, Q) \
+  asm volatile("s_add_i32 m0, %0, %1" ::"s"(fill_base), "n"((unsigned)((STG_) * STG + (Q) * 1024 - (KT) * 128)) : "scc")
+// (source = scalar base of the pass + the lane's 32-bit byte offset within it: the pass-to-pass advance is scalar arithmetic and a
+// lane keeps NT offsets instead of 2 NT pointer pairs -- the two-row-group shape at D = 768 has no vector register to spare)
+#define OSC_DMA(VOFF, SBASE, KT) \
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(VOFF), "s"(SBASE), "n"((KT) * 128) : "memory")
 
 template <int NKT, int MODE, int NRG, bool SYM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_panel(const PanelArgs a) {
-  static_assert(NKT % RING == 0, "a tile's K steps must be whole laps of the ring (compile-time stage indices)");
   static_assert(NRG == 1 || NRG == 2, "row groups per wave");
   static_assert(!SYM || MODE == 1, "the half sweep is a form of the main sweep");
+  // Round 6: D <= 768 with TWO row groups.  2 x 192 panel registers + eight accumulators do not fit 512, so the K loop of
+  // that shape covers 64 columns per pass (NT = 2 subtiles, four 32 x 32 accumulators, two passes per 128-column tile, the
+  // epilogue behind each pass on its two subtiles): every B fragment feeds two MFMAs, half the fragment reads and half the
+  // LDS-DMA bytes per MFMA.  The sweep is POWER-bound (scripts/exp/r06/README.md: the shader clock settles near 1.75 GHz
+  // and every cycle saved by scheduling alone comes back as a lower clock), so bytes moved per flop are what count.
+  constexpr int NT = (NKT == 12 && NRG == 2) ? 2 : 4;   // 32-column subtiles per K-loop pass
+  constexpr int NPASS = 4 / NT;                          // passes per 128-column tile
+  constexpr unsigned STG = NT * 4096u;                   // bytes of one stage: 32 NT columns x 128 B (one K step)
+  constexpr int NSTG = (int)(RING * STAGE_BYTES / STG);  // 6 / 12 stages in the same 96 KB
+  constexpr int GK = NT == 4 ? 2 : 3;                    // K steps per barrier group
+  constexpr int LA = 2;                                  // groups fetched ahead
+  constexpr int NG = NKT / GK;
+  constexpr int MM = NRG * NT;                           // MFMAs per k16 slice
+  constexpr int APAN = 32;                               // k16 slices of a row group's panel in AGPRs where two groups need 384 registers (the rest in VGPRs)
+  constexpr int HS = NT == 4 ? 3 : 8;                    // stages behind the low / high fragment base (16-bit offset field)
+  static_assert(NKT % NSTG == 0 || NSTG == NKT, "a pass's K steps must be whole laps of the ring (compile-time stage indices)");
+  static_assert(NKT % GK == 0 && (LA + 1) * GK <= NSTG && LA >= 2 && LA < NG, "ring plan");
   constexpr int NK16 = NKT * 4;
   constexpr int HCAP = (SYM ? HB_CAP_SYM : HB_CAP) / NRG;  // entries of one (row group, wave) hit list
-  extern __shared__ __attribute__((aligned(1024))) float lds[];  // RING stages x [128 rows][32 float slots] (+2 KB lead)
+  extern __shared__ __attribute__((aligned(1024))) float lds[];  // NSTG stages x [32 NT rows][32 float slots] (+2 KB lead)
   __shared__ int s_item, s_chunk, s_first;
   __shared__ __attribute__((aligned(16))) float s_tau[4][NRG][2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,11 +169,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int frow = lane >> 3;
   const int swz = (l31 >> 1) & 7;
   const unsigned lds_base = (unsigned)(size_t)lds + 2048u;
-  const unsigned fill_base = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(32 * wave * 128));
-  unsigned rd[4];  // fragment read base of k16 slice s: row l31, chunk (2 s + h) ^ swz   (+ stage, + subtile * 4096)
+  const unsigned fill_base = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(8 * NT * wave * 128));
+  // fragment read bases (absolute LDS byte addresses) of k16 slice s: row l31, chunk (2 s + h) ^ swz   (+ stage, + subtile * 4096)
+  unsigned rlo[4], rhi[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) rd[s] = (unsigned)(l31 * 128 + (((2 * s + h) ^ swz) * 16));
-  const char* ldsc = reinterpret_cast<const char*>(lds) + 2048;
+  for (int s = 0; s < 4; ++s) {
+    rlo[s] = lds_base + (unsigned)(l31 * 128 + (((2 * s + h) ^ swz) * 16));
+    rhi[s] = rlo[s] + (unsigned)HS * STG;
+  }
   const int nsets = (a.rb_count + NRG - 1) / NRG;  // work item = (column split, set of NRG consecutive row blocks)
   // SYM: chunk c (T tiles) is swept by the row blocks I < min(nrb, (c + 1) T), i.e. by all nrb of them in the last chunk
   // and by (c + 1) T in the others, so the item and list tables have closed forms (host copies: knn_panel_sym_tables):
@@ -264,17 +292,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (l31 < 16) s_tau[wave][r][h][l31] = a.tau[grow0 + (l31 & 3) + 8 * (l31 >> 2)];
       }
     }
-    // source of piece q of this wave's share of a column tile: row 32 wave + 8 q + frow of the tile, swizzled chunk
-    const _Float16* bsrc[4];
+    // source of piece q of this wave's share of a pass's columns: row 8 NT wave + 8 q + frow of the pass, swizzled chunk
+    unsigned boff[NT];  // byte offset within the pass's columns
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      bsrc[q] = a.B + (size_t)t0 * tile_stride + (size_t)(32 * wave + 8 * q + frow) * ldh +
-                ((lane & 7) ^ (((q & 1) << 2) | (frow >> 1))) * 8;
+    for (int q = 0; q < NT; ++q)
+      boff[q] = (unsigned)(((size_t)(8 * NT * wave + 8 * q + frow) * ldh + ((lane & 7) ^ (((q & 1) << 2) | (frow >> 1))) * 8) * 2);
+    const size_t pass_stride = (size_t)(32 * NT) * ldh;  // halfs between passes
+    const _Float16* pbase;  // first column of the pass to run next (wave-uniform, kept scalar)
+    {
+      const size_t pb = reinterpret_cast<size_t>(a.B + (size_t)t0 * tile_stride);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pb), hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+      pbase = reinterpret_cast<const _Float16*>(((size_t)hi << 32) | lo);
+    }
 #pragma unroll
-    for (int st = 0; st < 4; ++st)
+    for (int kt = 0; kt < LA * GK; ++kt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { OSC_PIECE(bsrc[q], st, st, q); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int q = 0; q < NT; ++q) {
+        OSC_SETM0(kt, kt, q);
+        asm volatile("s_nop 0");
+        OSC_DMA(boff[q], pbase, kt);
+      }
+    OSC_VMC(0);
     __syncthreads();
     // ---- one column tile: the K loop, then the tile's epilogue on its accumulators.  Moving the hit test into the
     // next tile's K loop was tried twice and dropped: with a second accumulator set hipcc spills 51 registers next to the
@@ -282,15 +320,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // groups it runs, correctly, no faster (17.6 vs 17.0 ms) -- the K loop of a lone wave per SIMD is bound by its own
     // instruction issue (32 MFMAs, 32 fragment reads, 8 DMA pieces of ~5 instructions per pair), not by the matrix pipe,
     // so VALU work placed there is not hidden.
-    f32x16 acc[NRG][4];
+    f32x16 acc[NRG][NT];
     // tc[t]: SYM, the threshold of this lane's column of subtile t (+inf where the column side does not apply: the
     // diagonal tile, whose pairs are all met on the row side, and columns beyond N)
     auto row_mask = [&](auto GC, const f32x16(&pa)[4], const float(&tg)[16], const float(&tc)[4]) -> unsigned long long {
       constexpr int g = decltype(GC)::value;
-      bool any = fmaxf(fmaxf(pa[0][g], pa[1][g]), fmaxf(pa[2][g], pa[3][g])) > tg[g];
-      if constexpr (SYM)  // (bitwise or: both sides are plain compares, no lane-divergent branch wanted here)
-        any = any | (fmaxf(fmaxf(pa[0][g] - tc[0], pa[1][g] - tc[1]), fmaxf(pa[2][g] - tc[2], pa[3][g] - tc[3])) > 0.f);
-      return __ballot(any);
+      (void)tc;
+      return __ballot(fmaxf(fmaxf(pa[0][g], pa[1][g]), fmaxf(pa[2][g], pa[3][g])) > tg[g]);
+    };
+    // SYM, the union test of a row register: "some score of this (row register, lane) beats its row's threshold or its
+    // column's".  Round 6: ONE compare against min(tau_row, the smallest of the lane's column thresholds) instead of a
+    // compare per side with a subtraction per subtile (4 VALU per register instead of 11) -- a superset of the exact
+    // union (any score above its own column's threshold is above the smallest one), and the flush decides every score
+    // against its own two thresholds anyway: the lists gain a few coarse entries whose scores all fail there.
+    auto row_mask_u = [&](auto GC, const f32x16(&pa)[NT], const float(&tg)[16], const float tcmin) -> unsigned long long {
+      constexpr int g = decltype(GC)::value;  // NT = 4: the row register; NT = 2: the PAIR of row registers 2 g, 2 g + 1 (rows rl, rl + 1)
+      if constexpr (NT == 4) {
+        return __ballot(fmaxf(fmaxf(pa[0][g], pa[1][g]), fmaxf(pa[2][g], pa[3][g])) > fminf(tg[g], tcmin));
+      } else {
+        const float m = fmaxf(fmaxf(pa[0][2 * g], pa[1][2 * g]), fmaxf(pa[0][2 * g + 1], pa[1][2 * g + 1]));
+        return __ballot(m > fminf(fminf(tg[2 * g], tg[2 * g + 1]), tcmin));
+      }
     };
     auto hit_rows = [&](auto GC, const f32x16(&pa)[4], const float(&tg)[16], const float(&tc)[4], int pct, int rb, uint2* hb, int& wc) {  // query-row register g of the tile pct has a hit
       constexpr int g = decltype(GC)::value;
@@ -329,67 +379,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (fm[decltype(GC)::value] != 0ull) hit_rows(GC, pa, tg, tc, pct, rb, hb, wc);
       });
     };
-    auto k_loop = [&](int ct) {
-      const bool last_tile = ct + 1 == t1;
-      const _Float16* nsrc[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) nsrc[q] = bsrc[q] + tile_stride;
-      // K steps in pairs (one barrier per 32 MFMAs): pair pr reads stages (2 pr) % 6, (2 pr + 1) % 6 and fetches the pair
-      // two pairs ahead (of this tile or the next) into the stages the previous pair has released
-      static_for<0, NKT / 2>([&](auto PR) {
-        constexpr int pr = decltype(PR)::value;
-        constexpr bool next_tile = 2 * pr + 4 >= NKT;
-        const bool fetch = !(next_tile && last_tile);
-        v4f fa[4], fb[4];
-        auto read_frags = [&](int st, int sl, v4f(&bv)[4]) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) bv[t] = *(const v4f*)(ldsc + rd[sl] + st * STAGE_BYTES + t * 4096);
-        };
-        read_frags((2 * pr) % RING, 0, fa);
-        static_for<0, 8>([&](auto UU) {  // eight k16 slices: two K steps
-          constexpr int u = decltype(UU)::value;
-          constexpr int kt = 2 * pr + (u >> 2), sl = u & 3;
-          v4f(&cur)[4] = (u & 1) ? fb : fa;
-          v4f(&nxt)[4] = (u & 1) ? fa : fb;
-          if constexpr (u + 1 < 8) read_frags((2 * pr + ((u + 1) >> 2)) % RING, (u + 1) & 3, nxt);
-          __builtin_amdgcn_sched_barrier(0);
-          // The MFMAs are written as asm to pin the register classes: the panel (srcA) in ACCUMULATION registers, the
-          // accumulators in VECTOR registers.  hipcc's own choice was the reverse for the accumulators, which cost a
-          // v_accvgpr_read per value in the hit test (VALU compares cannot read AGPRs) and shuffled panel slices
-          // between the two files every tile.  The tile's first slice starts from C = 0 (inline constant).
-#pragma unroll
-          for (int r = 0; r < NRG; ++r)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              if constexpr (pr == 0 && u == 0)
-                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[r][t]) : "a"(areg[r][kt * 4 + sl]), "v"(cur[t]));
-              else
-                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[r][t]) : "a"(areg[r][kt * 4 + sl]), "v"(cur[t]));
-            }
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (u < 4) {
-            if (fetch) {  // two DMA pieces behind each of the first four MFMA groups
-              constexpr int fk = (2 * pr + 4 + (u >> 1)) % NKT, fst = (2 * pr + 4 + (u >> 1)) % RING;
-              constexpr int qa = 2 * (u & 1);
-              if constexpr (next_tile) {
-                OSC_PIECE(nsrc[qa], fk, fst, qa);
-                OSC_PIECE(nsrc[qa + 1], fk, fst, qa + 1);
-              } else {
-                OSC_PIECE(bsrc[qa], fk, fst, qa);
-                OSC_PIECE(bsrc[qa + 1], fk, fst, qa + 1);
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        });
-        if (fetch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the pair fetched during this pair stays in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // raw barrier: __syncthreads() would make hipcc drain vmcnt for later stores, and with them the DMA pieces meant
-        // to stay in flight; every ds_read of the pair has been consumed by its MFMAs already
-        __builtin_amdgcn_s_barrier();
+    // ---- one pass of the K loop: 32 NT columns against the wave's NRG row groups, all NKT K steps; hand-placed.
+    // Slice (k16) of MM = NRG NT MFMAs, j = r NT + t on fragment t:
+    //   NT = 4:  [wait cur 0,1] m0  RD nxt0 nxt1   m1  [M0 if MM = 4]   [wait cur 2,3] m2  RD nxt2 nxt3   m3 ... m(MM-2) [M0]  m(MM-1) [DMA]
+    //   NT = 2:  [wait cur 0]   m0  RD nxt0   [wait cur 1] m1  RD nxt1   m2 [M0]   m3 [DMA]      (a piece every second slice)
+    // K steps in groups of GK behind one workgroup barrier; the group LA ahead (of this pass or the next) is fetched during a
+    // group, one piece per slice (NT = 4) / two slices (NT = 2).  The barrier sits BEFORE the group's last slice, whose
+    // fragments are in registers by then (lgkmcnt(0): the wave is done with the group's stages; vmcnt: its own pieces of the
+    // next group have landed), so the first slice of the next group is read behind the barrier under that slice's MFMAs.
+    // The pass's first fragments are read at its start (nothing is carried across the epilogue).
+    auto k_pass = [&](auto LASTC) {
+      constexpr bool last_pass = decltype(LASTC)::value;  // the item's last pass: there is no next one to fetch
+      const _Float16* const nbase = pbase + pass_stride;
+      v4f fa[NT], fb[NT];
+#define OSC_RD_AT(DST, ST, SL, T)                                            \
+  do {                                                                        \
+    if constexpr ((ST) < HS) OSC_RD(DST, rlo[SL], (ST) * STG + (T) * 4096);   \
+    else OSC_RD(DST, rhi[SL], ((ST) - HS) * STG + (T) * 4096);                \
+  } while (0)
+      static_for<0, NT>([&](auto TC) { OSC_RD_AT(fa[decltype(TC)::value], 0, 0, decltype(TC)::value); });
+      static_for<0, 4 * NKT>([&](auto SS) {
+        constexpr int sx = decltype(SS)::value;
+        constexpr int kt = sx >> 2, sl = sx & 3, g = kt / GK, ug = sx % (4 * GK);
+        constexpr bool group_end = ug == 4 * GK - 1, has_next = sx + 1 < 4 * NKT;
+        constexpr int nst = ((sx + 1) >> 2) % NSTG, nsl = (sx + 1) & 3;
+        constexpr bool next_pass = g + LA >= NG;
+        constexpr int fg = (g + LA) % NG;  // the group fetched during this one
+        constexpr bool fetch = !(next_pass && last_pass);
+        // the piece this slice carries: NT = 4 one per slice, NT = 2 one per two slices (the odd ones)
+        constexpr bool has_piece = fetch && (NT == 4 || (ug & 1) == 1);
+        constexpr int pi = NT == 4 ? ug : ug >> 1;  // piece of the group: K step pi / NT of it, part pi % NT
+        constexpr int fk = fg * GK + pi / NT, pq = pi % NT, fst = fk % NSTG;
+        constexpr int ai = kt * 4 + sl;
+        v4f(&cur)[NT] = (sx & 1) ? fb : fa;
+        v4f(&nxt)[NT] = (sx & 1) ? fa : fb;
+        const _Float16* const psrc = next_pass ? nbase : pbase;
+        // (panel slices in ACCUMULATION registers, accumulators in VECTOR registers: hipcc's own choice was the reverse for
+        // the accumulators, which cost a v_accvgpr_read per value in the hit test; where two row groups need 384 panel
+        // registers the slices from APAN on live in vector registers.  The pass's first slice starts from C = 0.)
+#define OSC_MFMA(J)                                                                                                              \
+  do {                                                                                                                           \
+    constexpr int r_ = (J) / NT, t_ = (J) % NT;                                                                                  \
+    if constexpr (NRG * NK16 * 4 <= 256 || ai < APAN) {                                                                          \
+      if constexpr (sx == 0)                                                                                                     \
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[r_][t_]) : "a"(areg[r_][ai]), "v"(cur[t_]));            \
+      else                                                                                                                       \
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[r_][t_]) : "a"(areg[r_][ai]), "v"(cur[t_]));            \
+    } else {                                                                                                                     \
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[r_][t_]) : "v"(areg[r_][ai]), "v"(cur[t_]));              \
+    }                                                                                                                            \
+  } while (0)
+#define OSC_RDN(T)                                            \
+  do {                                                        \
+    if constexpr (has_next) OSC_RD_AT(nxt[T], nst, nsl, T);   \
+  } while (0)
+        if constexpr (group_end) {
+          OSC_LGKM(0);
+          if constexpr (fetch) OSC_VMC((LA - 1) * GK * NT - 1); else OSC_VMC(0);
+          // raw barrier: __syncthreads() would make hipcc drain vmcnt, and with it the pieces meant to stay in flight
+          __builtin_amdgcn_s_barrier();
+        } else {
+          OSC_LGKM(NT / 2);
+        }
+        // (written out per MFMA: asm operands inside a third level of generic lambdas trip clang's implicit captures)
+#define OSC_STEP(J)                                                                                               \
+  do {                                                                                                            \
+    if constexpr ((J) < MM) {                                                                                     \
+      if constexpr (!group_end && ((NT == 4 && (J) == 2) || (NT == 2 && (J) == 1))) OSC_LGKM(NT / 2);             \
+      OSC_MFMA(J);                                                                                                \
+      if constexpr (NT == 4 && (J) == 0) { OSC_RDN(0); OSC_RDN(1); }                                              \
+      if constexpr (NT == 4 && (J) == 2) { OSC_RDN(2 % NT); OSC_RDN(3 % NT); }                                         \
+      if constexpr (NT == 2 && (J) == 0) OSC_RDN(0);                                                              \
+      if constexpr (NT == 2 && (J) == 1) OSC_RDN(1);                                                              \
+      if constexpr (has_piece && (J) == (MM == 4 && NT == 4 ? 1 : MM - 2)) OSC_SETM0(fk, fst, pq);                \
+      if constexpr (has_piece && (J) == MM - 1) OSC_DMA(boff[pq], psrc, fk);                                    \
+    }                                                                                                             \
+  } while (0)
+        OSC_STEP(0);
+        OSC_STEP(1);
+        OSC_STEP(2);
+        OSC_STEP(3);
+        OSC_STEP(4);
+        OSC_STEP(5);
+        OSC_STEP(6);
+        OSC_STEP(7);
       });
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bsrc[q] = nsrc[q];
+      pbase = nbase;
+    };
+    auto k_loop = [&](int ct, int pass) {
+      if (ct + 1 == t1 && pass + 1 == NPASS) k_pass(std::true_type{});
+      else k_pass(std::false_type{});
     };
     // SYM: take the coarse entries of row group r apart and deliver the hits to the buckets of their receiving rows (a lane
     // per entry).  Runs at the end of the item, and earlier whenever the list is more than half full.
@@ -411,36 +490,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const v4f* const sc = s_sc + (wave * NRG + r) * HCAP;
         const float* const taur = &s_tau[wave][r][0][0];  // [half][row register]
         const int grow0 = rb * 128 + 32 * wave;
-        // one lane per coarse entry: score t of the entry is a candidate of its row (row side) and / or of its column
-        auto take_apart = [&](int e, int& rl, int& tl, int& l5, v4f& sv, bool (&rp)[4], bool (&cp)[4]) {
+        // one lane per coarse entry: score t of the entry is a candidate of its row (row side) and / or of its column.
+        // NT = 4: the entry is one row register's four subtile scores (row rl, subtiles 0-3).  NT = 2 (64-column passes): the
+        // scores of a PAIR of row registers on the pass's two subtiles -- t = 0, 1: row rl, t = 2, 3: row rl + 1, subtile
+        // 2 pass + (t & 1) -- so that an entry stands for four scores in either shape (one union test per four scores).
+        auto row_of = [&](int rl, int t) { return NT == 4 ? rl : rl + (t >> 1); };
+        auto sub_of = [&](int ps, int t) { return NT == 4 ? t : 2 * ps + (t & 1); };
+        auto take_apart = [&](int e, int& rl, int& tl, int& l5, int& ps, v4f& sv, bool (&rp)[4], bool (&cp)[4]) {
           const bool valid = e < n;
           const unsigned hdv = valid ? hd[e] : 0u;
-          rl = (int)(hdv >> 10);
+          rl = (int)((hdv >> 10) & 31u);
+          ps = (int)((hdv >> 15) & 1u);
           tl = (int)((hdv >> 5) & 31u);
           l5 = (int)(hdv & 31u);
           sv = valid ? sc[e] : v4f{0.f, 0.f, 0.f, 0.f};
           const int ct = t0 + tl;
-          const float trow = taur[((rl >> 2) & 1) * 16 + (rl & 3) + 4 * (rl >> 3)];
           v4f tcv = v4f{3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
           if (valid && ct > rb) tcv = *reinterpret_cast<const v4f*>(&s_tc[tl * 128 + l5 * 4]);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const int col = ct * 128 + 32 * t + l5;
-            rp[t] = valid && sv[t] > trow && col != grow0 + rl && col < a.N;  // graph.py:37: no self-similarity; the ragged tail
-            cp[t] = valid && sv[t] > tcv[t];
+            const int row = row_of(rl, t), sub = sub_of(ps, t);
+            const float trow = taur[((row >> 2) & 1) * 16 + (row & 3) + 4 * (row >> 3)];
+            const int col = ct * 128 + 32 * sub + l5;
+            rp[t] = valid && sv[t] > trow && col != grow0 + row && col < a.N;  // graph.py:37: no self-similarity; the ragged tail
+            cp[t] = valid && sv[t] > tcv[sub];
           }
         };
         for (int b = lane; b < nbl; b += 64) s_cnt[b] = 0;
         int nrow = 0;
         for (int e0 = 0; e0 < n; e0 += 64) {  // (a wave's LDS accesses complete in order: no barrier between these passes)
-          int rl, tl, l5;
+          int rl, tl, l5, ps;
           v4f sv;
           bool rp[4], cp[4];
-          take_apart(e0 + lane, rl, tl, l5, sv, rp, cp);
+          take_apart(e0 + lane, rl, tl, l5, ps, sv, rp, cp);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             nrow += __popcll(__ballot(rp[t]));
-            if (cp[t]) atomicAdd(&s_cnt[tl * 4 + t], 1);
+            if (cp[t]) atomicAdd(&s_cnt[tl * 4 + sub_of(ps, t)], 1);
           }
         }
         int rbase = 0;
@@ -452,24 +538,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         rbase = __builtin_amdgcn_readfirstlane(rbase);
         for (int e0 = 0; e0 < n; e0 += 64) {
-          int rl, tl, l5;
+          int rl, tl, l5, ps;
           v4f sv;
           bool rp[4], cp[4];
-          take_apart(e0 + lane, rl, tl, l5, sv, rp, cp);
+          take_apart(e0 + lane, rl, tl, l5, ps, sv, rp, cp);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
+            const int row = row_of(rl, t), sub = sub_of(ps, t);
             const unsigned long long m = __ballot(rp[t]);
             const int rpos = rbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             if (rp[t] && rpos < a.bucket_cap)
               a.bucket_ent[(size_t)own * a.bucket_cap + rpos] =
-                  make_uint2(((unsigned)rl << 27) | ROW_SIDE | (unsigned)((t0 + tl) * 128 + 32 * t + l5), __float_as_uint(sv[t]));
+                  make_uint2(((unsigned)row << 27) | ROW_SIDE | (unsigned)((t0 + tl) * 128 + 32 * sub + l5), __float_as_uint(sv[t]));
             rbase += __popcll(m);
             if (cp[t]) {
-              const int b = tl * 4 + t;
+              const int b = tl * 4 + sub;
               const int cpos = s_base[b] + atomicAdd(&s_cnt[b], 1);
               if (cpos < a.bucket_cap)
                 a.bucket_ent[(size_t)(t0 * 4 + b) * a.bucket_cap + cpos] =
-                    make_uint2(((unsigned)l5 << 27) | ROW_SIDE | (unsigned)(grow0 + rl), __float_as_uint(sv[t]));
+                    make_uint2(((unsigned)l5 << 27) | ROW_SIDE | (unsigned)(grow0 + row), __float_as_uint(sv[t]));
             }
           }
         }
@@ -480,15 +567,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // masks), so no entry is ever dropped unless ONE tile alone yields more than a whole list.
       for (int ct = t0; ct <= t1; ++ct) {
         const bool flush_only = ct == t1;
+        for (int pass = 0; pass < (flush_only ? 1 : NPASS); ++pass) {  // (NT = 2: the tile's columns 0-63, then 64-127)
         if (!flush_only) {
-          k_loop(ct);
+          k_loop(ct, pass);
           asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the asm MFMAs' results -> VALU reads: hipcc pads nothing for asm
         }
         static_for<0, NRG>([&](auto RC) {
           constexpr int r = decltype(RC)::value;
           if (!rok[r]) return;
+#ifdef OSC_PANEL_NO_EPI  // measurement only (wrong lattice): the sweep without its hit test
+          return;
+#endif
           const bool test = !flush_only && ct >= rbv[r];  // (second row group of a set: the tile below its diagonal belongs to the first)
-          unsigned long long fm[16];
+          constexpr int NU = NT == 4 ? 16 : 8;  // union tests: one per four scores of a lane
+          unsigned long long fm[NU];
           int add = 0;
           if (test) {
             float tg[16];
@@ -497,42 +589,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][r][h][4 * q]);
               tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
             }
-            float tc[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+            float tcmin = 3.0e38f;  // the smallest threshold of this lane's columns in the pass (+inf: no column side on the diagonal tile)
             if (ct > rbv[r]) {
-              const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(ct - t0) * 128 + l31 * 4]);
-              tc[0] = c4[0], tc[1] = c4[1], tc[2] = c4[2], tc[3] = c4[3];
+              // (the lane id recomputed in place: with two row groups at D = 768 every per-lane value that lives across the K loop
+              // without being used in it is spilled, and a scratch reload here costs a vmcnt(0) -- a drain of the DMA ring -- per pass)
+              unsigned l31o;
+              asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_and_b32 %0, 31, %0" : "=v"(l31o));
+              const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(ct - t0) * 128 + l31o * 4]);
+              if constexpr (NT == 4) tcmin = fminf(fminf(c4[0], c4[1]), fminf(c4[2], c4[3]));
+              else tcmin = pass == 0 ? fminf(c4[0], c4[1]) : fminf(c4[2], c4[3]);
             }
-            static_for<0, 16>([&](auto GC) {
-              fm[decltype(GC)::value] = row_mask(GC, acc[r], tg, tc);
+            static_for<0, NU>([&](auto GC) {
+              fm[decltype(GC)::value] = row_mask_u(GC, acc[r], tg, tcmin);
               add += __popcll(fm[decltype(GC)::value]);
             });
           }
-          if (wcnt[r] > 0 && (flush_only || wcnt[r] + add > HCAP)) {
+          if (wcnt[r] > 0 && ((flush_only && pass == 0) || wcnt[r] + add > HCAP)) {
+#ifndef OSC_PANEL_NO_DELIVER  // measurement only (wrong lattice): the lists are emptied, not delivered
             deliver(RC);
+#endif
             wcnt[r] = 0;
           }
           if (test && add > 0) {
             unsigned* const hd = s_hdr + (wave * NRG + r) * HCAP;
             v4f* const sc = s_sc + (wave * NRG + r) * HCAP;
-            const unsigned tag = (unsigned)((ct - t0) << 5) | (unsigned)l31;
-            static_for<0, 16>([&](auto GC) {
-              constexpr int g = decltype(GC)::value;
-              const unsigned long long m = fm[g];
+            // (the lane's part of the header -- pass, tile of the item, lane, and the half's row offset 4 h -- in ONE register made
+            // opaque to hipcc: left to itself it hoists the sixteen (row register | 4 h) constants out of every loop and, in the
+            // two-row-group shape at D = 768, spills them: a scratch reload + vmcnt(0) -- a drain of the DMA ring -- per entry)
+            unsigned tag, l31o_scratch;  // lane id -> (h << 12) | l31, recomputed in place (see the threshold fetch above)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %1, 7, %0\n\tv_and_b32 %0, 31, %0\n\tv_and_b32 %1, 0x1000, %1\n\tv_or_b32 %0, %1, %0"
+                         : "=&v"(tag), "=&v"(l31o_scratch));
+            tag |= (unsigned)(pass << 15) | (unsigned)((ct - t0) << 5);
+            asm volatile("" : "+v"(tag));
+            static_for<0, NU>([&](auto GC) {
+              constexpr int g = NT == 4 ? decltype(GC)::value : 2 * decltype(GC)::value;  // (first) row register of the entry
+              const unsigned long long m = fm[decltype(GC)::value];
               if (m != 0ull) {
                 const int pos = wcnt[r] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 if (((m >> lane) & 1ull) && pos < HCAP) {
-                  hd[pos] = ((unsigned)((g & 3) + 8 * (g >> 2) + 4 * h) << 10) | tag;
-                  sc[pos] = v4f{acc[r][0][g], acc[r][1][g], acc[r][2][g], acc[r][3][g]};
+                  hd[pos] = ((unsigned)((g & 3) + 8 * (g >> 2)) << 10) + tag;  // (disjoint bits: local row = (g & 3) + 8 (g >> 2) + 4 h)
+                  if constexpr (NT == 4) sc[pos] = v4f{acc[r][0][g], acc[r][1][g], acc[r][2][g], acc[r][3][g]};
+                  else sc[pos] = v4f{acc[r][0][g], acc[r][1][g], acc[r][0][g + 1], acc[r][1][g + 1]};
                 }
                 wcnt[r] += __popcll(m);
               }
             });
           }
         });
+        }
       }
     } else if constexpr (MODE == 1) {
+      static_assert(SYM || MODE != 1 || NT == 4, "the full sweep's fine entries are written for 128-column passes");
       for (int ct = t0; ct < t1; ++ct) {
-        k_loop(ct);
+        k_loop(ct, 0);
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the asm MFMAs' results -> VALU reads: hipcc pads nothing for asm
 #pragma unroll
         for (int r = 0; r < NRG; ++r) {
@@ -548,8 +657,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
     } else {
+      static_assert(MODE != 0 || NT == 4, "the sample sweep's running maxima are written for 128-column passes");
       for (int ct = t0; ct < t1; ++ct) {
-        k_loop(ct);
+        k_loop(ct, 0);
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
         // ---- tile maxima of the sample sweep --------------------------------------------------------------------
 #pragma unroll
@@ -1439,6 +1549,7 @@ void launch_panel(const PanelArgs& a, int nkt, int nrg, bool sym, int grid, hipS
       if (nkt == 6 && nrg == 2) OSC_PANEL(6, 2, true);
       else if (nkt == 6 && nrg == 1) OSC_PANEL(6, 1, true);
       else if (nkt == 12 && nrg == 1) OSC_PANEL(12, 1, true);
+      else if (nkt == 12 && nrg == 2) OSC_PANEL(12, 2, true);
       else throw std::runtime_error("launch_panel: unsupported K depth / row groups");
       HIP_CHECK(hipGetLastError());
       return;
@@ -1476,9 +1587,14 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
   }
   p.ldh = 64 * p.nkt;
   // row groups per wave: two where the panel is small enough (D <= 384: 2 x 96 registers), see the file header
-  p.nrg = (p.nkt == 6 && tune.nrg != 1) ? 2 : 1;
   p.npad = ((N + 127) / 128) * 128;
   p.nrb = p.npad / 128;
+  // (round 6: two row groups also at K depth 12 in the half sweep -- k_panel<12, 1, 2, true>, 64-column passes -- from 720 row
+  // blocks on: gemm_topk at D = 768, one / two groups, profiles/r06_knn_nrg_ab.txt: 40 000 rows 2.05 / 2.23 ms, 60 000 3.64 / 3.73,
+  // 80 000 6.19 / 6.20, 100 000 9.50 / 8.97, 140 000 x 640 16.9 / 15.8, 200 000 33.5 / 31.4 -- the items are twice as long and
+  // half as many, which smaller lattices pay for at the tail of the persistent grid)
+  p.nrg = p.tile_core ? 1 : p.nkt == 6 ? (tune.nrg != 1 ? 2 : 1) : (p.nkt == 12 && sym && (tune.nrg == 2 || (tune.nrg == 0 && p.nrb >= 720))) ? 2 : 1;
+  p.nrg_s = p.nkt == 6 ? p.nrg : 1;
   p.keep = keep;
   // Thresholds: the sample holds one column in rho; tau = the 14th largest tile maximum ~ the 15th-17th best sample
   // score, so about rho * 16 columns of the full sweep beat it (gamma-distributed: 0.1 % of the rows see fewer than
@@ -1574,8 +1690,9 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
   // rows short of candidates at N = 20000, config 4's build 412 -> 419 ms; not kept)
   best = 1e30;
   p.SA = 1;
+  const int nsets_s = (p.nrb + p.nrg_s - 1) / p.nrg_s;
   for (int S = 1; S <= 6 && S <= p.sample_groups; ++S) {
-    const double rounds = (double)nsets * S / std::max(1, cus);
+    const double rounds = (double)nsets_s * S / std::max(1, cus);
     const double cost = std::ceil(rounds) / rounds * (1.0 + 0.03 * S);
     if (cost < best - 1e-9) {
       best = cost;
@@ -1636,7 +1753,7 @@ void launch_panel_tilemax(const void* Yh, const void* Ys, const KnnPanelPlan& p,
     launch_tile_thr<0>(a, p.nkt, 2 * grid, s);
     return;
   }
-  launch_panel<0>(a, p.nkt, p.nrg, false, grid, s);
+  launch_panel<0>(a, p.nkt, p.nrg_s, false, grid, s);
 }
 
 void launch_panel_tau(const float* tmax, const KnnPanelPlan& p, int32_t N, float* tau, hipStream_t s, int32_t r0, int32_t r1) {

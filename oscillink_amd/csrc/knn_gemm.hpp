@@ -15,7 +15,8 @@ int knn_tile_nkt(int32_t D);
 struct KnnPanelPlan {
   bool ok;             // the lattice is large enough for sampled thresholds (else: use the tile prefilter)
   int nkt;             // 6 or 12
-  int nrg;             // row groups (32 rows of consecutive 128-row blocks) a wave's register panel holds: 2 at K depth 6, else 1
+  int nrg;             // row groups (32 rows of consecutive 128-row blocks) a wave's register panel holds in the MAIN sweep: 2 at K depth 6 and, round 6, in the half sweep at K depth 12 from 256 row blocks on (64-column passes); else 1
+  int nrg_s;           // ... in the SAMPLE sweep: nrg at K depth 6, else 1 (its running maxima beside 384 panel registers would not fit)
   int32_t ldh;         // pitch of the fp16 images in halfs = 64 * nkt
   int32_t npad;        // rows of the query image (N rounded up to 128), zero-filled beyond N
   int32_t nrb;         // query row blocks (npad / 128)
@@ -63,7 +64,7 @@ inline int32_t knn_panel_row(const KnnPanelPlan& p, int32_t N, int32_t r) { retu
 void knn_panel_set_pieces(KnnPanelPlan& p, int32_t N, const int32_t* starts, int npieces);
 // A/B overrides of the planner (OSC_KNN_PANEL_NRG / _RHO / _T / _RANK, read by the caller; 0 = the planner's own choice)
 struct KnnPanelTune {
-  int nrg = 0;     // 1: one row group per wave also at K depth 6
+  int nrg = 0;     // 1: one row group per wave also at K depth 6; 2: two also at K depth 12 below 256 row blocks (half sweep)
   double rho = 0;  // one sample column in rho
   int T = 0;       // half sweep: tiles per chunk
   int rank = 0;    // threshold = rank-th largest group maximum of the sample

@@ -1222,6 +1222,11 @@ int osc_profile_reset(osc_handle h) {
 }
 int osc_profile_get(osc_handle h, int32_t which, int64_t* launches, double* total_ms) {
   return guarded(h, [&](L& l) {
+    if (which == 16) {  // main sweep of the last build's prefilter: 0 none, 1 full (per rank), 2 half (one per build)
+      if (launches) *launches = l.knn_sweep;
+      if (total_ms) *total_ms = 0.0;
+      return;
+    }
     if (which == 15) {  // pieces the last build received its anchors in (0: they were on the device before it started)
       if (launches) *launches = l.create_pieces;
       if (total_ms) *total_ms = 0.0;

@@ -394,7 +394,7 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
       if (j & 1) HIP_CHECK(hipStreamWaitEvent(s, E(ev_sample), 0));  // (the sample image was written on the first stream)
       const int rb0 = r0 / 128, rb1 = last ? pp.nrb : r1 / 128;
       KnnPanelPlan pj = pp;  // (splits of the sample sweep chosen for THIS many row blocks)
-      const int nsets = (rb1 - rb0 + pp.nrg - 1) / pp.nrg;
+      const int nsets = (rb1 - rb0 + pp.nrg_s - 1) / pp.nrg_s;
       double best = 1e30;
       for (int S = 1; S <= 6 && S <= pp.sample_groups; ++S) {
         const double rounds = (double)nsets * S / std::max(1, cus);
@@ -562,6 +562,7 @@ static bool build_graph_once(L& h, const float* host_Y) {
   if (h.knn_mode == 3) panel = prefilter = (keep_f >= k + 8) && !any_k && depth_ok && N >= 6144 && N < (1 << 25);
   if (h.knn_mode == 2) panel = false;
   h.knn_panel = panel;
+  h.knn_sweep = 0;
   DevBuf<float> cand_val, cval;
   DevBuf<int32_t> cand_idx, cidx, fail_rows, fail_count;
   DevBuf<float> Yh;  // fp16 image, viewed as float slots
@@ -584,6 +585,7 @@ static bool build_graph_once(L& h, const float* host_Y) {
     // (round 5: the row scatter also under a SHARED half sweep -- a rank then owns image row blocks, i.e. lattice rows spread
     // over the whole lattice, and the ranks' lists are combined by sums instead of an all-gather, below)
     pp = knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, h.knn_scatter && (parts == 1 || sym_ok), sym_ok, h.knn_tune);
+    h.knn_sweep = pp.sym ? 2 : 1;
     p_img.alloc((size_t)(pp.npad + 128) * pp.ldh / 2);  // (+ one zero tile: k_tile_thr2 sweeps row blocks and column tiles in pairs)
     HIP_CHECK(hipMemsetAsync(p_img.p + (size_t)pp.npad * pp.ldh / 2, 0, (size_t)128 * pp.ldh * 2, h.stream));
     p_smp.alloc((size_t)pp.sample_tiles * 128 * pp.ldh / 2);
@@ -609,7 +611,8 @@ static bool build_graph_once(L& h, const float* host_Y) {
       // OSC_CREATE_PIECE_MB overrides this: tests of the retry below.)
       // (the wide tile core's lists are shorter and its wave tiles taller -- 64 rows, ~96 entries from one tile: 176 x bound rows;
       // soak_streamed_create.py, 82 785 x 800, k = 16, grouped: pieces of 8192 rows overflowed and the build handed over)
-      const double min_rows = pp.tile_core ? 176.0 * pp.hit_bound : 32.0 * pp.hit_bound * pp.nrg;
+      // (two row groups at K depth 12 append per 64-column PASS: half a tile of entries at a time)
+      const double min_rows = pp.tile_core ? 176.0 * pp.hit_bound : 32.0 * pp.hit_bound * (pp.nkt == 12 && pp.nrg == 2 ? 1 : pp.nrg);
       if (!h.create_piece_mb_set) m = std::max<int64_t>(m, ((int64_t)min_rows + chunk_rows - 1) / chunk_rows);
       // (what is left over joins the last piece: a piece's rows are permuted among themselves only, so a short piece of
       // anchors that arrive cluster by cluster packs each cluster into few tiles -- 3072 rows holding 7.7 clusters of 401 gave
@@ -656,7 +659,7 @@ static bool build_graph_once(L& h, const float* host_Y) {
     for (int part = 0; part < parts; ++part) {
       if (sharded && part != h.rank) continue;
       const int rb_begin = std::min(all_rb, part * rb_per), rb_count = std::max(0, std::min(rb_per, all_rb - rb_begin));
-      const int nsets = (rb_count + pp.nrg - 1) / pp.nrg;
+      const int nsets = (rb_count + pp.nrg_s - 1) / pp.nrg_s;  // (work items per column split of the SAMPLE sweep)
       launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
                            std::max(1, std::min(prop.multiProcessorCount, nsets * pp.SA)), h.stream);
     }
@@ -713,7 +716,7 @@ static bool build_graph_once(L& h, const float* host_Y) {
       } else if (!sym_sharded) {  // (a sharded half sweep has its thresholds and buckets already: above)
         ProfScope ps(h, 3);
         launch_panel_tilemax(p_img.p, p_smp.p, pp, N, rb_begin, rb_count, p_tmax.p, p_queue.p,
-                             std::max(1, std::min(prop.multiProcessorCount, nsets * pp.SA)), h.stream);
+                             std::max(1, std::min(prop.multiProcessorCount, (rb_count + pp.nrg_s - 1) / pp.nrg_s * pp.SA)), h.stream);
         launch_panel_tau(p_tmax.p, pp, N, p_tau.p, h.stream);
         if (pp.sym) {
           const size_t nb = (size_t)pp.npad / 32;

@@ -12,6 +12,7 @@ receipt assembly + HMAC signing, persistence.
 from __future__ import annotations
 
 import ctypes as C
+import gc
 import hashlib
 import hmac
 import json
@@ -233,11 +234,13 @@ class OscillinkLattice:
         shape, pieces, unused = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
         self._call("osc_profile_get", 14, C.byref(shape), C.byref(unused))
         self._call("osc_profile_get", 15, C.byref(pieces), C.byref(unused))
+        sweep = C.c_int64(0)
+        self._call("osc_profile_get", 16, C.byref(sweep), C.byref(unused))
         return {"prefilter": int(pf.value), "fallback_rows": int(fb.value), "small_solves": int(ss.value),
                 "reordered": int(ro.value), "clustering": float(cc.value), "apply_launches": int(ln.value),
                 "apply_slab_cols": int(sc.value), "apply_xs_workgroups": int(xw.value),
                 "apply_src_blocks": int(sb.value), "blocked_applies": int(ba.value), "apply_blocked_shape": int(shape.value),
-                "create_pieces": int(pieces.value)}
+                "create_pieces": int(pieces.value), "knn_sweep": int(sweep.value)}
 
     def halo_info(self) -> dict[str, int]:
         """Row-sharded runs (OSC_SHARD=row under a communicator): the rows of the search direction this rank receives
@@ -607,8 +610,19 @@ class OscillinkLattice:
 
     @staticmethod
     def _null_dicts(i, j, z, r, n):
+        """The reference's list of {"edge": [i, j], "z": .., "residual": ..} (receipts.py:63-83).  At config 3 every row has a
+        null point (a dense residual row is 29 values among 100 000 zeros), so this makes 100 000 dicts + 100 000 lists: the
+        cyclic collector, which wakes up every 700 new containers and re-walks the young ones, was two thirds of the 47 ms the
+        list took -- nothing built here can be part of a cycle, so it is paused for the construction."""
         il, jl, zl, rl = i[:n].tolist(), j[:n].tolist(), z[:n].astype(float).tolist(), r[:n].astype(float).tolist()
-        return [{"edge": [a, b], "z": c, "residual": d} for a, b, c, d in zip(il, jl, zl, rl)]
+        paused = n > 2000 and gc.isenabled()
+        if paused:
+            gc.disable()
+        try:
+            return [{"edge": [a, b], "z": c, "residual": d} for a, b, c, d in zip(il, jl, zl, rl)]
+        finally:
+            if paused:
+                gc.enable()
 
     def _coherence_drop(self, Ustar: Optional[np.ndarray] = None) -> np.ndarray:
         self._ensure_device_ustar()

@@ -1515,15 +1515,18 @@ def test_deferred_x_update_leaves_the_same_state_at_every_stop_point(amd, path, 
             assert np.array_equal(Ua, Ub)
 
 
-def test_panel_planner_overrides_give_the_same_lattice(amd, monkeypatch):
+@pytest.mark.parametrize("N,D,k", [(18000, 320, 16), (18000, 600, 16), (33000, 768, 40)])
+def test_panel_planner_overrides_give_the_same_lattice(amd, monkeypatch, N, D, k):
     """OSC_KNN_PANEL_T / _RHO / _NRG move the half sweep's chunk length, the sample density of the thresholds and the row
-    groups per wave; the lattice is the one of the planner's own choice (and of the exact route) whatever they say."""
+    groups per wave; the lattice is the one of the planner's own choice (and of the exact route) whatever they say.
+    Round 6: K depth 12 (384 < D <= 768) with TWO row groups -- k_panel<12,1,2,true>, 64-column passes, pair-form coarse
+    entries -- forced here at sizes where the planner would keep one (it takes two from 720 row blocks on)."""
     rng = np.random.default_rng(5)
-    N, D, k = 18000, 320, 16
     Y = rng.standard_normal((N, D), dtype=np.float32)
     monkeypatch.setenv("OSC_KNN_MODE", "panel")
     want = None
     for env in ({}, {"OSC_KNN_PANEL_T": "4"}, {"OSC_KNN_PANEL_RHO": "16"}, {"OSC_KNN_PANEL_NRG": "1"}, {"OSC_KNN_PANEL_RANK": "12"},
+                {"OSC_KNN_PANEL_NRG": "2"}, {"OSC_KNN_PANEL_NRG": "2", "OSC_KNN_PANEL_T": "6"},
                 {"OSC_KNN_PANEL_NRG": "1", "OSC_KNN_PANEL_T": "9", "OSC_KNN_PANEL_SYM": "0"}):
         for v in ("OSC_KNN_PANEL_T", "OSC_KNN_PANEL_RHO", "OSC_KNN_PANEL_NRG", "OSC_KNN_PANEL_RANK", "OSC_KNN_PANEL_SYM"):
             monkeypatch.delenv(v, raising=False)
