@@ -1653,3 +1653,81 @@ def test_second_stage_proof_keeps_clustered_rows_off_the_exact_kernel(amd, monke
     # products (the re-scoring's lane-strided sums vs the exact kernel's MFMA tiles)
     assert np.array_equal(out["1"][1][0], out["0"][1][0]) and np.array_equal(out["1"][1][1], out["0"][1][1])
     assert np.allclose(out["1"][1][2], out["0"][1][2], rtol=2e-6, atol=1e-8)
+
+
+def _anchors_with_bad_rows(N, D, seed):
+    """i.i.d. anchors with NaN rows (one NaN element is enough: graph.py:35 turns the whole unit row into NaN), +-Inf
+    elements (norm = inf, inf / inf = NaN) and zero rows (norm 0: the unit row is 0 / 1e-12 = 0, every similarity 0)."""
+    rng = np.random.default_rng(seed)
+    Y = rng.standard_normal((N, D), dtype=np.float32)
+    nan_rows = [5, 4097, 8191, 12345, N - 1]
+    inf_rows = [77, 10000, N - 4445]
+    zero_rows = [0, 128, 9000, 16384, N - 1000]
+    for t, r in enumerate(nan_rows):
+        Y[r, (17 * t) % D] = np.nan
+    Y[nan_rows[1]] = np.nan  # ... and a row that is NaN throughout
+    Y[inf_rows[0], 3] = np.inf
+    Y[inf_rows[1], D - 1] = -np.inf
+    Y[inf_rows[2], ::7] = np.inf
+    Y[zero_rows] = 0.0
+    return Y, sorted(nan_rows + inf_rows), zero_rows
+
+
+@pytest.mark.parametrize("D,mode,nrg", [(600, "panel", "1"), (600, "panel", "2"), (256, "panel", "0"), (900, "panel", "0"),
+                                        (600, "prefilter", "0"), (600, "exact", "0")])
+def test_non_finite_and_zero_anchor_rows_on_the_large_lattice_routes(amd, orc, D, mode, nrg, monkeypatch):
+    """graph.py:35-37 with anchors that are not finite: a NaN / Inf row's similarities are NaN, which rank last in every
+    other row's ordering and fail `> 0` (graph.py:51, :64) -- such a row has no edges and is nobody's neighbour; a zero
+    row's similarities are all 0, not `> 0` either.  The finite rows' lists are those of the finite columns.  Until round 6
+    this was held only at N = 64 through the diffusion gates; here the lattice is large enough for the thresholds-and-hits
+    prefilter (fp16 image of a NaN row, tile maxima and thresholds of a NaN row, hits against a NaN column's threshold,
+    bucket delivery, the proof) on the panel core at both K depths and with one / two row groups, on the tile core
+    (D = 900), the list-maintaining tile prefilter and the all-fp32 kernel -- each against the oracle's graph."""
+    from tests._fullsize import check_graph_built_from_lists, device_knn_lists, near_tie_gap
+
+    N, k = 20000, 16
+    Y, nonfinite, zero = _anchors_with_bad_rows(N, D, 100 + D)
+    with np.errstate(invalid="ignore"):
+        idx_o, _ = orc.knn_topk(Y, k, block=2048)
+    monkeypatch.setenv("OSC_KNN_MODE", mode)
+    monkeypatch.setenv("OSC_KNN_PANEL_NRG", nrg)
+    lat = amd.Oscillink(Y, kneighbors=k)
+    info = lat.build_info()
+    csr = lat.graph_csr()
+    idx, val = device_knn_lists(lat, N, k)
+    lat.close()
+    rp, col, a, w, sd = csr
+    assert info["prefilter"] == {"panel": 2, "prefilter": 1, "exact": 0}[mode]
+    deg = np.diff(rp)
+    assert (deg[nonfinite] == 0).all() and (deg[zero] == 0).all()
+    assert not np.isin(col, nonfinite + zero).any()
+    assert np.isfinite(a).all() and np.isfinite(w).all() and np.isfinite(sd).all()
+    # the finite rows' lists are the oracle's (as sets; a row may differ by a float64-proven rank-k near-tie) ...
+    good = np.setdiff1d(np.arange(N), np.array(nonfinite + zero))
+    rows = good[(np.sort(idx[good], axis=1) != np.sort(idx_o[good], axis=1)).any(axis=1)]
+    assert rows.size <= 8, rows.size
+    for r in rows:
+        members = sorted(set(idx[r].tolist()) ^ set(idx_o[r].tolist()))
+        assert not np.isin(members, nonfinite).any() and near_tie_gap(Y, int(r), members) < 1e-6, (int(r), members)
+    assert not np.isin(idx[good], nonfinite).any()
+    # ... and the graph is the oracle's mutual test / cap / Laplacian applied to the device's lists, on EVERY row
+    with np.errstate(invalid="ignore"):
+        check_graph_built_from_lists(orc, N, idx, val, csr)
+
+
+def test_non_finite_anchor_rows_on_the_wide_tile_core(amd, monkeypatch):
+    """The same beyond 768 columns at a size whose main sweep runs with 64 x 128 wave tiles (k_tile_thr2, from ~49 000 rows),
+    against the all-fp32 route, which the test above holds to the oracle."""
+    N, D, k = 50000, 800, 8
+    Y, nonfinite, zero = _anchors_with_bad_rows(N, D, 7)
+    graphs = {}
+    for mode in ("panel", "exact"):
+        monkeypatch.setenv("OSC_KNN_MODE", mode)
+        lat = amd.Oscillink(Y, kneighbors=k)
+        graphs[mode] = (lat.graph_csr(), lat.build_info())
+        lat.close()
+    (rp, col, a, _, _), info = graphs["panel"]
+    (rp_e, col_e, a_e, _, _), _ = graphs["exact"]
+    assert info["prefilter"] == 2
+    assert (np.diff(rp)[nonfinite + zero] == 0).all() and not np.isin(col, nonfinite + zero).any()
+    assert np.array_equal(rp, rp_e) and np.array_equal(col, col_e) and np.allclose(a, a_e, rtol=2e-5, atol=1e-9)
