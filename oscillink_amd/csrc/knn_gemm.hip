@@ -333,13 +333,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // compare per side with a subtraction per subtile (4 VALU per register instead of 11) -- a superset of the exact
     // union (any score above its own column's threshold is above the smallest one), and the flush decides every score
     // against its own two thresholds anyway: the lists gain a few coarse entries whose scores all fail there.
+    // (v_max3 / v_min3 written as asm: through fmaxf / fminf hipcc first quiets every operand that "might be a signalling NaN"
+    // with a v_max x, x of its own -- two extra instructions per test; MFMA results and loaded thresholds never are, and a NaN
+    // score fails the compare either way)
+    auto max3r = [](float x, float y, float z) { float m; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(x), "v"(y), "v"(z)); return m; };
+    auto max2r = [](float x, float y) { float m; asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y)); return m; };
+    auto min3r = [](float x, float y, float z) { float m; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(x), "v"(y), "v"(z)); return m; };
+    auto min2r = [](float x, float y) { float m; asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y)); return m; };
     auto row_mask_u = [&](auto GC, const f32x16(&pa)[NT], const float(&tg)[16], const float tcmin) -> unsigned long long {
       constexpr int g = decltype(GC)::value;  // NT = 4: the row register; NT = 2: the PAIR of row registers 2 g, 2 g + 1 (rows rl, rl + 1)
       if constexpr (NT == 4) {
-        return __ballot(fmaxf(fmaxf(pa[0][g], pa[1][g]), fmaxf(pa[2][g], pa[3][g])) > fminf(tg[g], tcmin));
+        return __ballot(max2r(max3r(pa[0][g], pa[1][g], pa[2][g]), pa[3][g]) > min2r(tg[g], tcmin));
       } else {
-        const float m = fmaxf(fmaxf(pa[0][2 * g], pa[1][2 * g]), fmaxf(pa[0][2 * g + 1], pa[1][2 * g + 1]));
-        return __ballot(m > fminf(fminf(tg[2 * g], tg[2 * g + 1]), tcmin));
+        return __ballot(max2r(max3r(pa[0][2 * g], pa[1][2 * g], pa[0][2 * g + 1]), pa[1][2 * g + 1]) > min3r(tg[2 * g], tg[2 * g + 1], tcmin));
       }
     };
     auto hit_rows = [&](auto GC, const f32x16(&pa)[4], const float(&tg)[16], const float(&tc)[4], int pct, int rb, uint2* hb, int& wc) {  // query-row register g of the tile pct has a hit
@@ -596,8 +602,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               unsigned l31o;
               asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_and_b32 %0, 31, %0" : "=v"(l31o));
               const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(ct - t0) * 128 + l31o * 4]);
-              if constexpr (NT == 4) tcmin = fminf(fminf(c4[0], c4[1]), fminf(c4[2], c4[3]));
-              else tcmin = pass == 0 ? fminf(c4[0], c4[1]) : fminf(c4[2], c4[3]);
+              if constexpr (NT == 4) tcmin = min2r(min3r(c4[0], c4[1], c4[2]), c4[3]);
+              else tcmin = pass == 0 ? min2r(c4[0], c4[1]) : min2r(c4[2], c4[3]);
             }
             static_for<0, NU>([&](auto GC) {
               fm[decltype(GC)::value] = row_mask_u(GC, acc[r], tg, tcmin);
