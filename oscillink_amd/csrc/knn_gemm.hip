@@ -1040,6 +1040,9 @@ __device__ __forceinline__ unsigned order_key(unsigned bits) {  // ascending flo
 // sorted: the re-scoring ranks by exact score.
 constexpr int SEL_CAP = 1024;    // candidates of one row the select can hold (expected: ~5 keep)
 constexpr int SORT_CAP = 2560;   // entries one workgroup sorts (20 KB of LDS: several workgroups per CU)
+// (Round 6, tried and dropped: ONE workgroup per bucket -- 9600 entries, 75 KB of LDS, the bucket read twice by one workgroup
+// instead of twice by each of four: k_panel_select 0.55 -> 0.82 ms at config 3.  The kernel is bound by its per-row ballot
+// searches, not by the 920 MB it fetches for 150 MB of entries; two workgroups per CU instead of eight lose more than the reads save.)
 // Half-sweep builds (sym): every candidate of the 32 rows of (row block, wave) sits in ONE bucket (k_panel's flush).
 struct SelectSym {
   int32_t on, T;
@@ -1051,8 +1054,8 @@ struct SelectSym {
 __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, const int32_t* hit_cnt, int32_t hit_cap, int32_t S,
                                                       int32_t rb_begin, int32_t rb_count, int32_t nsub, int32_t keep,
                                                       int32_t N, int32_t mapped, KnnRowMap map, float* cval, int32_t* cidx,
-                                                      int32_t* fail_rows, int32_t* fail_count, const SelectSym sy) {
-  __shared__ uint2 sorted[SORT_CAP];
+                                                      int32_t* fail_rows, int32_t* fail_count, const SelectSym sy, const int32_t sort_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint2 sorted[];  // sort_cap entries
   __shared__ int hist[32], start[33], cursor[32], s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = blockIdx.x % nsub, w = (blockIdx.x / nsub) % 4, rbi = blockIdx.x / (4 * nsub);
@@ -1096,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
       acc += hist[r];
     }
     start[32] = acc;
-    if (acc > SORT_CAP) s_bad = 1;
+    if (acc > sort_cap) s_bad = 1;
   }
   __syncthreads();
   const bool bad = s_bad != 0;
@@ -1879,10 +1882,13 @@ void launch_panel_select(const KnnPanelPlan& p, int rb_begin, int rb_count, int3
   // (per row: the planner's bound on the candidates its threshold lets through, max(5 keep, 20 rho) -- with 5 keep alone a
   // sparse sample (large rho) or a small k overflowed the sort array and sent whole 32-row groups to the exact kernel)
   int nsub = 1;
+  const int cap = SORT_CAP;
   while (nsub < 32 && p.hit_bound * (32 / nsub) > 0.75 * SORT_CAP) nsub *= 2;
-  hipLaunchKernelGGL(k_panel_select, dim3((unsigned)(rb_count * 4 * nsub)), dim3(256), 0, s,
+  const size_t lds_bytes = (size_t)cap * sizeof(uint2);
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(k_panel_select, dim3((unsigned)(rb_count * 4 * nsub)), dim3(256), lds_bytes, s,
                      static_cast<const uint2*>(hit_list), hit_cnt, p.hit_cap, p.S, rb_begin, rb_count, nsub, p.keep, N, p.scatter != 1 ? 1 : 0,
-                     p.map, cval, cidx, fail_rows, fail_count, sy);
+                     p.map, cval, cidx, fail_rows, fail_count, sy, (int32_t)cap);
   HIP_CHECK(hipGetLastError());
 }
 
