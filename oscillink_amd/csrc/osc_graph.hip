@@ -321,8 +321,9 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
   }
   // events: [j] piece j has landed, [pieces + j] the thresholds of all rows up to piece j's are written, then: everything
   // the caller queued before this call is done / the sample image is written / the second stream has drained
-  std::vector<hipEvent_t> ev((size_t)2 * pieces + 3, nullptr);
-  hipEvent_t &ev_start = ev[(size_t)2 * pieces], &ev_sample = ev[(size_t)2 * pieces + 1], &ev_done = ev[(size_t)2 * pieces + 2];
+  std::vector<hipEvent_t> ev((size_t)2 * pieces + 4, nullptr);
+  hipEvent_t &ev_start = ev[(size_t)2 * pieces], &ev_sample = ev[(size_t)2 * pieces + 1], &ev_done = ev[(size_t)2 * pieces + 2],
+             &ev_landed = ev[(size_t)2 * pieces + 3];
   // The host side: a copy from pageable memory returns when the data has left, so the calling thread issues the transfers
   // one by one and queues a piece's kernels behind each; a few threads gather the sample's rows into pinned memory
   // meanwhile (started first: the sample is what the first threshold waits for), and the sample follows the first piece.
@@ -344,11 +345,14 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
     release_stream(h.device, second);
   };
   try {
-    // (the sample's rows fill the first staging buffer and, beyond 32 MB, the second one: two transfers)
-    const int32_t half_rows = (int32_t)std::min<int64_t>(m_s, (int64_t)(kStageBytes / row_bytes));
-    float* const pin0 = static_cast<float*>(sp.buf[0]);
-    float* const pin1 = static_cast<float*>(sp.buf[1]);
-    const int nthr = std::max(1, std::min(threads, 8));
+    // The sample's rows travel through the two pinned staging buffers in FILLS of 32 MB: fill w uses buffer w & 1.  Up to 64 MB
+    // that is one gather and two transfers; beyond (round 6: configs 4 and 5 -- 128 / 102 MB of sample rows) the buffers are
+    // reused: a buffer is gathered into again once the transfer of its previous fill has left it, and a piece of anchors
+    // travels (and its row kernels run) during every such gather, so neither the bus nor the device waits for the host threads.
+    const int64_t rows_per_buf = std::max<int64_t>(1, (int64_t)(kStageBytes / row_bytes));
+    const int nfill = (int)((m_s + rows_per_buf - 1) / rows_per_buf);
+    const int nthr = nfill > 2 ? std::max(1, std::min(16, std::max(threads, (int)std::thread::hardware_concurrency() / 8)))
+                               : std::max(1, std::min(threads, 8));
     // The sample is defined in lattice terms (knn_rowmap.hpp: an even stride of lattice rows, dealt to the threshold groups
     // in turn), so it can be put together from the caller's array before a single image row exists -- and it is the very
     // sample the whole-array build copies out of its image: same thresholds, same hits, same rows proven.  (Its first form
@@ -357,13 +361,25 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
     // to the background level and every row went to the exact kernel -- soak_streamed_create.py, 60 000 x 768, k = 8,
     // clusters of 300; two permutations of the sample order later the count of distinct groups was still left to chance.)
     const int32_t gsz = pp.group_tiles * 128, G = pp.sample_groups;
-    for (int t = 0; t < nthr; ++t)
-      workers.emplace_back([=] {
-        for (int32_t r = (int32_t)((int64_t)m_s * t / nthr); r < (int32_t)((int64_t)m_s * (t + 1) / nthr); ++r) {
-          const int32_t row = knn_sample_lattice_row(knn_sample_index(r, m_s, gsz, G), m_s, N);
-          std::memcpy(r < half_rows ? pin0 + (size_t)r * D : pin1 + (size_t)(r - half_rows) * D, host_Y + (size_t)row * D, row_bytes);
-        }
-      });
+    auto fill_begin = [&](int w) { return (int32_t)std::min<int64_t>(m_s, (int64_t)w * rows_per_buf); };
+    // host threads gather the sample rows of fills [w0, w1) (at most two: one per buffer) into the staging buffers
+    auto gather_async = [&](int w0, int w1) {
+      const int32_t a = fill_begin(w0), b = fill_begin(w1);
+      float* const pin[2] = {static_cast<float*>(sp.buf[0]), static_cast<float*>(sp.buf[1])};
+      for (int t = 0; t < nthr; ++t)
+        workers.emplace_back([=] {
+          for (int32_t r = a + (int32_t)((int64_t)(b - a) * t / nthr); r < a + (int32_t)((int64_t)(b - a) * (t + 1) / nthr); ++r) {
+            const int32_t row = knn_sample_lattice_row(knn_sample_index(r, m_s, gsz, G), m_s, N);
+            const int w = (int)(r / rows_per_buf);
+            std::memcpy(pin[w & 1] + (size_t)(r - (int64_t)w * rows_per_buf) * D, host_Y + (size_t)row * D, row_bytes);
+          }
+        });
+    };
+    auto join_workers = [&] {
+      for (auto& t : workers) t.join();
+      workers.clear();
+    };
+    gather_async(0, std::min(2, nfill));
     // (events are made when first used: twenty-odd creations are 0.1 ms the first transfer need not wait for)
     auto E = [&](hipEvent_t& e) -> hipEvent_t {
       if (e == nullptr) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -414,25 +430,40 @@ void stream_pieces(L& h, const float* host_Y, const std::vector<int32_t>& starts
       if (c1 > c0)
         launch_panel_filter(p_img, pp, N, 0, pp.nrb, p_tau, sym_dev.bucket_ent, sym_dev.bucket_cnt, q + 1, cus, s, &sym_dev, 0, 1, c0, c1);
     };
-    const int lead = 1;  // pieces that travel while the sample is being gathered (25 MB in ~0.5 ms: one piece's time on the bus)
-    for (int j = 0; j < lead; ++j) {
-      send_piece(j);
-      queue_rows(j);
+    const int lead = 1;  // pieces that travel while the sample's first fills are being gathered (25 MB in ~0.5 ms: one piece's time on the bus)
+    int next_piece = 0;
+    for (; next_piece < lead; ++next_piece) {
+      send_piece(next_piece);
+      queue_rows(next_piece);
     }
     smp_raw.alloc((size_t)m_s * D);
     smp_n.alloc((size_t)m_s * ldn);
-    for (auto& t : workers) t.join();
-    workers.clear();
-    HIP_CHECK(hipMemcpyAsync(smp_raw.p, pin0, (size_t)half_rows * row_bytes, hipMemcpyHostToDevice, up));
-    if (m_s > half_rows)
-      HIP_CHECK(hipMemcpyAsync(smp_raw.p + (size_t)half_rows * D, pin1, (size_t)(m_s - half_rows) * row_bytes, hipMemcpyHostToDevice, up));
-    HIP_CHECK(hipEventRecord(sp.ev[0], up));
-    HIP_CHECK(hipStreamWaitEvent(h.stream, sp.ev[0], 0));  // the sample image: unit rows of the gathered anchors, in sample order
+    // fill w: staging buffer -> its rows of the gathered sample; the buffer is free again when sp.ev[w & 1] has fired
+    auto ship = [&](int w) {
+      const int32_t a = fill_begin(w), b = fill_begin(w + 1);
+      HIP_CHECK(hipMemcpyAsync(smp_raw.p + (size_t)a * D, sp.buf[w & 1], (size_t)(b - a) * row_bytes, hipMemcpyHostToDevice, up));
+      HIP_CHECK(hipEventRecord(sp.ev[w & 1], up));
+    };
+    join_workers();
+    for (int w = 0; w < std::min(2, nfill); ++w) ship(w);
+    for (int w = 2; w < nfill; ++w) {
+      HIP_CHECK(hipEventSynchronize(sp.ev[w & 1]));  // (fill w - 2 has left the buffer)
+      gather_async(w, w + 1);
+      if (next_piece < pieces) {  // the bus and the row kernels work while the host threads gather
+        send_piece(next_piece);
+        queue_rows(next_piece);
+        ++next_piece;
+      }
+      join_workers();
+      ship(w);
+    }
+    HIP_CHECK(hipEventRecord(E(ev_landed), up));
+    HIP_CHECK(hipStreamWaitEvent(h.stream, E(ev_landed), 0));  // the sample image: unit rows of the gathered anchors, in sample order
     launch_normalize_rows(smp_raw.p, D, smp_n.p, ldn, m_s, D, h.stream);
     launch_panel_sample_rows(smp_n.p, ldn, p_smp, pp, m_s, D, h.stream);
     HIP_CHECK(hipEventRecord(E(ev_sample), h.stream));
-    for (int j = 0; j < lead; ++j) queue_sweep(j);
-    for (int j = lead; j < pieces; ++j) {
+    for (int j = 0; j < next_piece; ++j) queue_sweep(j);
+    for (int j = next_piece; j < pieces; ++j) {
       send_piece(j);
       queue_rows(j);
       queue_sweep(j);
@@ -618,7 +649,7 @@ static bool build_graph_once(L& h, const float* host_Y) {
       // anchors that arrive cluster by cluster packs each cluster into few tiles -- 3072 rows holding 7.7 clusters of 401 gave
       // every row 17 cluster mates per column tile, more than a wave's hit list takes from one tile)
       const int64_t rows = m * chunk_rows, pieces = N / rows;
-      if (pieces >= 3 && (int64_t)N * row_bytes >= ((int64_t)h.create_min_mb << 20) && smp_bytes <= 2 * (int64_t)kStageBytes) {
+      if (pieces >= 3 && (int64_t)N * row_bytes >= ((int64_t)h.create_min_mb << 20) && smp_bytes <= 8 * (int64_t)kStageBytes) {  // (up to eight fills of the two staging buffers: stream_pieces)
         for (int64_t j = 0; j < pieces; ++j) piece_starts.push_back((int32_t)(j * rows));
         knn_panel_set_pieces(pp, N, piece_starts.data(), (int)piece_starts.size());
       }

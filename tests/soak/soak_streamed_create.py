@@ -7,9 +7,10 @@ i.i.d. / clustered-shuffled / grouped (cluster by cluster, cluster sizes 20-600)
 equal bit for bit (structure, capped adjacency, weights, sqrt degrees) -- or, where either build sent rows to the exact fp32
 kernel (printed), differ only in float64-proven rank-k near-ties of those routes' different summation orders, as between any
 two routes (soak_panel.py) --, Y and U must be the caller's array, and a streamed build must not send more than a handful of
-rows more to the exact kernel than the whole-array one.  Lattices the streamed create does not serve (sample > 32 MB, padded
-row pitch) show as 0 pieces.
-usage: soak_streamed_create.py [seed] [cases]"""
+rows more to the exact kernel than the whole-array one.  Lattices the streamed create does not serve (padded row pitch, pieces
+too few for their hit lists) show as 0 pieces.  `big` (round 6): 700-1100 MB of anchors with a shallow k, i.e. threshold samples
+of more than the two 32 MB staging buffers -- the sample then travels in three or more fills, a piece of anchors between them.
+usage: soak_streamed_create.py [seed] [cases] [big]"""
 import os
 import sys
 
@@ -20,6 +21,7 @@ import oscillink_amd as amd  # noqa: E402
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(seed)
 bad = 0
 
@@ -55,7 +57,7 @@ def create(Y, k, stream):
 
 for t in range(count):
     D = int(rng.choice([96, 128, 200, 256, 320, 384, 385, 448, 512, 640, 700, 768, 800, 896, 1152, 1280, 1536, 2048]))
-    mb = float(rng.uniform(66, 400))
+    mb = float(rng.uniform(700, 1100)) if big else float(rng.uniform(66, 400))
     N = int(mb * 1048576 / (4 * D))
     if t % 3 == 0:
         N = max(3072 * 8, N // 3072 * 3072)  # a whole number of column chunks

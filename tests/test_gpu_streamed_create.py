@@ -54,7 +54,10 @@ SHAPES = [(40000, 512, 16, "iid"), (30000, 768, 32, "clustered"), (60000, 384, 1
           # D > 768: the wide tile core (k_tile_thr2) takes chunk windows too, in pieces of >= 176 x hit bound rows (42k at k = 12)
           (140000, 896, 12, "grouped300"),
           # a threshold sample of more than one staging buffer (35.8 MB: two transfers)
-          (140000, 768, 8, "iid")]
+          (140000, 768, 8, "iid"),
+          # ... and of more than both (round 6: 76.7 MB = three fills, the third gathered while the second piece travels;
+          # configs 4 and 5 have 128 / 102 MB); two row groups per wave in the main sweep (2344 row blocks)
+          (300000, 768, 8, "iid")]
 
 
 @pytest.mark.parametrize("N,D,k,kind", SHAPES)
