@@ -617,8 +617,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             wcnt[r] = 0;
           }
           if (test && add > 0) {
-            unsigned* const hd = s_hdr + (wave * NRG + r) * HCAP;
-            v4f* const sc = s_sc + (wave * NRG + r) * HCAP;
+            // (LDS byte addresses of this (wave, row group)'s header and score lists: the low half of a flat LDS address)
+            const unsigned hdb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(s_hdr + (wave * NRG + r) * HCAP));
+            const unsigned scb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(s_sc + (wave * NRG + r) * HCAP));
             // (the lane's part of the header -- pass, tile of the item, lane, and the half's row offset 4 h -- in ONE register made
             // opaque to hipcc: left to itself it hoists the sixteen (row register | 4 h) constants out of every loop and, in the
             // two-row-group shape at D = 768, spills them: a scratch reload + vmcnt(0) -- a drain of the DMA ring -- per entry)
@@ -631,12 +632,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               constexpr int g = NT == 4 ? decltype(GC)::value : 2 * decltype(GC)::value;  // (first) row register of the entry
               const unsigned long long m = fm[decltype(GC)::value];
               if (m != 0ull) {
-                const int pos = wcnt[r] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (((m >> lane) & 1ull) && pos < HCAP) {
-                  hd[pos] = ((unsigned)((g & 3) + 8 * (g >> 2)) << 10) + tag;  // (disjoint bits: local row = (g & 3) + 8 (g >> 2) + 4 h)
-                  if constexpr (NT == 4) sc[pos] = v4f{acc[r][0][g], acc[r][1][g], acc[r][2][g], acc[r][3][g]};
-                  else sc[pos] = v4f{acc[r][0][g], acc[r][1][g], acc[r][0][g + 1], acc[r][1][g + 1]};
-                }
+                // The append of one union mask, 13 instructions written out (round 6; hipcc's own form of the same statement
+                // took 21: a per-lane bit test against two lane-mask registers, four moves to pack the scores for one 16-byte
+                // store, separate compare / and / saveexec / branch): exec <- the mask; position = list length + rank among the
+                // mask's lanes; lanes beyond the list's end drop out; header by one store, the four scores by two ds_write2_b32
+                // straight from their accumulator registers.
+                constexpr unsigned hconst = (unsigned)((g & 3) + 8 * (g >> 2)) << 10;  // (disjoint bits: local row = (g & 3) + 8 (g >> 2) + 4 h)
+                const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+                unsigned long long sv_;
+                unsigned p_, a1_, a2_, hv_;
+                const float s0_ = acc[r][0][g], s1_ = acc[r][1][g];
+                const float s2_ = NT == 4 ? acc[r][2 % NT][g] : acc[r][0][g + 1], s3_ = NT == 4 ? acc[r][3 % NT][g] : acc[r][1][g + 1];
+                asm volatile(
+                    "s_and_saveexec_b64 %[sv], %[m]\n\t"
+                    "v_mbcnt_lo_u32_b32 %[p], %[mlo], 0\n\t"
+                    "v_mbcnt_hi_u32_b32 %[p], %[mhi], %[p]\n\t"
+                    "v_add_u32 %[p], %[wc], %[p]\n\t"
+                    "v_cmp_gt_u32 vcc, %[cap], %[p]\n\t"
+                    "s_and_b64 exec, exec, vcc\n\t"
+                    "v_lshl_add_u32 %[a1], %[p], 2, %[hdb]\n\t"
+                    "v_lshl_add_u32 %[a2], %[p], 4, %[scb]\n\t"
+                    "v_add_u32 %[hv], %[hc], %[tag]\n\t"
+                    "ds_write_b32 %[a1], %[hv]\n\t"
+                    "ds_write2_b32 %[a2], %[s0], %[s1] offset1:1\n\t"
+                    "ds_write2_b32 %[a2], %[s2], %[s3] offset0:2 offset1:3\n\t"
+                    "s_mov_b64 exec, %[sv]"
+                    : [sv] "=&s"(sv_), [p] "=&v"(p_), [a1] "=&v"(a1_), [a2] "=&v"(a2_), [hv] "=&v"(hv_)
+                    : [m] "s"(m), [mlo] "s"(mlo), [mhi] "s"(mhi), [wc] "s"(wcnt[r]), [cap] "n"(HCAP), [hdb] "s"(hdb), [scb] "s"(scb),
+                      [hc] "n"(hconst), [tag] "v"(tag), [s0] "v"(s0_), [s1] "v"(s1_), [s2] "v"(s2_), [s3] "v"(s3_)
+                    : "vcc", "memory");
                 wcnt[r] += __popcll(m);
               }
             });
