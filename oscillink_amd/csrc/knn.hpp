@@ -46,7 +46,8 @@ void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* ca
                       float* out_val, int32_t* out_idx, int clip, hipStream_t s);
 void launch_knn_rescore(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t D, int32_t N, const int32_t* cidx,
                         const float* cval, int32_t k, float delta, float* out_val, int32_t* out_idx, int32_t* fail_rows,
-                        int32_t* fail_count, hipStream_t s, const KnnRowMap* map = nullptr);  // map: the plan's rows are IMAGE rows (KnnRowMap)
+                        int32_t* fail_count, hipStream_t s, const KnnRowMap* map = nullptr, float* pair_sc = nullptr,
+                        int32_t* pair_pos = nullptr);  // pair_sc / pair_pos (N x keep each): score every undirected candidate pair once (knn_kernels.hip)  // map: the plan's rows are IMAGE rows (KnnRowMap)
 void launch_mutual_ell(const float* kval, const int32_t* kidx, int32_t N, int32_t k, int32_t width, int32_t* ell_col,
                        float* ell_a, int32_t* deg, hipStream_t s);
 void launch_cap_and_normalize(float* ell_a, float* ell_w, const int32_t* ell_col, const int32_t* deg, int32_t width,

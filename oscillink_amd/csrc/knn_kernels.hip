@@ -801,6 +801,41 @@ __global__ __launch_bounds__(256) void k_to_f16(const float* Yn, int32_t ldn, _F
     Yh[row * ldh + c] = c < D ? (_Float16)(16.0f * Yn[row * ldn + c]) : (_Float16)0.0f;
 }
 
+// The re-scoring's selection and proof, shared by its one-launch and its two-launch (pair) form: lane l holds candidate slots
+// l and l + 64 (exact score sc, lattice id; id < 0: no candidate); writes the k best by (score desc, index asc), clipped at
+// 0, and queues the row for the exact kernel unless "every left-out column has fp16 score <= the list's last" proves it.
+__device__ __forceinline__ void rescore_select_and_prove(const float (&sc)[2], const int (&id)[2], int nvalid, int lane, int row, int32_t KC,
+                                                         int32_t k, float delta, const float* cval, float* out_val, int32_t* out_idx,
+                                                         int32_t* fail_rows, int32_t* fail_count) {
+  int rank[2] = {0, 0};
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2) {
+    for (int l = 0; l < 64; ++l) {
+      const float ov = __shfl(sc[m2], l, 64);
+      const int oi = __shfl(id[m2], l, 64);
+      if (oi < 0) continue;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        if (id[m] >= 0 && (ov > sc[m] || (ov == sc[m] && oi < id[m]))) ++rank[m];
+    }
+  }
+  float tk = NEG;  // exact k-th best score
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    if (id[m] >= 0 && rank[m] < k) {
+      out_val[(size_t)row * k + rank[m]] = fmaxf(sc[m], 0.f);
+      out_idx[(size_t)row * k + rank[m]] = id[m];
+    }
+    if (id[m] >= 0 && rank[m] == k - 1) tk = sc[m];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tk = fmaxf(tk, __shfl_xor(tk, o, 64));
+  if (lane == 0 && nvalid == KC) {  // a full list: columns were left out, prove none of them belongs
+    const float vlast = cval[(size_t)row * KC + KC - 1] * (1.0f / 256.0f);
+    if (!(vlast + delta < tk)) fail_rows[atomicAdd(fail_count, 1)] = row;
+  }
+}
+
 // Exact fp32 re-scoring of the prefilter's candidates, one wave per row.
 //   score(i,j) = sum_k Yn_i[k] Yn_j[k], lanes stride k, butterfly sum: symmetric in (i,j) bit for bit.
 //   final list = best k by (score desc, index asc), clipped at 0 (graph.py:46-49, 62).
@@ -889,34 +924,137 @@ __global__ __launch_bounds__(256) void k_knn_rescore(const float* __restrict__ Y
       }
     }
   }
-  // rank of my slots among all valid candidates
-  int rank[2] = {0, 0};
+  rescore_select_and_prove(sc, id, nvalid, lane, row, KC, k, delta, cval, out_val, out_idx, fail_rows, fail_count);
+}
+
+// ---- the same re-scoring with every undirected candidate pair scored ONCE (round 6) ------------------------------------------
+// score(i, j) is symmetric bit for bit (above), and most candidate pairs are mutual -- j is a candidate of i and i one of j:
+// the one-launch kernel gathers Yn_j for row i AND Yn_i for row j (config 3: 48 x 3 KB per row, 14.7 GB at the HBM ceiling;
+// config 5: 96 x 6 KB, 118 GB, 16 of a 98 ms build).  Here row i scores candidate j itself unless j < i and i stands in j's
+// list -- then row j scores the pair (for it i > j) and row i only notes where: pos[i][q] = j KC + (i's slot in j's list).  A
+// lookup reads j's list (KC ints: 192 B against a 3 KB row).  Launch 1 (k_knn_rescore_pair) writes the scores it computes
+// and the notes; launch 2 (k_knn_rescore_finish) gives every slot its score -- its own or the noted one -- and runs the
+// one-launch kernel's selection and proof on them.  Single-process builds only: every row's list must be at hand.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_knn_rescore_pair(const float* __restrict__ Yn, int32_t ldn, int32_t N, int32_t row_begin,
+                                                          int32_t row_end, const int32_t* __restrict__ cidx, int32_t KC,
+                                                          float* __restrict__ sc_g, int32_t* __restrict__ pos_g, int32_t mapped,
+                                                          KnnRowMap map) {
+  constexpr int EU = 4;  // candidates in flight
+  const int lane = threadIdx.x & 63;
+  const int irow = row_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (irow >= row_end) return;
+  const int row = mapped ? knn_map_lattice_row(map, N, irow) : irow;
+  const float* yi = Yn + (size_t)row * ldn;
+  float4 yr[NCH > 0 ? NCH : 1];
+  if constexpr (NCH > 0) {
 #pragma unroll
-  for (int m2 = 0; m2 < 2; ++m2) {
-    for (int l = 0; l < 64; ++l) {
-      const float ov = __shfl(sc[m2], l, 64);
-      const int oi = __shfl(id[m2], l, 64);
-      if (oi < 0) continue;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-        if (id[m] >= 0 && (ov > sc[m] || (ov == sc[m] && oi < id[m]))) ++rank[m];
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = lane * 4 + ch * 256;
+      yr[ch] = c < ldn ? ld4(yi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  float tk = NEG;  // exact k-th best score
+  auto partial = [&](int j) -> float {  // this lane's share of <Yn_row, Yn_j>: k_knn_rescore's, term for term
+    const float* yj = Yn + (size_t)j * ldn;
+    float s = 0.f;
+    if constexpr (NCH > 0) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c = lane * 4 + ch * 256;
+        if (c < ldn) {
+          const float4 a = yr[ch], b = ld4(yj + c);
+          s = fmaf(a.x, b.x, s);
+          s = fmaf(a.y, b.y, s);
+          s = fmaf(a.z, b.z, s);
+          s = fmaf(a.w, b.w, s);
+        }
+      }
+    } else {
+      for (int c = lane * 4; c < ldn; c += 256) {
+        const float4 a = ld4(yi + c), b = ld4(yj + c);
+        s = fmaf(a.x, b.x, s);
+        s = fmaf(a.y, b.y, s);
+        s = fmaf(a.z, b.z, s);
+        s = fmaf(a.w, b.w, s);
+      }
+    }
+    return s;
+  };
+  for (int q0 = 0; q0 < KC; q0 += EU) {
+    int jj[EU], look0[EU], look1[EU], at[EU];
+    float ss[EU];
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int q = q0 + u;
+      jj[u] = q < KC ? cidx[(size_t)row * KC + q] : -1;
+      if (jj[u] >= N) jj[u] = -1;  // uniform
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {  // the lists of the candidates below this row: all loads first
+      look0[u] = look1[u] = -2;
+      if (jj[u] >= 0 && jj[u] < row) {
+        if (lane < KC) look0[u] = cidx[(size_t)jj[u] * KC + lane];
+        if (lane + 64 < KC) look1[u] = cidx[(size_t)jj[u] * KC + lane + 64];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      at[u] = -1;
+      if (jj[u] >= 0 && jj[u] < row) {
+        const unsigned long long b0 = __ballot(look0[u] == row), b1 = __ballot(look1[u] == row);
+        if (b0 != 0ull) at[u] = __ffsll((long long)b0) - 1;
+        else if (b1 != 0ull) at[u] = 64 + __ffsll((long long)b1) - 1;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) ss[u] = (jj[u] >= 0 && at[u] < 0) ? partial(jj[u]) : 0.f;
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ss[u] += __shfl_xor(ss[u], o, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      const int q = q0 + u;
+      if (jj[u] < 0 || lane != 0) continue;
+      if (at[u] >= 0) {
+        pos_g[(size_t)row * KC + q] = jj[u] * KC + at[u];  // (N KC < 2^31: checked by the launcher)
+      } else {
+        pos_g[(size_t)row * KC + q] = -1;
+        sc_g[(size_t)row * KC + q] = ss[u];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_knn_rescore_finish(int32_t N, int32_t row_begin, int32_t row_end, const int32_t* __restrict__ cidx,
+                                                            const float* __restrict__ cval, int32_t KC, int32_t k, float delta,
+                                                            const float* __restrict__ sc_g, const int32_t* __restrict__ pos_g,
+                                                            float* out_val, int32_t* out_idx, int32_t* fail_rows, int32_t* fail_count,
+                                                            int32_t mapped, KnnRowMap map) {
+  const int lane = threadIdx.x & 63;
+  const int irow = row_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (irow >= row_end) return;
+  const int row = mapped ? knn_map_lattice_row(map, N, irow) : irow;
+  float sc[2] = {NEG, NEG};
+  int id[2] = {-1, -1};
+  int nvalid = 0;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    if (id[m] >= 0 && rank[m] < k) {
-      out_val[(size_t)row * k + rank[m]] = fmaxf(sc[m], 0.f);
-      out_idx[(size_t)row * k + rank[m]] = id[m];
+    const int q = lane + 64 * m;
+    bool ok = false;
+    if (q < KC) {
+      const int j = cidx[(size_t)row * KC + q];
+      if (j >= 0 && j < N) {
+        const int at = pos_g[(size_t)row * KC + q];
+        id[m] = j;
+        sc[m] = sc_g[at < 0 ? (size_t)row * KC + q : (size_t)at];
+        ok = true;
+      }
     }
-    if (id[m] >= 0 && rank[m] == k - 1) tk = sc[m];
+    nvalid += __popcll(__ballot(ok));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tk = fmaxf(tk, __shfl_xor(tk, o, 64));
-  if (lane == 0 && nvalid == KC) {  // a full list: columns were left out, prove none of them belongs
-    const float vlast = cval[(size_t)row * KC + KC - 1] * (1.0f / 256.0f);
-    if (!(vlast + delta < tk)) fail_rows[atomicAdd(fail_count, 1)] = row;
-  }
+  rescore_select_and_prove(sc, id, nvalid, lane, row, KC, k, delta, cval, out_val, out_idx, fail_rows, fail_count);
 }
 
 // ---- exact scores of a FEW query rows against all columns (the prefilter routes' fallback when only a handful of rows
@@ -1299,13 +1437,32 @@ void launch_knn_merge(const KnnPlan& p, const float* cand_val, const int32_t* ca
 
 void launch_knn_rescore(const KnnPlan& p, const float* Yn, int32_t ldn, int32_t D, int32_t N, const int32_t* cidx,
                         const float* cval, int32_t k, float delta, float* out_val, int32_t* out_idx, int32_t* fail_rows,
-                        int32_t* fail_count, hipStream_t s, const KnnRowMap* map) {
+                        int32_t* fail_count, hipStream_t s, const KnnRowMap* map, float* pair_sc, int32_t* pair_pos) {
   const int row_begin = p.rb_begin * BM, row_end = std::min(N, (p.rb_begin + p.rb_count) * BM);
   const int32_t mapped = map != nullptr ? 1 : 0;
   const KnnRowMap rm = map != nullptr ? *map : knn_row_map(N, nullptr, 1, false);
   if (row_end <= row_begin) return;
   const dim3 grid((unsigned)((row_end - row_begin + 3) / 4)), block(256);
   const int nch = (ldn + 255) / 256;
+  // pair form (every undirected candidate pair scored once): the caller's scratch arrays ask for it; it needs every row's list
+  // in THIS launch (a single-process build's whole row range) and slot addresses that fit an int
+  if (pair_sc != nullptr && pair_pos != nullptr && row_begin == 0 && row_end == N && (int64_t)N * p.keep < (int64_t)1 << 31) {
+#define OSC_RESCORE_PAIR(NN) \
+  hipLaunchKernelGGL(k_knn_rescore_pair<NN>, grid, block, 0, s, Yn, ldn, N, row_begin, row_end, cidx, p.keep, pair_sc, pair_pos, mapped, rm)
+    if (nch <= 1) OSC_RESCORE_PAIR(1);
+    else if (nch == 2) OSC_RESCORE_PAIR(2);
+    else if (nch == 3) OSC_RESCORE_PAIR(3);
+    else if (nch == 4) OSC_RESCORE_PAIR(4);
+    else if (nch <= 6) OSC_RESCORE_PAIR(6);
+    else if (nch <= 8) OSC_RESCORE_PAIR(8);
+    else OSC_RESCORE_PAIR(0);
+#undef OSC_RESCORE_PAIR
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_knn_rescore_finish, grid, block, 0, s, N, row_begin, row_end, cidx, cval, p.keep, k, delta, pair_sc, pair_pos,
+                       out_val, out_idx, fail_rows, fail_count, mapped, rm);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
 #define OSC_RESCORE(NN)                                                                                              \
   hipLaunchKernelGGL(k_knn_rescore<NN>, grid, block, 0, s, Yn, ldn, D, N, row_begin, row_end, cidx, cval, p.keep, k, \
                      delta, out_val, out_idx, fail_rows, fail_count, mapped, rm)

@@ -594,7 +594,8 @@ static bool build_graph_once(L& h, const float* host_Y) {
   if (h.knn_mode == 2) panel = false;
   h.knn_panel = panel;
   h.knn_sweep = 0;
-  DevBuf<float> cand_val, cval;
+  DevBuf<float> cand_val, cval, pair_sc;  // (pair_sc / pair_pos: the re-scoring's scratch where it scores every undirected pair once)
+  DevBuf<int32_t> pair_pos;
   DevBuf<int32_t> cand_idx, cidx, fail_rows, fail_count;
   DevBuf<float> Yh;  // fp16 image, viewed as float slots
   const int32_t ldh = ((h.D + 63) / 64) * 64;
@@ -801,8 +802,16 @@ static bool build_graph_once(L& h, const float* host_Y) {
       launch_panel_select(pp, rb_begin, rb_count, N, p_hits.p, p_hcnt.p, cval.p, cidx.p, fail_rows.p, fail_count.p,
                           h.stream, pp.sym ? &sym_dev : nullptr);
       if (knn_debug) fprintf(stderr, "[knn] after the select: %d rows without a candidate list\n", failed_so_far());
+      // (single-process builds of rows of >= 640 columns: every undirected candidate pair is scored once -- two launches and two
+      // N x keep scratch arrays.  A lookup in the partner's list costs keep x 4 bytes and a dependent round trip per candidate,
+      // which short rows do not repay: build with / without, profiles/r06_rescore_ab.txt: config 3 12.07 / 12.54 ms, config 5
+      // 91.7 / 96.1, config 4 (384 columns) 413.9 / 413.2, 40 000 x 256 3.68 / 3.20)
+      if (h.knn_rescore_pair && h.D >= 640 && parts == 1 && !exchange && h.comm == nullptr && (int64_t)N * keep_f < ((int64_t)1 << 31)) {
+        pair_sc.alloc((size_t)N * keep_f);
+        pair_pos.alloc((size_t)N * keep_f);
+      }
       launch_knn_rescore(plan, Yn.p, ldn, h.D, N, cidx.p, cval.p, k, delta, h.knn_val.p, h.knn_idx.p, fail_rows.p,
-                         fail_count.p, h.stream, pp.scatter != 1 ? &pp.map : nullptr);
+                         fail_count.p, h.stream, pp.scatter != 1 ? &pp.map : nullptr, pair_sc.p, pair_pos.p);
       if (knn_debug) fprintf(stderr, "[knn] after the re-scoring: %d rows unproven\n", failed_so_far());
     } else if (prefilter) {
       const KnnPlan plan = knn_plan(N, keep_f, slots, rb_begin, rb_count, true, h.knn_splits);

@@ -1731,3 +1731,42 @@ def test_non_finite_anchor_rows_on_the_wide_tile_core(amd, monkeypatch):
     assert info["prefilter"] == 2
     assert (np.diff(rp)[nonfinite + zero] == 0).all() and not np.isin(col, nonfinite + zero).any()
     assert np.array_equal(rp, rp_e) and np.array_equal(col, col_e) and np.allclose(a, a_e, rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("N,D,k,kind,mode", [(20000, 700, 32, "clustered", "panel"), (16400, 768, 16, "dups", "panel"),
+                                              (20000, 1000, 40, "iid", "panel"), (12000, 640, 24, "iid", "prefilter"),
+                                              (33000, 768, 8, "grouped", "panel")])
+def test_rescoring_every_candidate_pair_once_gives_the_same_lists(amd, N, D, k, kind, mode, monkeypatch):
+    """Round 6: in single-process builds of rows of >= 640 columns the exact re-scoring scores every undirected candidate pair
+    once -- row i leaves the pairs (i, j), j < i, in which it stands in j's list to row j and fetches j's result
+    (k_knn_rescore_pair + k_knn_rescore_finish) -- instead of from both ends (k_knn_rescore, OSC_KNN_RESCORE_PAIR=0).  The exact
+    dot product is symmetric bit for bit, so lists (indices AND similarities), proofs, fallback rows and lattices are identical:
+    clustered anchors (many unproven rows), exact duplicates (ties), the tile core beyond 768 columns, the tile prefilter's
+    lists, anchors that arrive cluster by cluster."""
+    from tests._fullsize import device_knn_lists
+
+    rng = np.random.default_rng(N + D)
+    if kind == "iid":
+        Y = rng.standard_normal((N, D), dtype=np.float32)
+    elif kind == "dups":
+        base = rng.standard_normal((N // 40 + 1, D), dtype=np.float32)
+        Y = base[np.arange(N) % base.shape[0]].copy()
+    else:
+        nc = N // 100
+        Y = rng.standard_normal((nc, D), dtype=np.float32)[np.repeat(np.arange(nc), 100)][:N]
+        Y = (Y + 0.35 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+        if kind == "clustered":
+            Y = Y[rng.permutation(N)]
+    monkeypatch.setenv("OSC_KNN_MODE", mode)
+    got = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("OSC_KNN_RESCORE_PAIR", pair)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        got[pair] = (device_knn_lists(lat, N, k), lat.graph_csr(), lat.build_info())
+        lat.close()
+    (idx1, val1), csr1, info1 = got["1"]
+    (idx0, val0), csr0, info0 = got["0"]
+    assert info1["prefilter"] == info0["prefilter"] and info1["fallback_rows"] == info0["fallback_rows"]
+    assert np.array_equal(idx1, idx0) and np.array_equal(val1, val0)
+    for a, b in zip(csr1, csr0):
+        assert np.array_equal(a, b)
