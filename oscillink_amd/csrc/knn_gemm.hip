@@ -1414,7 +1414,9 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
     __syncthreads();
     for (int step = 0; step < total; ++step) {
       const int stage = step & 1;
+#ifndef OSC_TILE2_NODMA  // measurement only (wrong lattice): the sweep on stale stages -- what the staging costs it
       if (issued < total) issue_next();
+#endif
       const char* Asw = ldsc + (size_t)stage * T2_STAGE + (size_t)(64 * rg + l31) * 128;
       const char* Bsw = ldsc + (size_t)stage * T2_STAGE + 256 * 128 + (size_t)(128 * cg + l31) * 128;
 #pragma unroll
