@@ -283,3 +283,42 @@ def test_bench_refuses_more_gpus_than_devices_before_any_build():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env2, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == "" and "WORLD_SIZE=2" in r.stderr
+
+
+def test_panel_kernels_touch_m0_only_through_their_dma_setup(tmp_path):
+    """csrc/knn_gemm.hip (round 6): the K loop of k_panel writes M0 -- the LDS destination of an LDS-DMA piece -- with one
+    `s_add_i32 m0, base, literal` and issues the `global_load_lds_dwordx4` a few instructions later, WITHOUT saving or restoring
+    M0: that is sound only while nothing hipcc generates inside those kernels reads or writes M0.  Disassemble the kernels
+    (cross-compiled for gfx950, no GPU needed) and hold hipcc to it; the hazard would otherwise surface only as wrong hit lists
+    on the GPU box."""
+    import subprocess
+
+    from oscillink_amd import _build
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    asm = tmp_path / "knn_gemm.s"
+    r = subprocess.run([hipcc, *_build.FLAGS, "--cuda-device-only", "-S", os.path.join(_build.CSRC, "knn_gemm.hip"), "-o", str(asm)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    kernels, cur = {}, None
+    for line in asm.read_text().splitlines():
+        m = re.match(r"^(_ZN3osc12_GLOBAL__N_17k_panelI\w+):", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = {"set": 0, "dma": 0, "other": []}
+            continue
+        if cur is None:
+            continue
+        code = line.split(";")[0].strip()
+        if code.startswith("s_endpgm"):
+            cur = None
+        elif code.startswith("s_add_i32 m0,"):
+            kernels[cur]["set"] += 1
+        elif code.startswith("global_load_lds_dwordx4"):
+            kernels[cur]["dma"] += 1
+        elif re.search(r"\bm0\b", code):
+            kernels[cur]["other"].append(code)
+    assert len(kernels) >= 10, sorted(kernels)  # sample / full / half sweep x K depth 6, 12 x one, two row groups
+    for name, k in kernels.items():
+        assert not k["other"], (name, k["other"][:4])
+        assert k["set"] > 0 and k["set"] == k["dma"], (name, k["set"], k["dma"])  # one M0 write per piece
