@@ -118,3 +118,34 @@ def build_lattice(req: Any, api_key: Optional[str] = None, *,
             raise ServiceError(400, "chain must have >=2 nodes")
         lat.add_chain(list(chain), lamP=float(_get(p, "lamP", 0.0)))
     return lat, N, D, k_eff, {"lamG": lamG, "lamC": lamC, "lamQ": lamQ, "kneighbors": k_eff}, profile_id
+
+
+def warmup(shapes=((1200, 128, 16),), *, requests: int = 2, seed: int = 0) -> list[dict]:
+    """Pay a process's one-time costs before its first real request: a throw-away request per (N, D, k) -- create, settle,
+    light receipt, bundle -- on every device of OSCILLINK_DEVICES.  The first lattice of a process loads the kernels'
+    code objects, creates the streams, fills the device and pinned-memory pools and registers the staging buffers (config 3's
+    shape: first request 75 ms, steady 31 ms -- profiles/r06_request_latency.txt); the reference has no counterpart (NumPy has
+    nothing to load).  Call it once at service start-up with the largest shapes the deployment expects
+    (`warmup([(100000, 768, 32)])`); returns, per shape and device, the wall-clock of the first and of the last throw-away request."""
+    import time
+
+    backend()
+    rng = np.random.default_rng(seed)
+    out = []
+    for (N, D, k) in shapes:
+        Y = rng.standard_normal((int(N), int(D))).astype(np.float32)
+        psi = (Y[: min(32, int(N))].mean(0) / (np.linalg.norm(Y[: min(32, int(N))].mean(0)) + 1e-12)).astype(np.float32)
+        for dev in devices():
+            ms = []
+            for _ in range(max(1, int(requests))):
+                t0 = time.perf_counter()
+                lat = OscillinkLattice(Y, kneighbors=min(int(k), max(1, int(N) - 1)), device=dev)
+                lat.set_query(psi)
+                lat.settle(max_iters=12, tol=1e-3)
+                lat.set_receipt_detail("light")
+                lat.receipt()
+                lat.bundle(k=min(10, int(N)))
+                lat.close()
+                ms.append(1000.0 * (time.perf_counter() - t0))
+            out.append({"N": int(N), "D": int(D), "k": int(k), "device": int(dev), "first_ms": ms[0], "last_ms": ms[-1]})
+    return out

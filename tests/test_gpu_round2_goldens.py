@@ -155,3 +155,13 @@ def test_service_adapter_builds_like_the_reference_service(amd, monkeypatch):
     monkeypatch.setenv("OSCILLINK_BACKEND", "numpy")
     with pytest.raises(ServiceError):
         build_lattice(req)
+
+
+def test_service_warmup_runs_throwaway_requests(amd):
+    """oscillink_amd.service.warmup: throw-away requests (create, settle, light receipt, bundle, close) per shape and device,
+    so that a service's first real request does not pay the process's one-time costs; reports first / last wall-clock."""
+    from oscillink_amd.service import warmup
+
+    out = warmup([(600, 32, 6), (9000, 64, 8)], requests=2)
+    assert [(o["N"], o["D"], o["k"]) for o in out] == [(600, 32, 6), (9000, 64, 8)]
+    assert all(o["first_ms"] > 0 and o["last_ms"] > 0 for o in out)
