@@ -1639,7 +1639,12 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
   // (round 3, config 4's shape, keep = 24: rho 6 / 8 / 12 / 16 -> build 798 / 790 / 775 / 784 ms with 6 / 1 / 1 / 129 rows sent
   // to the exact kernel; from 24 on the folded group maxima put tau so low that every hit list overflows.  Config 3,
   // keep = 48: 8 / 12 / 16 -> 26.5 / 22.2 / 26.8 ms.  Hence at least 12.)
-  const double rho = rho_env > 0.0 ? rho_env : std::max(12.0, keep / 4.0);
+  // (round 6: beyond 4800 row blocks at most 400 sample tiles -- 51 200 columns -- while rho stays <= 20.  The thresholds are order statistics of <= 128 group maxima, which a
+  // denser sample of a very large lattice does not sharpen, while the sample sweep costs nrb / rho tile passes per row block:
+  // config 4 (7813 row blocks) rho 12 / 16 / 20 / 24 -> build 403 / 399 / 394 / 396 ms, 0 fallback rows each
+  // (scripts/exp/r06/c4_sweep.py); up to 4800 row blocks nothing changes; never beyond 20: 1.5 M x 256 at rho = 29 sent 111
+  // rows to the exact kernel and built slower -- profiles/r06_rho_cap.txt)
+  const double rho = rho_env > 0.0 ? rho_env : std::max(std::max(12.0, keep / 4.0), std::min(20.0, p.nrb / 400.0));
   p.sample_tiles = (int32_t)std::max(24.0, std::min(p.nrb / 2.0, std::round(p.nrb / rho)));
   // tile maxima are folded over groups of consecutive sample tiles so that a row has at most 128 of them (the r-th
   // largest group maximum is still a lower bound of the r-th best sample score)
