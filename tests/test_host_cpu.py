@@ -285,7 +285,7 @@ def test_bench_refuses_more_gpus_than_devices_before_any_build():
     assert r.returncode != 0 and r.stdout.strip() == "" and "WORLD_SIZE=2" in r.stderr
 
 
-def test_panel_kernels_touch_m0_only_through_their_dma_setup(tmp_path):
+def test_panel_kernels_m0_discipline_and_untouched_k_loops(tmp_path):
     """csrc/knn_gemm.hip (round 6): the K loop of k_panel writes M0 -- the LDS destination of an LDS-DMA piece -- with one
     `s_add_i32 m0, base, literal` and issues the `global_load_lds_dwordx4` a few instructions later, WITHOUT saving or restoring
     M0: that is sound only while nothing hipcc generates inside those kernels reads or writes M0.  Disassemble the kernels
@@ -305,10 +305,11 @@ def test_panel_kernels_touch_m0_only_through_their_dma_setup(tmp_path):
         m = re.match(r"^(_ZN3osc12_GLOBAL__N_17k_panelI\w+):", line)
         if m:
             cur = m.group(1)
-            kernels[cur] = {"set": 0, "dma": 0, "other": []}
+            kernels[cur] = {"set": 0, "dma": 0, "other": [], "body": []}
             continue
         if cur is None:
             continue
+        kernels[cur]["body"].append(line.strip())
         code = line.split(";")[0].strip()
         if code.startswith("s_endpgm"):
             cur = None
@@ -322,3 +323,17 @@ def test_panel_kernels_touch_m0_only_through_their_dma_setup(tmp_path):
     for name, k in kernels.items():
         assert not k["other"], (name, k["other"][:4])
         assert k["set"] > 0 and k["set"] == k["dma"], (name, k["set"], k["dma"])  # one M0 write per piece
+        # ... and between a kernel's first and last MFMA -- the hand-placed K loops -- hipcc adds nothing but scalar
+        # instructions (hazard nops, satisfied waits, the barrier, the branch between the two pass bodies): a register copy or a
+        # spill there could read a fragment register before its counted lgkmcnt wait, or stall the DMA ring on a vmcnt(0)
+        body = k["body"]
+        mf = [i for i, t in enumerate(body) if t.startswith("v_mfma")]
+        inasm, foreign = False, []
+        for t in body[mf[0]:mf[-1] + 1]:
+            if t.startswith(";;#ASMSTART"):
+                inasm = True
+            elif t.startswith(";;#ASMEND"):
+                inasm = False
+            elif not inasm and t and not t.startswith((";", ".", "s_")) and not t.startswith("v_mfma"):
+                foreign.append(t)
+        assert not foreign, (name, foreign[:6])
