@@ -1364,11 +1364,17 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
       uint2* const hb = lists + (wave * 2 + r) * T2_CAP;
       const bool special = pct == rb || (pct + 1) * 128 > a.N;
       unsigned long long fm[16];
+      // (round 6, as in k_panel: ONE compare of the register's best score against min(tau_row, the smallest of the lane's four
+      // column thresholds) -- a superset of the exact union, which the per-subtile masks below decide anyway -- with raw v_max3 /
+      // v_min: 4 VALU per row register instead of 11)
+      auto max3r = [](float x, float y, float z) { float m; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(x), "v"(y), "v"(z)); return m; };
+      auto max2r = [](float x, float y) { float m; asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y)); return m; };
+      auto min3r = [](float x, float y, float z) { float m; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(x), "v"(y), "v"(z)); return m; };
+      auto min2r = [](float x, float y) { float m; asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y)); return m; };
+      const float tcmin = min2r(min3r(tc[0], tc[1], tc[2]), tc[3]);
       static_for<0, 16>([&](auto GC) {
         constexpr int g = decltype(GC)::value;
-        bool any = fmaxf(fmaxf(acc[r][0][g], acc[r][1][g]), fmaxf(acc[r][2][g], acc[r][3][g])) > tg[g];
-        any = any | (fmaxf(fmaxf(acc[r][0][g] - tc[0], acc[r][1][g] - tc[1]), fmaxf(acc[r][2][g] - tc[2], acc[r][3][g] - tc[3])) > 0.f);
-        fm[g] = __ballot(any);
+        fm[g] = __ballot(max2r(max3r(acc[r][0][g], acc[r][1][g], acc[r][2][g]), acc[r][3][g]) > min2r(tg[g], tcmin));
       });
       static_for<0, 16>([&](auto GC) {
         constexpr int g = decltype(GC)::value;
@@ -1419,14 +1425,24 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
 #endif
       const char* Asw = ldsc + (size_t)stage * T2_STAGE + (size_t)(64 * rg + l31) * 128;
       const char* Bsw = ldsc + (size_t)stage * T2_STAGE + 256 * 128 + (size_t)(128 * cg + l31) * 128;
+#ifdef OSC_TILE2_NORD  // measurement only (wrong lattice): fragments read once per K step instead of per k16 slice
+      half8 av[2], bv[4];
+#endif
 #pragma unroll
       for (int sl = 0; sl < 4; ++sl) {
         const int co = ((2 * sl + h) ^ swz) * 16;
+#ifndef OSC_TILE2_NORD
         half8 av[2], bv[4];
+#else
+        if (sl == 0) {
+#endif
 #pragma unroll
         for (int r = 0; r < 2; ++r) av[r] = *reinterpret_cast<const half8*>(Asw + (size_t)r * 32 * 128 + co);
 #pragma unroll
         for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const half8*>(Bsw + (size_t)t * 32 * 128 + co);
+#ifdef OSC_TILE2_NORD
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1452,8 +1468,10 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
       } else {
         ++kt;
       }
+#ifndef OSC_TILE2_NOBAR  // measurement only (wrong lattice): no wait for the staged K step, no workgroup barrier
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+#endif
     }
     if (rok) {
       static_for<0, 2>([&](auto RC) {
