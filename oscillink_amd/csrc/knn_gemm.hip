@@ -1213,10 +1213,12 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
 // stages, one workgroup per CU (still two waves per SIMD).  Everything else is k_tile_thr<1>: flat (tile pair, K step)
 // pipeline, threshold test on both sides, fine 8-byte entries in per-(wave, row group) LDS lists that are delivered to the
 // 32-row buckets when the next tile might not fit and at the end of the item.
-constexpr int T2_CAP = 160;
+constexpr int T2_CAP = 160;  // (the planner's measure of a list: fine entries; the kernel's lists hold T2_HC coarse ones since round 6)
+constexpr int T2_HC = 72;    // coarse entries (20 bytes: header + a row register's four subtile scores) per (wave, row group) list
 constexpr unsigned T2_STAGE = (256 + 256) * 128;
 constexpr size_t T2_LDS = (size_t)2 * T2_STAGE;
-constexpr size_t T2_LDS_ALL = T2_LDS + (size_t)16 * T2_CAP * 8 + (size_t)TT_TILES * 512 + (size_t)8 * 8 * TT_TILES * 4;
+constexpr size_t T2_LISTS = (size_t)16 * T2_HC * 20;  // [16 lists][T2_HC] headers, then [16][T2_HC] score quads
+constexpr size_t T2_LDS_ALL = T2_LDS + T2_LISTS + (size_t)TT_TILES * 512 + (size_t)8 * 8 * TT_TILES * 4;
 
 __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const int nkt) {
   extern __shared__ __attribute__((aligned(1024))) float lds[];
@@ -1229,9 +1231,10 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
   const int rg = wave >> 1, cg = wave & 1;  // the wave's 64 rows (of the set's 256) and 128 columns (of the tile pair's 256)
   const unsigned lds_base = (unsigned)(size_t)lds;
   const char* ldsc = reinterpret_cast<const char*>(lds);
-  uint2* const lists = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds) + T2_LDS);
-  float* const s_tc = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + T2_LDS + (size_t)16 * T2_CAP * 8);
-  int* const s_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + T2_LDS + (size_t)16 * T2_CAP * 8 + (size_t)TT_TILES * 512) +
+  unsigned* const t2_hdr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + T2_LDS);
+  v4f* const t2_sc = reinterpret_cast<v4f*>(reinterpret_cast<char*>(lds) + T2_LDS + (size_t)16 * T2_HC * 4);
+  float* const s_tc = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + T2_LDS + T2_LISTS);
+  int* const s_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + T2_LDS + T2_LISTS + (size_t)TT_TILES * 512) +
                      wave * (8 * TT_TILES);
   int* const s_base = s_cnt + 4 * TT_TILES;
   const size_t ldh = (size_t)a.ldh;
@@ -1301,24 +1304,56 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[r][t][g] = 0.f;
-    // deliver the fine entries of row group r to the buckets (k_tile_thr<1>'s flush, per list)
+    // Round 6: COARSE entries, as in k_panel's half sweep.  With fine 8-byte entries (a ballot, a rank and an LDS store per
+    // subtile of every row register with a hit) the hit test was ~10 % of config 5's main sweep (127-132 ms over two builds;
+    // 115.0 without any hit test, the accumulators kept alive); now 122.1, i.e. 6 %.  One union test per row register -- its best score against min(tau_row, the
+    // smallest of the lane's four column thresholds) -- and one 20-byte entry {local row, tile of the item, lane; the four
+    // subtile scores} per (register, lane) that fired, appended by 13 hand-written instructions; the delivery, which runs when a
+    // tile's entries would not fit and at the end of the item with a lane per entry, decides every score against its own two
+    // thresholds (row side / column side, the diagonal, the ragged tail) and writes the same bucket entries as before.
     auto deliver = [&](auto RC) {
       constexpr int r = decltype(RC)::value;
-      const uint2* hb = lists + (wave * 2 + r) * T2_CAP;
       const int nbl = (t1 - t0) * 4;
-      const int n = min(wcnt[r], T2_CAP);
+      const int n = min(wcnt[r], T2_HC);
       const int own = rb * 4 + 2 * (rg & 1) + r;
-      if (wcnt[r] > T2_CAP && lane == 0) {
+      if (wcnt[r] > T2_HC && lane == 0) {  // (only ONE tile that yields more than a whole list can overflow)
         a.flags[chunk] = 1;
         atomicAdd(&a.bucket_cnt[own], a.bucket_cap + 1);
       }
+      const unsigned* const hd = t2_hdr + (wave * 2 + r) * T2_HC;
+      const v4f* const sc = t2_sc + (wave * 2 + r) * T2_HC;
+      const float* const taur = &s_tau[wave][r][0][0];  // [half][row register]
+      const int grow0 = wrow0 + 32 * r;                 // image row of the list's local row 0
+      auto take_apart = [&](int e, int& rl, int& tl, int& l5, v4f& sv, bool (&rp)[4], bool (&cp)[4]) {
+        const bool valid = e < n;
+        const unsigned hdv = valid ? hd[e] : 0u;
+        rl = (int)((hdv >> 10) & 31u);
+        tl = (int)((hdv >> 5) & 31u);
+        l5 = (int)(hdv & 31u);
+        sv = valid ? sc[e] : v4f{0.f, 0.f, 0.f, 0.f};
+        const int ct = t0 + tl;
+        const float trow = taur[((rl >> 2) & 1) * 16 + (rl & 3) + 4 * (rl >> 3)];
+        v4f tcv = v4f{3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+        if (valid && ct > rb) tcv = *reinterpret_cast<const v4f*>(&s_tc[tl * 128 + l5 * 4]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int col = ct * 128 + 32 * t + l5;
+          rp[t] = valid && sv[t] > trow && col != grow0 + rl && col < a.N;  // graph.py:37: no self-similarity; the ragged tail
+          cp[t] = valid && sv[t] > tcv[t];
+        }
+      };
       for (int b = lane; b < nbl; b += 64) s_cnt[b] = 0;
       int nrow = 0;
-      for (int e0 = 0; e0 < n; e0 += 64) {
-        const int e = e0 + lane;
-        const unsigned x = e < n ? hb[e].x : 0u;
-        if (x & COL_SIDE) atomicAdd(&s_cnt[(int)((x & COL_MASK) >> 5) - t0 * 4], 1);
-        nrow += __popcll(__ballot((x & ROW_SIDE) != 0u));
+      for (int e0 = 0; e0 < n; e0 += 64) {  // (a wave's LDS accesses complete in order: no barrier between these passes)
+        int rl, tl, l5;
+        v4f sv;
+        bool rp[4], cp[4];
+        take_apart(e0 + lane, rl, tl, l5, sv, rp, cp);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          nrow += __popcll(__ballot(rp[t]));
+          if (cp[t]) atomicAdd(&s_cnt[tl * 4 + t], 1);
+        }
       }
       int rbase = 0;
       if (lane == 0 && nrow > 0) rbase = atomicAdd(&a.bucket_cnt[own], nrow);
@@ -1328,26 +1363,31 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
         s_cnt[b] = 0;
       }
       rbase = __builtin_amdgcn_readfirstlane(rbase);
-      const unsigned irow0 = (unsigned)(wrow0 + 32 * r);
       for (int e0 = 0; e0 < n; e0 += 64) {
-        const int e = e0 + lane;
-        const uint2 v = e < n ? hb[e] : make_uint2(0u, 0u);
-        const bool rs = (v.x & ROW_SIDE) != 0u, cs = (v.x & COL_SIDE) != 0u;
-        const unsigned long long m = __ballot(rs);
-        const int rpos = rbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (rs && rpos < a.bucket_cap) a.bucket_ent[(size_t)own * a.bucket_cap + rpos] = make_uint2((v.x & ~COL_SIDE), v.y);
-        rbase += __popcll(m);
-        if (cs) {
-          const unsigned col = v.x & COL_MASK;
-          const int b = (int)(col >> 5) - t0 * 4;
-          const int cpos = s_base[b] + atomicAdd(&s_cnt[b], 1);
-          if (cpos < a.bucket_cap)
-            a.bucket_ent[(size_t)(col >> 5) * a.bucket_cap + cpos] = make_uint2(((col & 31u) << 27) | ROW_SIDE | (irow0 + (v.x >> 27)), v.y);
+        int rl, tl, l5;
+        v4f sv;
+        bool rp[4], cp[4];
+        take_apart(e0 + lane, rl, tl, l5, sv, rp, cp);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const unsigned long long m = __ballot(rp[t]);
+          const int rpos = rbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (rp[t] && rpos < a.bucket_cap)
+            a.bucket_ent[(size_t)own * a.bucket_cap + rpos] =
+                make_uint2(((unsigned)rl << 27) | ROW_SIDE | (unsigned)((t0 + tl) * 128 + 32 * t + l5), __float_as_uint(sv[t]));
+          rbase += __popcll(m);
+          if (cp[t]) {
+            const int b = tl * 4 + t;
+            const int cpos = s_base[b] + atomicAdd(&s_cnt[b], 1);
+            if (cpos < a.bucket_cap)
+              a.bucket_ent[(size_t)(t0 * 4 + b) * a.bucket_cap + cpos] =
+                  make_uint2(((unsigned)l5 << 27) | ROW_SIDE | (unsigned)(grow0 + rl), __float_as_uint(sv[t]));
+          }
         }
       }
       wcnt[r] = 0;
     };
-    // the hit test of row group r on the tile pct (k_panel's, fine entries)
+    // the hit test of row group r on the tile pct: union masks, then (behind a delivery if the tile's entries would not fit) the append
     auto hit_test = [&](auto RC, int pct) {
       constexpr int r = decltype(RC)::value;
       float tg[16];
@@ -1356,50 +1396,59 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
         const v4f t4 = *reinterpret_cast<const v4f*>(&s_tau[wave][r][h][4 * q]);
         tg[4 * q] = t4[0], tg[4 * q + 1] = t4[1], tg[4 * q + 2] = t4[2], tg[4 * q + 3] = t4[3];
       }
-      float tc[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-      if (pct > rb) {
-        const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(pct - t0) * 128 + l31 * 4]);
-        tc[0] = c4[0], tc[1] = c4[1], tc[2] = c4[2], tc[3] = c4[3];
-      }
-      uint2* const hb = lists + (wave * 2 + r) * T2_CAP;
-      const bool special = pct == rb || (pct + 1) * 128 > a.N;
-      unsigned long long fm[16];
-      // (round 6, as in k_panel: ONE compare of the register's best score against min(tau_row, the smallest of the lane's four
-      // column thresholds) -- a superset of the exact union, which the per-subtile masks below decide anyway -- with raw v_max3 /
-      // v_min: 4 VALU per row register instead of 11)
       auto max3r = [](float x, float y, float z) { float m; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(x), "v"(y), "v"(z)); return m; };
       auto max2r = [](float x, float y) { float m; asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y)); return m; };
       auto min3r = [](float x, float y, float z) { float m; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(x), "v"(y), "v"(z)); return m; };
       auto min2r = [](float x, float y) { float m; asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y)); return m; };
-      const float tcmin = min2r(min3r(tc[0], tc[1], tc[2]), tc[3]);
+      float tcmin = 3.0e38f;  // (+inf: no column side on the diagonal tile)
+      if (pct > rb) {
+        const v4f c4 = *reinterpret_cast<const v4f*>(&s_tc[(pct - t0) * 128 + l31 * 4]);
+        tcmin = min2r(min3r(c4[0], c4[1], c4[2]), c4[3]);
+      }
+      unsigned long long fm[16];
+      int add = 0;
       static_for<0, 16>([&](auto GC) {
         constexpr int g = decltype(GC)::value;
         fm[g] = __ballot(max2r(max3r(acc[r][0][g], acc[r][1][g], acc[r][2][g]), acc[r][3][g]) > min2r(tg[g], tcmin));
+        add += __popcll(fm[g]);
       });
+#ifdef OSC_TILE2_NODELIVER  // measurement only (wrong lattice): full lists are emptied, not delivered
+      if (wcnt[r] > 0 && wcnt[r] + add > T2_HC) wcnt[r] = 0;
+#else
+      if (wcnt[r] > 0 && wcnt[r] + add > T2_HC) deliver(RC);  // (resets the count)
+#endif
+      if (add == 0) return;
+      const unsigned hdb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(t2_hdr + (wave * 2 + r) * T2_HC));
+      const unsigned scb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(t2_sc + (wave * 2 + r) * T2_HC));
+      const unsigned tag = (unsigned)(h << 12) | (unsigned)((pct - t0) << 5) | (unsigned)l31;
       static_for<0, 16>([&](auto GC) {
         constexpr int g = decltype(GC)::value;
-        if (fm[g] == 0ull) return;
-        const int rl = (g & 3) + 8 * (g >> 2) + 4 * h;
-        const int grow = wrow0 + 32 * r + rl;
-        const int cbase = pct * 128 + l31;
-        unsigned long long mk[4];
-        unsigned side[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          bool pred = acc[r][t][g] > tg[g];
-          if (special) pred = pred && (cbase + 32 * t) != grow && (cbase + 32 * t) < a.N;
-          const bool cp = acc[r][t][g] > tc[t];
-          side[t] = (pred ? ROW_SIDE : 0u) | (cp ? COL_SIDE : 0u);
-          mk[t] = __ballot(pred | cp);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (mk[t] == 0ull) continue;
-          const bool pred = (mk[t] >> lane) & 1ull;
-          const int pos = wcnt[r] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[t] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[t], 0u));
-          if (pred && pos < T2_CAP)
-            hb[pos] = make_uint2(((unsigned)rl << 27) | side[t] | (unsigned)(cbase + 32 * t), __float_as_uint(acc[r][t][g]));
-          wcnt[r] += __popcll(mk[t]);
+        const unsigned long long m = fm[g];
+        if (m != 0ull) {  // (k_panel's append, instruction for instruction)
+          constexpr unsigned hconst = (unsigned)((g & 3) + 8 * (g >> 2)) << 10;  // (disjoint bits: local row = (g & 3) + 8 (g >> 2) + 4 h)
+          const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+          unsigned long long sv_;
+          unsigned p_, a1_, a2_, hv_;
+          const float s0_ = acc[r][0][g], s1_ = acc[r][1][g], s2_ = acc[r][2][g], s3_ = acc[r][3][g];
+          asm volatile(
+              "s_and_saveexec_b64 %[sv], %[m]\n\t"
+              "v_mbcnt_lo_u32_b32 %[p], %[mlo], 0\n\t"
+              "v_mbcnt_hi_u32_b32 %[p], %[mhi], %[p]\n\t"
+              "v_add_u32 %[p], %[wc], %[p]\n\t"
+              "v_cmp_gt_u32 vcc, %[cap], %[p]\n\t"
+              "s_and_b64 exec, exec, vcc\n\t"
+              "v_lshl_add_u32 %[a1], %[p], 2, %[hdb]\n\t"
+              "v_lshl_add_u32 %[a2], %[p], 4, %[scb]\n\t"
+              "v_add_u32 %[hv], %[hc], %[tag]\n\t"
+              "ds_write_b32 %[a1], %[hv]\n\t"
+              "ds_write2_b32 %[a2], %[s0], %[s1] offset1:1\n\t"
+              "ds_write2_b32 %[a2], %[s2], %[s3] offset0:2 offset1:3\n\t"
+              "s_mov_b64 exec, %[sv]"
+              : [sv] "=&s"(sv_), [p] "=&v"(p_), [a1] "=&v"(a1_), [a2] "=&v"(a2_), [hv] "=&v"(hv_)
+              : [m] "s"(m), [mlo] "s"(mlo), [mhi] "s"(mhi), [wc] "s"(wcnt[r]), [cap] "n"(T2_HC), [hdb] "s"(hdb), [scb] "s"(scb),
+                [hc] "n"(hconst), [tag] "v"(tag), [s0] "v"(s0_), [s1] "v"(s1_), [s2] "v"(s2_), [s3] "v"(s3_)
+              : "vcc", "memory");
+          wcnt[r] += __popcll(m);
         }
       });
     };
@@ -1450,13 +1499,16 @@ __global__ __launch_bounds__(512, 1) void k_tile_thr2(const PanelArgs a, const i
       }
       if (kt == nkt - 1) {  // ---- the tile pair's accumulators are complete ----
         const int pct = ct + cg;  // this wave's column tile
+#ifndef OSC_TILE2_NOEPI  // measurement only (wrong lattice): the sweep without its hit test
         if (rok && pct >= rb && pct < t1) {
-          static_for<0, 2>([&](auto RC) {
-            constexpr int r = decltype(RC)::value;
-            if (wcnt[r] > T2_CAP - 96) deliver(RC);  // (a tile adds ~20 entries to a list on average)
-            hit_test(RC, pct);
-          });
+          static_for<0, 2>([&](auto RC) { hit_test(RC, pct); });  // (delivers the list first when the tile's entries would not fit)
         }
+#else  // (the accumulators stay "used": without this hipcc deletes the MFMAs and their fragment reads with the hit test)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(acc[r][t]));
+#endif
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
