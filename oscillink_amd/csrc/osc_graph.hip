@@ -650,7 +650,10 @@ static bool build_graph_once(L& h, const float* host_Y) {
       // anchors that arrive cluster by cluster packs each cluster into few tiles -- 3072 rows holding 7.7 clusters of 401 gave
       // every row 17 cluster mates per column tile, more than a wave's hit list takes from one tile)
       const int64_t rows = m * chunk_rows, pieces = N / rows;
-      if (pieces >= 3 && (int64_t)N * row_bytes >= ((int64_t)h.create_min_mb << 20) && smp_bytes <= 8 * (int64_t)kStageBytes) {  // (up to eight fills of the two staging buffers: stream_pieces)
+      // (two pieces only where the anchors are large -- config 5's 1.2 GB under the wide tile core's 176 x bound rows: the second
+      // half travels behind the first half's kernels; a small lattice in two pieces loses to the whole-array upload)
+      const int64_t min_pieces = (int64_t)N * row_bytes >= ((int64_t)512 << 20) ? 2 : 3;
+      if (pieces >= min_pieces && (int64_t)N * row_bytes >= ((int64_t)h.create_min_mb << 20) && smp_bytes <= 8 * (int64_t)kStageBytes) {  // (up to eight fills of the two staging buffers: stream_pieces)
         for (int64_t j = 0; j < pieces; ++j) piece_starts.push_back((int32_t)(j * rows));
         knn_panel_set_pieces(pp, N, piece_starts.data(), (int)piece_starts.size());
       }

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""n creates of one shape from host anchors under the environment's OSC_CREATE_STREAM (for create_trace.sh).  usage: create_n.py c4|c5|x3 [n]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+from oscillink_amd import Oscillink  # noqa: E402
+
+SHAPES = {"c3": (100000, 768, 32), "c4": (1000000, 384, 16), "c5": (200000, 1536, 64), "x3": (300000, 768, 8)}
+N, D, k = SHAPES[sys.argv[1]]
+Y = np.random.default_rng(0).standard_normal((N, D)).astype(np.float32)
+for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3):
+    t0 = time.perf_counter()
+    lat = Oscillink(Y, kneighbors=k)
+    t = 1e3 * (time.perf_counter() - t0)
+    print(f"create {i}: {t:.1f} ms, pieces {lat.build_info()['create_pieces']}", flush=True)
+    lat.close()
+    time.sleep(0.05)
