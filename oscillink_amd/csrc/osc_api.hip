@@ -62,6 +62,7 @@ void read_env_build(L& h) {
   h.create_stream = !(num("OSC_CREATE_STREAM", v) && v == 0);
   h.create_force_retry = num("OSC_CREATE_FORCE_RETRY", v) && v != 0;
   h.create_min_mb = num("OSC_CREATE_MIN_MB", v) ? std::max(1, v) : 64;
+  h.create_two_mb = num("OSC_CREATE_TWO_PIECE_MB", v) ? std::max(1, v) : 256;
   h.create_piece_mb_set = num("OSC_CREATE_PIECE_MB", v);
   h.create_piece_mb = h.create_piece_mb_set ? std::max(1, std::min(v, 1024)) : 24;
   h.knn_tune = KnnPanelTune{};

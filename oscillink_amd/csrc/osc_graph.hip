@@ -650,9 +650,11 @@ static bool build_graph_once(L& h, const float* host_Y) {
       // anchors that arrive cluster by cluster packs each cluster into few tiles -- 3072 rows holding 7.7 clusters of 401 gave
       // every row 17 cluster mates per column tile, more than a wave's hit list takes from one tile)
       const int64_t rows = m * chunk_rows, pieces = N / rows;
-      // (two pieces only where the anchors are large -- config 5's 1.2 GB under the wide tile core's 176 x bound rows: the second
-      // half travels behind the first half's kernels; a small lattice in two pieces loses to the whole-array upload)
-      const int64_t min_pieces = (int64_t)N * row_bytes >= ((int64_t)512 << 20) ? 2 : 3;
+      // (two pieces from 256 MB of anchors on -- in practice the wide tile core's 176 x bound rows: the second half travels behind
+      // the first half's kernels.  Create, two pieces vs whole array (scripts/exp/r06/create_n.py, profiles/r06_two_piece.txt):
+      // config 5's 1.2 GB 98.9 vs 111.7 ms, 150 000 x 1152 k 56 48.0 vs 54.7, 132 000 x 800 k 48 30.8 vs 34.6; on the panel core
+      // 48 000 x 768 k 64 (147 MB) is a tie, 9.1-9.6 vs 9.4: three pieces stay the rule below)
+      const int64_t min_pieces = (int64_t)N * row_bytes >= ((int64_t)h.create_two_mb << 20) ? 2 : 3;
       if (pieces >= min_pieces && (int64_t)N * row_bytes >= ((int64_t)h.create_min_mb << 20) && smp_bytes <= 8 * (int64_t)kStageBytes) {  // (up to eight fills of the two staging buffers: stream_pieces)
         for (int64_t j = 0; j < pieces; ++j) piece_starts.push_back((int32_t)(j * rows));
         knn_panel_set_pieces(pp, N, piece_starts.data(), (int)piece_starts.size());

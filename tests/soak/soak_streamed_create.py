@@ -11,7 +11,8 @@ rows more to the exact kernel than the whole-array one.  Lattices the streamed c
 too few for their hit lists) show as 0 pieces.  `big` (round 6): 700-1100 MB of anchors with a shallow k, i.e. threshold samples
 of more than the two 32 MB staging buffers -- the sample then travels in three or more fills, a piece of anchors between them.
 `big2`: the same sizes beyond 1024 columns with k 33-64 -- the wide tile core's piece rule then leaves TWO pieces (config 5's case).
-usage: soak_streamed_create.py [seed] [cases] [big|big2]"""
+`mid2`: 400-520 MB at 800-1024 columns, k 20-64 -- the smallest lattices the wide tile core serves, in two or three pieces.
+usage: soak_streamed_create.py [seed] [cases] [big|big2|mid2]"""
 import os
 import sys
 
@@ -23,6 +24,7 @@ import oscillink_amd as amd  # noqa: E402
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 big2 = len(sys.argv) > 3 and sys.argv[3] == "big2"
+mid2 = len(sys.argv) > 3 and sys.argv[3] == "mid2"
 big = big2 or (len(sys.argv) > 3 and sys.argv[3] == "big")
 rng = np.random.default_rng(seed)
 bad = 0
@@ -62,10 +64,13 @@ for t in range(count):
     mb = float(rng.uniform(700, 1100)) if big else float(rng.uniform(66, 400))
     if big2:
         D = int(rng.choice([1152, 1280, 1536, 2048]))
+    if mid2:
+        D = int(rng.choice([800, 896, 1024]))
+        mb = float(rng.uniform(400, 520))
     N = int(mb * 1048576 / (4 * D))
     if t % 3 == 0:
         N = max(3072 * 8, N // 3072 * 3072)  # a whole number of column chunks
-    k = int(rng.integers(33, 65)) if big2 else int(rng.integers(2, 65))
+    k = int(rng.integers(33, 65)) if big2 else int(rng.integers(20, 65)) if mid2 else int(rng.integers(2, 65))
     kind = ("iid", "clustered", "grouped", "duplicates")[t % 4]
     if kind == "iid":
         Y = rng.standard_normal((N, D), dtype=np.float32)

@@ -58,7 +58,7 @@ SHAPES = [(40000, 512, 16, "iid"), (30000, 768, 32, "clustered"), (60000, 384, 1
           # ... and of more than both (round 6: 76.7 MB = three fills, the third gathered while the second piece travels;
           # configs 4 and 5 have 128 / 102 MB); two row groups per wave in the main sweep (2344 row blocks)
           (300000, 768, 8, "iid"),
-          # config 5's shape: the wide tile core's pieces of >= 176 x hit bound rows leave TWO (allowed from 512 MB of anchors on);
+          # config 5's shape: the wide tile core's pieces of >= 176 x hit bound rows leave TWO (allowed from 256 MB of anchors on);
           # the same with anchors that arrive cluster by cluster
           (200000, 1536, 64, "iid"), (150000, 1536, 48, "grouped300")]
 
@@ -74,7 +74,7 @@ def test_streamed_create_builds_the_lattice_of_the_whole_array_build(N, D, k, ki
     lat = _lattice(Y, k, stream=True)
     got = _snapshot(lat, psi)
     assert whole["info"]["create_pieces"] == 0
-    assert got["info"]["create_pieces"] >= (2 if N * D * 4 >= 512 << 20 else 3), got["info"]
+    assert got["info"]["create_pieces"] >= (2 if N * D * 4 >= 256 << 20 else 3), got["info"]
     assert got["info"]["prefilter"] == 2 and got["info"]["fallback_rows"] <= max(32, whole["info"]["fallback_rows"] * 2)
     np.testing.assert_array_equal(got["Y"], Y)   # every piece landed where it belongs
     np.testing.assert_array_equal(got["U0"], Y)  # lattice.py:58: U = Y.copy()
