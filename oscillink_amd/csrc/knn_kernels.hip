@@ -807,16 +807,19 @@ __global__ __launch_bounds__(256) void k_to_f16(const float* Yn, int32_t ldn, _F
 __device__ __forceinline__ void rescore_select_and_prove(const float (&sc)[2], const int (&id)[2], int nvalid, int lane, int row, int32_t KC,
                                                          int32_t k, float delta, const float* cval, float* out_val, int32_t* out_idx,
                                                          int32_t* fail_rows, int32_t* fail_count) {
+  // (only the KC slots in use are visited -- both callers fill slots q < KC and nothing else: at 48 candidates 48 rounds on one
+  // register instead of 128 on two, k_knn_rescore_finish 0.29 -> 0.1 ms at config 3)
   int rank[2] = {0, 0};
+  const bool two = KC > 64;  // (wave-uniform)
 #pragma unroll
   for (int m2 = 0; m2 < 2; ++m2) {
-    for (int l = 0; l < 64; ++l) {
+    const int nl = m2 == 0 ? min(KC, 64) : KC - 64;
+    for (int l = 0; l < nl; ++l) {
       const float ov = __shfl(sc[m2], l, 64);
       const int oi = __shfl(id[m2], l, 64);
       if (oi < 0) continue;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-        if (id[m] >= 0 && (ov > sc[m] || (ov == sc[m] && oi < id[m]))) ++rank[m];
+      if (id[0] >= 0 && (ov > sc[0] || (ov == sc[0] && oi < id[0]))) ++rank[0];
+      if (two && id[1] >= 0 && (ov > sc[1] || (ov == sc[1] && oi < id[1]))) ++rank[1];
     }
   }
   float tk = NEG;  // exact k-th best score
@@ -1219,14 +1222,19 @@ __global__ __launch_bounds__(256) void k_mutual_ell(const float* kval, const int
     }
     if (!keep[ps]) jcol[ps] = 0x7fffffff;
   }
+  // (a kept column's slot = the number of kept columns below it; slots e >= k hold 0x7fffffff and are not visited: k rounds
+  // instead of 256 per row)
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     int rank = 0;
+    if (ps < npass) {
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-      for (int l = 0; l < 64; ++l) {
-        const int oc = __shfl(jcol[qs], l, 64);
-        rank += (oc < jcol[ps]) ? 1 : 0;
+      for (int qs = 0; qs < 2; ++qs) {
+        const int nl = min(64, k - 64 * qs);
+        for (int l = 0; l < nl; ++l) {
+          const int oc = __shfl(jcol[qs], l, 64);
+          rank += (oc < jcol[ps]) ? 1 : 0;
+        }
       }
     }
     if (keep[ps]) {
