@@ -785,9 +785,10 @@ __global__ void k_blk_fill(const int32_t* col, const float* w, const int32_t* de
 }
 
 // ---- initial residual around the blocked matvec (InitFinishArgs) ---------------------------------------------------
-template <int LPR, int NCH>
+// DIFF: dst = src - minus (the receipt's U - U*, formed on the way into the slabs: no row-major copy of the difference)
+template <int LPR, int NCH, bool DIFF = false>
 __global__ __launch_bounds__(256) void k_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, int32_t c0,
-                                                      int32_t c1) {
+                                                      int32_t c1, const float* minus = nullptr) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, lr = lane % LPR;
@@ -797,7 +798,14 @@ __global__ __launch_bounds__(256) void k_rows_to_slab(const float* src, float* d
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int col = c0 + (ch * LPR + lr) * 4;
-      if (col < c1) st4(dst + blk_off(N, row, col), ld4_stream(src + (size_t)row * ld + col));
+      if (col < c1) {
+        float4 v = ld4_stream(src + (size_t)row * ld + col);
+        if constexpr (DIFF) {
+          const float4 w = ld4_stream(minus + (size_t)row * ld + col);
+          v = make_float4(v.x - w.x, v.y - w.y, v.z - w.z, v.w - w.w);
+        }
+        st4(dst + blk_off(N, row, col), v);
+      }
     }
   }
 }
@@ -1192,11 +1200,18 @@ static const BlkShape& blk_shape(int variant) {
 int blocked_variants() { return kBlkShapeCount; }
 int blocked_groups_max(int variant) { return blk_shape(variant).gm; }
 int blocked_gather_waves(int variant) { return blk_shape(variant).cw; }
-void launch_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, int32_t c0, int32_t c1, int grid, hipStream_t s) {
+void launch_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, int32_t c0, int32_t c1, int grid, hipStream_t s,
+                         const float* sub) {
   for (int32_t s0 = c0; s0 < c1; s0 += 2048) {  // at most 2048 columns per launch, like the other elementwise kernels
     const int32_t s1 = std::min(c1, s0 + 2048);
     const Shape sh = pick_shape(s1 - s0);
-#define CALL(L, C) hipLaunchKernelGGL((k_rows_to_slab<L, C>), dim3(grid), dim3(256), 0, s, src, dst, N, ld, s0, s1)
+    if (sub != nullptr) {
+#define CALL(L, C) hipLaunchKernelGGL((k_rows_to_slab<L, C, true>), dim3(grid), dim3(256), 0, s, src, dst, N, ld, s0, s1, sub)
+      OSC_SHAPE_SWITCH(sh, CALL);
+#undef CALL
+      continue;
+    }
+#define CALL(L, C) hipLaunchKernelGGL((k_rows_to_slab<L, C, false>), dim3(grid), dim3(256), 0, s, src, dst, N, ld, s0, s1, nullptr)
     OSC_SHAPE_SWITCH(sh, CALL);
 #undef CALL
   }

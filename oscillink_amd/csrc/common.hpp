@@ -256,7 +256,8 @@ struct InitFinishArgs {
   int64_t N, pblk;
   int32_t ld, c0, c1;
 };
-void launch_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, int32_t c0, int32_t c1, int grid, hipStream_t s);
+void launch_rows_to_slab(const float* src, float* dst, int64_t N, int32_t ld, int32_t c0, int32_t c1, int grid, hipStream_t s,
+                         const float* sub = nullptr);  // sub: dst = src - sub
 void launch_init_finish(const InitFinishArgs& a, int grid, hipStream_t s);
 int chain_fix_chunks(int32_t prows);
 void launch_chain_fix(const ChainFixArgs& a, hipStream_t s);

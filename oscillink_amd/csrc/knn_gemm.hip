@@ -1002,10 +1002,17 @@ __global__ void k_panel_image(const float* Yn, int32_t ldn, _Float16* Yh, int32_
   const int row = r0 + (int)(i / per_row), c0 = (int)(i % per_row) * 8;
   const int64_t src = row < N ? (mapped ? knn_map_lattice_row(map, N, row) : row) : 0;  // KnnPanelPlan::map
   half8 v;
+  if (row < N && c0 + 8 <= D) {  // (the unit rows' pitch is a multiple of 32 floats: two 16-byte loads instead of eight dwords)
+    const float4 a = *reinterpret_cast<const float4*>(Yn + (size_t)src * ldn + c0);
+    const float4 b = *reinterpret_cast<const float4*>(Yn + (size_t)src * ldn + c0 + 4);
+    v[0] = (_Float16)(16.0f * a.x), v[1] = (_Float16)(16.0f * a.y), v[2] = (_Float16)(16.0f * a.z), v[3] = (_Float16)(16.0f * a.w);
+    v[4] = (_Float16)(16.0f * b.x), v[5] = (_Float16)(16.0f * b.y), v[6] = (_Float16)(16.0f * b.z), v[7] = (_Float16)(16.0f * b.w);
+  } else {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = c0 + j;
-    v[j] = (row < N && c < D) ? (_Float16)(16.0f * Yn[(size_t)src * ldn + c]) : (_Float16)0.f;
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      v[j] = (row < N && c < D) ? (_Float16)(16.0f * Yn[(size_t)src * ldn + c]) : (_Float16)0.f;
+    }
   }
   *(half8*)(Yh + (size_t)row * ldh + c0) = v;
 }

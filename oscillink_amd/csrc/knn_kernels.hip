@@ -45,12 +45,32 @@ __global__ __launch_bounds__(256) void k_normalize_rows(const float* Y, int32_t 
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= N) return;
   const float* y = Y + row * ldy;
+  float* yn = Yn + row * ldn;
   float ss = 0.f;
+  if (D <= 1024) {  // the row stays in registers between the sum and the scaling (same sums, same order: one read of Y)
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < D ? y[c] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (lane + 64 * i < D) ss = fmaf(v[i], v[i], ss);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = 1.f / (sqrtf(ss) + 1e-12f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = lane + 64 * i;
+      if (c < ldn) yn[c] = c < D ? v[i] * inv : 0.f;
+    }
+    return;
+  }
   for (int c = lane; c < D; c += 64) ss = fmaf(y[c], y[c], ss);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
   const float inv = 1.f / (sqrtf(ss) + 1e-12f);
-  float* yn = Yn + row * ldn;
   for (int c = lane; c < ldn; c += 64) yn[c] = c < D ? y[c] * inv : 0.f;
 }
 

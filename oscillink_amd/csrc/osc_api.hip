@@ -839,13 +839,13 @@ int osc_ustar_cosine_to(osc_handle h, const float* psi, float* out) {
 static double quad_form_of_difference(L& l, const float* A, const float* B) {
   ensure_cg_scratch(l, 1);
   const int grid = cg_grid(l);
-  // Large lattices on one process: the difference row-major into R, then the blocked matvec with its column sums of x . (M x)
-  // (P takes the slab-major copy, AP the product nobody reads): 0.76 instead of 1.23 ms at config 3.  Same terms per row; a
-  // row's sum runs block by block instead of in list order (the matvec's 3e-8 relative on the state, far inside the 1e-4 of
-  // the receipt's energies).
+  // Large lattices on one process: the blocked matvec with its column sums of x . (M x) on the difference, which is formed on
+  // its way into the slab-major operand (P; AP takes the product nobody reads): 0.76 instead of 1.23 ms at config 3, and
+  // since round 6 without the row-major copy of the difference (one array pass of three less in front of the matvec).  Same
+  // terms per row; a row's sum runs block by block instead of in list order (the matvec's 3e-8 relative on the state, far
+  // inside the 1e-4 of the receipt's energies).  (A and B are never the solver's scratch arrays: U / U* / dynamics snapshots.)
   if (!row_mode(l) && l.comm == nullptr) {
-    launch_axpby(l.R.p, A, 1.0f, B, -1.0f, (int64_t)l.N * l.ld, l.stream);
-    if (const int rows = blocked_quad_form(l, ustar_op(l), l.R.p, l.P.p, l.AP.p, path_active(l))) {
+    if (const int rows = blocked_quad_form(l, ustar_op(l), A, l.P.p, l.AP.p, path_active(l), B)) {
       launch_reduce_sum(l.part0.p, rows, l.ld, l.c0, l.c1, l.colsum.p, l.stream);
       std::vector<double> cs((size_t)l.ld, 0.0);
       HIP_CHECK(hipMemcpyAsync(cs.data() + l.c0, l.colsum.p + l.c0, (size_t)(l.c1 - l.c0) * 8, hipMemcpyDeviceToHost, l.stream));

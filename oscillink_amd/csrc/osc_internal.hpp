@@ -289,7 +289,8 @@ uint32_t* ctrl_segment(L& h, size_t words);
 void ensure_ctrl(L& h, size_t slots);
 void ensure_cg_scratch(L& h, int max_iters);
 int cg_grid(const L& h);
-int blocked_quad_form(L& h, const OpParams& op, const float* x_rows, float* scratch_slab, float* scratch_out, bool with_path);
+int blocked_quad_form(L& h, const OpParams& op, const float* x_rows, float* scratch_slab, float* scratch_out, bool with_path,
+                      const float* x_sub = nullptr);  // x_sub: the form of x_rows - x_sub
 GraphView graph_view(L& h, bool with_path);
 void graph_counts(L& h);
 void alloc_ell(L& h, int32_t width);

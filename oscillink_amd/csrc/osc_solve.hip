@@ -383,7 +383,8 @@ void blocked_setup(L& h, const OpParams& op, const float* X, float* OUT, const f
 // x . (op x) summed per column into h.part0 for a ROW-major x (N x ld, the handle's whole window) through the blocked matvec:
 // x -> slab-major (scratch_slab), one launch (+ the chain fix-up), op x -> scratch_out.  Returns the rows of partial sums
 // h.part0 holds, 0 where the blocked matvec does not serve this lattice (the caller takes the plain apply's DOT form).
-int blocked_quad_form(L& h, const OpParams& op, const float* x_rows, float* scratch_slab, float* scratch_out, bool with_path) {
+int blocked_quad_form(L& h, const OpParams& op, const float* x_rows, float* scratch_slab, float* scratch_out, bool with_path,
+                      const float* x_sub) {
   const int grid = cg_grid(h);
   if (!(h.p_blocked && xs_plan(h, h.c1 - h.c0, grid) > 0 && (h.ld & 31) == 0 && (h.c0 & 31) == 0)) return 0;
   BlkArgs ba{};
@@ -391,7 +392,7 @@ int blocked_quad_form(L& h, const OpParams& op, const float* x_rows, float* scra
   int blk_shape = 0;
   blocked_setup(h, op, scratch_slab, scratch_out, h.B.p, h.ld, with_path, grid, ba, cf, blk_shape);
   if (ba.nb == 0) return 0;
-  launch_rows_to_slab(x_rows, scratch_slab, h.N, h.ld, h.c0, h.c1, grid, h.stream);
+  launch_rows_to_slab(x_rows, scratch_slab, h.N, h.ld, h.c0, h.c1, grid, h.stream, x_sub);
   ba.gate = nullptr;
   launch_apply_blocked(ba, grid, h.stream, nullptr, blk_shape);
   h.blk_applies += 1;

@@ -112,6 +112,7 @@ def test_column_shard_plan():
 def test_signature_json_fast_path_equals_json_dumps():
     """The state signature hashes json.dumps(..., sort_keys=True) of a dict holding the N gates; the mirror splices the
     gate list in (and skips float formatting for ungated lattices).  Byte-identical to the plain form."""
+    import hashlib
     import json
 
     from oscillink_amd.lattice import OscillinkLattice as L
@@ -123,6 +124,15 @@ def test_signature_json_fast_path_equals_json_dumps():
               np.array([1.0, 0.0, 1.0], dtype=np.float32)):
         plain = json.dumps({**rest, "B": np.round(B, 6).tolist()}, sort_keys=True)
         assert L._signature_json(rest, B) == plain
+        # ... and the digest that starts from the cached hash state of an ungated lattice's prefix (twice: cold, then cached)
+        want = hashlib.sha256(plain.encode("utf-8")).hexdigest()
+        assert L._signature_digest(rest, B) == want
+        assert L._signature_digest(rest, B) == want
+    assert L._signature_digest({}, np.ones(5, dtype=np.float32)) == hashlib.sha256(
+        json.dumps({"B": [1.0] * 5}, sort_keys=True).encode("utf-8")).hexdigest()
+    for n in range(2000, 2012):  # the per-N cache stays small
+        L._signature_digest(rest, np.ones(n, dtype=np.float32))
+    assert len(L._ones_prefix) <= 8
 
 
 def _rdzv_worker(rank, world, port, q):
