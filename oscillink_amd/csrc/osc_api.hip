@@ -36,6 +36,7 @@ void read_env_solver(L& h) {
     h.x_last_form = v == 1;
   }
   if (num("OSC_SMALL_PATH", v)) h.small_path = v != 0;
+  if (num("OSC_RECEIPT_PAIR", v)) h.receipt_pair = v != 0;
   if (const char* e = getenv("OSC_SHARD")) h.shard_mode = !strcmp(e, "row") ? 1 : 0;
   if (num("OSC_ROW_FAKE_SHARDS", v)) h.fake_row_shards = std::max(0, v);
   h.fake_col_w = 0;
@@ -1139,7 +1140,31 @@ static void receipt_rows(L& l, float z_th, DevBuf<float>& coh, DevBuf<float>& an
     a.null_z = nz.p;
     a.null_r = nr.p;
   }
+  // the pair form (receipt_kernels.hip): every edge's squared distances computed once -- half the gathers of the one-launch
+  // kernel, the same outputs bit for bit (OSC_RECEIPT_PAIR=0: the one-launch kernel; tests, A/B)
+  DevBuf<float> pdy, pdu;
+  DevBuf<int32_t> pfail;
+  const bool pair = l.receipt_pair && (l.ld + 255) / 256 <= 6 && (int64_t)l.N * l.width < ((int64_t)1 << 31) && l.N >= 4096;
+  if (pair) {
+    pdy.alloc((size_t)l.N * l.width);
+    pdu.alloc((size_t)l.N * l.width);
+    pfail.alloc(1);
+    HIP_CHECK(hipMemsetAsync(pfail.p, 0, 4, l.stream));
+    a.pair_dy = pdy.p;
+    a.pair_du = pdu.p;
+    a.pair_fail = pfail.p;
+  }
   launch_receipt_rows(a, l.stream);
+  if (pair) {
+    int32_t fail = 0;
+    HIP_CHECK(hipMemcpyAsync(&fail, pfail.p, 4, hipMemcpyDeviceToHost, l.stream));
+    sync(l);
+    if (fail != 0) {  // an edge without its mirror (asymmetric lists: not produced by the build or accepted by the injection)
+      a.pair_dy = a.pair_du = nullptr;
+      a.pair_fail = nullptr;
+      launch_receipt_rows(a, l.stream);
+    }
+  }
 }
 
 int osc_receipt_components(osc_handle h, float* coh, float* anchor, float* query) {

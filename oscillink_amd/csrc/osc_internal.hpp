@@ -141,6 +141,7 @@ struct osc_lattice {
   int32_t create_piece_mb = 24;  // OSC_CREATE_PIECE_MB: anchors per piece, at least (experiments)
   bool create_piece_mb_set = false;
   int32_t create_min_mb = 64;  // OSC_CREATE_MIN_MB: anchors below this travel whole (the streamed create's fixed costs)
+  bool receipt_pair = true;  // OSC_RECEIPT_PAIR=0: the receipt's per-edge pass from both ends of every edge (one launch)
   int32_t create_two_mb = 256;  // OSC_CREATE_TWO_PIECE_MB: anchors from this size on may travel in TWO pieces (three below it)
   bool create_force_retry = false;  // OSC_CREATE_FORCE_RETRY (test hook): a streamed build always hands over to the whole-array one
   int32_t create_pieces = 0;   // pieces the last build received its anchors in (0: they were on the device before it started)

@@ -180,6 +180,194 @@ __global__ __launch_bounds__(256) void k_receipt_rows(const ReceiptArgs a) {
 }
 
 
+// ---- the pair form (round 6): every undirected edge's two squared distances computed ONCE ---------------------------------
+// k_receipt_rows gathers the rows of both ends of every edge from both ends: 2 nnz D 4 bytes x 2 arrays, 17.7 GB at config 3,
+// its whole time (2.5 ms at 6.7 TB/s).  The per-edge values are symmetric bit for bit by construction (sdiff above: the two
+// directions' differences are exact negations, the squares, the per-lane fma order and the butterfly are the same), so row i
+// computes only its edges to j >= i and leaves (dy, du) in an ELL-shaped scratch; k_receipt_finish then walks every row's
+// edges in order, takes its own slot's pair or -- j < i -- the slot of i in row j's list (the wave reads that list with one
+// coalesced load and finds the slot with a ballot, four lists in flight), and accumulates exactly as k_receipt_rows does:
+// same values, same order, same outputs.  An edge whose mirror slot does not exist (an asymmetric list: cannot happen, the
+// build and the injection enforce symmetry) raises a flag; the caller then runs the one-launch kernel instead.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_receipt_pairs(const ReceiptArgs a) {
+  static_assert(NCH > 0, "the pair form keeps the row in registers");
+  constexpr int EU = 2;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.N) return;
+  const size_t ro = (size_t)row * a.ld;
+  const float inv_i = 1.0f / (a.sqrt_deg[row] + 1e-12f);
+  float an = 0.f, qu = 0.f;
+  float4 yi_r[NCH], ui_r[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {  // (k_receipt_rows' own-row pass, expression for expression)
+    const int c = lane * 4 + ch * 256;
+    float4 us = make_float4(0.f, 0.f, 0.f, 0.f), y = us, ps = us;
+    if (c < a.ld) {
+      us = ld4(a.Ustar + ro + c);
+      y = ld4(a.Y + ro + c);
+      ps = ld4(a.psi + c);
+      const float d0 = us.x - y.x, d1 = us.y - y.y, d2 = us.z - y.z, d3 = us.w - y.w;
+      const float q0 = us.x - ps.x, q1 = us.y - ps.y, q2 = us.z - ps.z, q3 = us.w - ps.w;
+      an = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, an))));
+      qu = fmaf(q0, q0, fmaf(q1, q1, fmaf(q2, q2, fmaf(q3, q3, qu))));
+    }
+    yi_r[ch] = y;
+    ui_r[ch] = us;
+  }
+  an = wave_sum(an);
+  qu = wave_sum(qu);
+  if (lane == 0) {
+    if (a.anchor) a.anchor[row] = a.lamG * an;
+    if (a.query) a.query[row] = a.lamQ * a.B[row] * qu;
+  }
+  const int deg = a.deg[row];
+  const int32_t* crow = a.col + (size_t)row * a.width;
+  int e = 0;
+  while (e < deg) {
+    int jj[EU], es[EU], n = 0;
+    while (e < deg && n < EU) {  // (wave-uniform: the next edges to a row not below this one)
+      const int j = crow[e];
+      if (j >= row) {
+        jj[n] = j;
+        es[n] = e;
+        ++n;
+      }
+      ++e;
+    }
+    float ij[EU], dy[EU], du[EU];
+#pragma unroll
+    for (int u = 0; u < EU; ++u) ij[u] = u < n ? 1.0f / (a.sqrt_deg[jj[u]] + 1e-12f) : 0.f;
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      dy[u] = 0.f;
+      du[u] = 0.f;
+      if (u < n) {
+        const size_t jo = (size_t)jj[u] * a.ld;
+        const float inv_j = ij[u];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          const int c = lane * 4 + ch * 256;
+          if (c < a.ld) {
+            const float4 yi = yi_r[ch], ui = ui_r[ch];
+            const float4 yj = ld4(a.Y + jo + c), uj = ld4(a.Ustar + jo + c);
+            const float y0 = sdiff(yi.x, inv_i, yj.x, inv_j), y1 = sdiff(yi.y, inv_i, yj.y, inv_j);
+            const float y2 = sdiff(yi.z, inv_i, yj.z, inv_j), y3 = sdiff(yi.w, inv_i, yj.w, inv_j);
+            const float u0 = sdiff(ui.x, inv_i, uj.x, inv_j), u1 = sdiff(ui.y, inv_i, uj.y, inv_j);
+            const float u2 = sdiff(ui.z, inv_i, uj.z, inv_j), u3 = sdiff(ui.w, inv_i, uj.w, inv_j);
+            dy[u] = fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, fmaf(y3, y3, dy[u]))));
+            du[u] = fmaf(u0, u0, fmaf(u1, u1, fmaf(u2, u2, fmaf(u3, u3, du[u]))));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+      if (u < n) {
+        dy[u] = wave_sum(dy[u]);
+        du[u] = wave_sum(du[u]);
+        if (lane == 0) {
+          a.pair_dy[(size_t)row * a.width + es[u]] = dy[u];
+          a.pair_du[(size_t)row * a.width + es[u]] = du[u];
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_receipt_finish(const ReceiptArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.N) return;
+  const int deg = a.deg[row];
+  const int32_t* crow = a.col + (size_t)row * a.width;
+  const float* arow = a.adj + (size_t)row * a.width;
+  float coh = 0.f;
+  double s1 = 0.0, s2 = 0.0;
+  float rmax = 0.f;
+  int jmax = -1;
+  for (int e0 = 0; e0 < deg; e0 += 64) {
+    const int e = e0 + lane;
+    const bool have = e < deg;
+    const int j = have ? crow[e] : -1;
+    const float w = have ? arow[e] : 0.f;
+    long long src = (have && j >= row) ? (long long)row * a.width + e : -1;
+    // the mirror slots of this chunk's edges to rows below this one: four of those rows' lists in flight
+    unsigned long long need = __ballot(have && j < row);
+    while (need) {
+      int ln[4], jj[4], c0[4], c1[4], dj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ln[u] = -1;
+        jj[u] = 0;
+        c0[u] = c1[u] = -2;
+        dj[u] = 0;
+        if (need) {
+          ln[u] = __ffsll((long long)need) - 1;
+          need &= need - 1;
+          jj[u] = __shfl(j, ln[u], 64);
+          dj[u] = a.deg[jj[u]];
+          const int32_t* lj = a.col + (size_t)jj[u] * a.width;
+          if (lane < dj[u]) c0[u] = lj[lane];
+          if (lane + 64 < dj[u]) c1[u] = lj[lane + 64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ln[u] < 0) continue;  // (wave-uniform)
+        const unsigned long long m0 = __ballot(c0[u] == row), m1 = __ballot(c1[u] == row);
+        int pos = m0 ? __ffsll((long long)m0) - 1 : m1 ? 64 + __ffsll((long long)m1) - 1 : -1;
+        if (pos < 0 && dj[u] > 128) {  // (lists longer than two registers: the rest, one coalesced load at a time)
+          const int32_t* lj = a.col + (size_t)jj[u] * a.width;
+          for (int t0 = 128; t0 < dj[u] && pos < 0; t0 += 64) {
+            const unsigned long long m = __ballot(t0 + lane < dj[u] && lj[t0 + lane] == row);
+            if (m) pos = t0 + __ffsll((long long)m) - 1;
+          }
+        }
+        if (pos < 0 && lane == 0) atomicOr(a.pair_fail, 1);
+        if (lane == ln[u]) src = pos >= 0 ? (long long)jj[u] * a.width + pos : -1;
+      }
+    }
+    const float dyv = src >= 0 ? a.pair_dy[src] : 0.f, duv = src >= 0 ? a.pair_du[src] : 0.f;
+    if (a.edge_flow != nullptr && have) {
+      const double f = 0.5 * (double)a.lamC * (double)w * ((double)dyv - (double)duv);
+      a.edge_flow[(size_t)row * a.width + e] = (w > 0.f && f > 0.0) ? (float)f : 0.f;
+    }
+    const int n = min(64, deg - e0);
+    for (int t = 0; t < n; ++t) {  // in edge order, every lane the same sums: k_receipt_rows' edge_finish
+      const float wt = __shfl(w, t, 64), dyt = __shfl(dyv, t, 64), dut = __shfl(duv, t, 64);
+      const int jt = __shfl(j, t, 64);
+      if (wt > 0.f) {
+        coh += 0.5f * a.lamC * wt * (dyt - dut);
+        const float R = a.lamC * wt * dut;
+        s1 += (double)R;
+        s2 += (double)R * (double)R;
+        bool take = R > rmax;
+        if (!take && R == rmax && R > 0.f && a.api_id != nullptr && jmax >= 0) take = a.api_id[jt] < a.api_id[jmax];
+        if (take) {
+          rmax = R;
+          jmax = jt;
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    if (a.coh) a.coh[row] = coh;
+    if (a.null_j) {
+      const double mu = s1 / (double)a.N;
+      double var = s2 / (double)a.N - mu * mu;
+      if (var < 0.0) var = 0.0;
+      const double z = ((double)rmax - mu) / (sqrt(var) + 1e-12);
+      const bool is_null = (jmax >= 0) && (rmax > 0.f) && (z > (double)a.z_th);
+      a.null_j[row] = is_null ? jmax : -1;
+      a.null_z[row] = (float)z;
+      a.null_r[row] = rmax;
+    }
+  }
+}
+
+
 // ---- greedy MMR on the device (graph.py:114-133; bundle(), lattice.py:530-568) ---------------------------------------
 // val_i = (1 - lambda) score_i - lambda max_{j chosen} cos(Y_i, Y_j) over the rows still alive; the next item is the
 // first maximum in API row order.  One step = argmax (two stages), normalise the chosen row, one cosine pass over the
@@ -314,6 +502,16 @@ __global__ __launch_bounds__(256) void k_mmr_update(const float* Y, int32_t ld, 
 void launch_receipt_rows(const ReceiptArgs& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.N + 3) / 4)), block(256);
   const int nch = (a.ld + 255) / 256;
+  if (a.pair_dy != nullptr && a.pair_du != nullptr && a.pair_fail != nullptr && nch <= 6) {  // the pair form (two launches)
+    if (nch <= 1) hipLaunchKernelGGL(k_receipt_pairs<1>, grid, block, 0, s, a);
+    else if (nch == 2) hipLaunchKernelGGL(k_receipt_pairs<2>, grid, block, 0, s, a);
+    else if (nch == 3) hipLaunchKernelGGL(k_receipt_pairs<3>, grid, block, 0, s, a);
+    else if (nch == 4) hipLaunchKernelGGL(k_receipt_pairs<4>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_receipt_pairs<6>, grid, block, 0, s, a);
+    hipLaunchKernelGGL(k_receipt_finish, grid, block, 0, s, a);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (nch <= 1) hipLaunchKernelGGL(k_receipt_rows<1>, grid, block, 0, s, a);
   else if (nch == 2) hipLaunchKernelGGL(k_receipt_rows<2>, grid, block, 0, s, a);
   else if (nch == 3) hipLaunchKernelGGL(k_receipt_rows<3>, grid, block, 0, s, a);

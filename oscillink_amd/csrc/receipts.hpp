@@ -26,6 +26,12 @@ struct ReceiptArgs {
   // max(0, 0.5 lamC a_ij (||Up_i - Up_j||^2 - ||Un_i - Un_j||^2)) goes to edge_flow[row * width + e] (ELL-shaped, slots
   // past the degree untouched); nullptr = not wanted
   float* edge_flow = nullptr;
+  // the pair form (receipt_kernels.hip: k_receipt_pairs + k_receipt_finish): ELL-shaped scratch [N * width] for the two squared
+  // distances of every edge, computed from its lower end only, and a word the finish raises if an edge has no mirror slot
+  // (then the outputs are not valid and the caller runs the one-launch kernel).  All three set = use the pair form.
+  float* pair_dy = nullptr;
+  float* pair_du = nullptr;
+  int32_t* pair_fail = nullptr;
 };
 
 void launch_receipt_rows(const ReceiptArgs& a, hipStream_t s);

@@ -1770,3 +1770,50 @@ def test_rescoring_every_candidate_pair_once_gives_the_same_lists(amd, N, D, k, 
     assert np.array_equal(idx1, idx0) and np.array_equal(val1, val0)
     for a, b in zip(csr1, csr0):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("N,D,k,kind,extra", [(20000, 768, 32, "iid", ""), (9000, 128, 16, "clustered", "gates"), (12000, 1536, 48, "iid", "chain"),
+                                                (6000, 300, 8, "dups", ""), (30000, 64, 6, "clustered", "reorder"), (5000, 1600, 12, "iid", "")])
+def test_receipt_pass_that_computes_every_edge_once_gives_the_same_receipt(amd, N, D, k, kind, extra, monkeypatch):
+    """Round 6: the receipt's per-edge pass computes the two squared distances of every undirected edge ONCE (row i its edges to
+    j >= i: k_receipt_pairs; k_receipt_finish fetches the mirror slots and accumulates in edge order) instead of from both ends
+    (k_receipt_rows, OSC_RECEIPT_PAIR=0).  The per-edge values are symmetric bit for bit, so the node components, the null
+    points (index, z, residual), the sums of the receipt and the bundle are identical -- with gates, a chain, duplicated rows
+    (exact ties in the null-point argmax), a lattice stored in BFS order, rows of more than 1536 columns (no pair form there)."""
+    rng = np.random.default_rng(N + D)
+    if kind == "iid":
+        Y = rng.standard_normal((N, D), dtype=np.float32)
+    elif kind == "dups":
+        base = rng.standard_normal((N // 30 + 1, D), dtype=np.float32)
+        Y = base[np.arange(N) % base.shape[0]].copy()
+    else:
+        nc = max(1, N // 100)
+        Y = rng.standard_normal((nc, D), dtype=np.float32)[np.repeat(np.arange(nc), 100)][:N]
+        Y = (Y + 0.35 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+        Y = Y[rng.permutation(N)]
+    psi = Y[:16].mean(0)
+    psi = (psi / (np.linalg.norm(psi) + 1e-12)).astype(np.float32)
+    if extra == "reorder":
+        monkeypatch.setenv("OSC_REORDER", "1")
+    gates = rng.uniform(0.0, 1.0, N).astype(np.float32) if extra == "gates" else None
+    got = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("OSC_RECEIPT_PAIR", pair)
+        lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
+        lat.set_query(psi, gates=gates)
+        if extra == "chain":
+            lat.add_chain(list(range(0, 40, 3)), lamP=0.2)
+        lat.settle(max_iters=12, tol=1e-3)
+        lat.set_receipt_detail("full")
+        rec = lat.receipt()
+        comps = lat._components()
+        nulls = sorted((tuple(d["edge"]), d["z"], d["residual"]) for d in rec["null_points"])
+        got[pair] = (rec["deltaH_total"], rec["coh_drop_sum"], rec["anchor_pen_sum"], rec["query_term_sum"], nulls,
+                     [np.asarray(c).copy() for c in comps], lat.bundle(k=8))
+        lat.close()
+    a, b = got["1"], got["0"]
+    assert a[:4] == b[:4]
+    assert a[4] == b[4] and (len(a[4]) > 0 or kind == "dups")  # (exact duplicates: no residual, no null point)
+    for x, y in zip(a[5], b[5]):
+        assert np.array_equal(x, y)
+    assert a[6] == b[6]
