@@ -1808,6 +1808,7 @@ KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, boo
       p.SA = S;
     }
   }
+  if (tune.sa > 0) p.SA = std::max(1, std::min(tune.sa, p.sample_groups));
   p.sample_tiles_per_split = ((p.sample_groups + p.SA - 1) / p.SA) * p.group_tiles;
   return p;
 }

@@ -70,6 +70,7 @@ struct KnnPanelTune {
   int rank = 0;    // threshold = rank-th largest group maximum of the sample
   int tile_wide = 1;  // 0: the tile core's main sweep with 32 x 128 wave tiles (k_tile_thr<1>)
   int tile_group_mb = 0;  // k_tile_thr2: image bytes of one group of row sets (0: 128 MB)
+  int sa = 0;      // sample sweep: splits of the sample's tile groups per row-block set (0: the planner's tail model)
 };
 KnnPanelPlan knn_panel_plan(int32_t N, int32_t D, int32_t keep, int32_t cus, bool scatter_rows = false, bool sym = false,
                             const KnnPanelTune& tune = KnnPanelTune{});

@@ -47,24 +47,33 @@ __global__ __launch_bounds__(256) void k_normalize_rows(const float* Y, int32_t 
   const float* y = Y + row * ldy;
   float* yn = Yn + row * ldn;
   float ss = 0.f;
-  if (D <= 1024) {  // the row stays in registers between the sum and the scaling (same sums, same order: one read of Y)
-    float v[16];
+  // the row stays in registers between the sum and the scaling (same sums, same order: one read of Y)
+  auto in_registers = [&](auto NC) {
+    constexpr int NV = decltype(NC)::value;
+    float v[NV];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       v[i] = c < D ? y[c] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < NV; ++i)
       if (lane + 64 * i < D) ss = fmaf(v[i], v[i], ss);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float inv = 1.f / (sqrtf(ss) + 1e-12f);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < ldn) yn[c] = c < D ? v[i] * inv : 0.f;
     }
+  };
+  if (D <= 1024) {
+    in_registers(std::integral_constant<int, 16>{});
+    return;
+  }
+  if (D <= 2048) {
+    in_registers(std::integral_constant<int, 32>{});
     return;
   }
   for (int c = lane; c < D; c += 64) ss = fmaf(y[c], y[c], ss);
@@ -1274,16 +1283,17 @@ __global__ void k_row_scale(const float* ell_a, const int32_t* deg, int32_t widt
   for (int e = 0; e < deg[row]; ++e) s += ell_a[(size_t)row * width + e];
   scale[row] = fminf(1.0f, cap / (s + 1e-12f));  // graph.py:77-78
 }
+// (one thread per ELL slot since round 6 -- a thread per row walked its row's slots one by one, 64 rows a wave instruction: 0.54 ms
+// at config 5's 200 000 x 76 slots; the per-entry expressions are unchanged)
 __global__ void k_apply_cap(float* ell_a, const int32_t* ell_col, const int32_t* deg, int32_t width, int32_t N,
                             const float* scale) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= N) return;
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= (int64_t)N * width) return;
+  const int row = (int)(o / width), e = (int)(o - (int64_t)row * width);
+  if (e >= deg[row]) return;
   const float si = scale[row];
-  for (int e = 0; e < deg[row]; ++e) {
-    const size_t o = (size_t)row * width + e;
-    const float a2 = ell_a[o] * sqrtf(si * scale[ell_col[o]]);  // graph.py:80-81
-    ell_a[o] = 0.5f * (a2 + a2);                                 // graph.py:83 (symmetric input: identity)
-  }
+  const float a2 = ell_a[o] * sqrtf(si * scale[ell_col[o]]);  // graph.py:80-81
+  ell_a[o] = 0.5f * (a2 + a2);                                 // graph.py:83 (symmetric input: identity)
 }
 __global__ void k_sqrt_deg(const float* ell_a, const int32_t* deg, int32_t width, int32_t N, float* sqrt_deg) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1294,13 +1304,12 @@ __global__ void k_sqrt_deg(const float* ell_a, const int32_t* deg, int32_t width
 }
 __global__ void k_normalize_w(const float* ell_a, const int32_t* ell_col, const int32_t* deg, int32_t width, int32_t N,
                               const float* sqrt_deg, float* ell_w) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= N) return;
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (one thread per ELL slot, as k_apply_cap)
+  if (o >= (int64_t)N * width) return;
+  const int row = (int)(o / width), e = (int)(o - (int64_t)row * width);
+  if (e >= deg[row]) return;
   const float di = 1.0f / sqrt_deg[row];
-  for (int e = 0; e < deg[row]; ++e) {
-    const size_t o = (size_t)row * width + e;
-    ell_w[o] = (ell_a[o] * di) * (1.0f / sqrt_deg[ell_col[o]]);  // graph.py:89-90
-  }
+  ell_w[o] = (ell_a[o] * di) * (1.0f / sqrt_deg[ell_col[o]]);  // graph.py:89-90
 }
 
 }  // namespace
@@ -1567,12 +1576,13 @@ void launch_mutual_ell(const float* kval, const int32_t* kidx, int32_t N, int32_
 void launch_cap_and_normalize(float* ell_a, float* ell_w, const int32_t* ell_col, const int32_t* deg, int32_t width,
                               int32_t N, float cap, int apply_cap, float* scale_tmp, float* sqrt_deg, hipStream_t s) {
   const dim3 grid((unsigned)((N + 255) / 256)), block(256);
+  const dim3 grid_slots((unsigned)(((int64_t)N * width + 255) / 256));  // (N x width < 2^31: the ELL arrays' own limit)
   if (apply_cap) {
     hipLaunchKernelGGL(k_row_scale, grid, block, 0, s, ell_a, deg, width, N, cap, scale_tmp);
-    hipLaunchKernelGGL(k_apply_cap, grid, block, 0, s, ell_a, ell_col, deg, width, N, scale_tmp);
+    hipLaunchKernelGGL(k_apply_cap, grid_slots, block, 0, s, ell_a, ell_col, deg, width, N, scale_tmp);
   }
   hipLaunchKernelGGL(k_sqrt_deg, grid, block, 0, s, ell_a, deg, width, N, sqrt_deg);
-  hipLaunchKernelGGL(k_normalize_w, grid, block, 0, s, ell_a, ell_col, deg, width, N, sqrt_deg, ell_w);
+  hipLaunchKernelGGL(k_normalize_w, grid_slots, block, 0, s, ell_a, ell_col, deg, width, N, sqrt_deg, ell_w);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -72,6 +72,7 @@ void read_env_build(L& h) {
   if (const char* e = getenv("OSC_KNN_PANEL_RHO")) h.knn_tune.rho = atof(e);
   if (num("OSC_KNN_PANEL_T", v)) h.knn_tune.T = v;
   if (num("OSC_KNN_PANEL_RANK", v)) h.knn_tune.rank = v;
+  if (num("OSC_KNN_PANEL_SA", v)) h.knn_tune.sa = v;
   if (num("OSC_KNN_TILE_WIDE", v)) h.knn_tune.tile_wide = v != 0 ? 1 : 0;
   if (num("OSC_KNN_TILE_GROUP_MB", v)) h.knn_tune.tile_group_mb = v;
   h.knn_force_exchange = num("OSC_KNN_FORCE_EXCHANGE", v) && v != 0;
