@@ -795,9 +795,10 @@ int osc_mmr(osc_handle h, const float* scores, int32_t k, float lambda_div, int3
     d_base.alloc((size_t)N);
     d_maxsim.alloc((size_t)N);
     d_alive.alloc((size_t)N);
-    d_pval.alloc((size_t)nblocks);
-    d_pid.alloc((size_t)nblocks);
-    d_prow.alloc((size_t)nblocks);
+    const size_t nparts = std::max<size_t>((size_t)nblocks, (size_t)mmr_parts(N));  // (from the second step on: a partial per workgroup of the cosine pass)
+    d_pval.alloc(nparts);
+    d_pid.alloc(nparts);
+    d_prow.alloc(nparts);
     d_chosen.alloc((size_t)want);
     l.vec_q.alloc((size_t)l.D);
     HIP_CHECK(hipMemcpyAsync(d_base.p, base.data(), (size_t)N * 8, hipMemcpyHostToDevice, l.stream));

@@ -470,30 +470,69 @@ __global__ __launch_bounds__(256) void k_mmr_argmax2(const double* pval, const i
   for (int c = threadIdx.x; c < D; c += 256) q[c] = y[c] * inv;
 }
 
-// maxsim_i = max(maxsim_i, cos(Y_i, q)) for every row (first step: = cos); one wave per row
-__global__ __launch_bounds__(256) void k_mmr_update(const float* Y, int32_t ld, int32_t D, const float* q, int32_t N, int first,
-                                                    double* maxsim) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= N) return;
-  const float* y = Y + (size_t)row * ld;
-  float s = 0.f, n2 = 0.f;
-  const int d4 = D & ~3;
-  for (int c = lane * 4; c < d4; c += 256) {
-    const float4 v = ld4(y + c), w = ld4(q + c);
-    s = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, s))));
-    n2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, n2))));
+// maxsim_i = max(maxsim_i, cos(Y_i, q)) for every row (first pass: = cos), one wave per row -- and, round 6, the first argmax
+// stage of the NEXT step in the same launch: a wave updates its row's running maximum and, if the row is still alive, offers (1 - lambda) score - lambda maxsim; the workgroup's four offers
+// go to one partial.  (The argmax is a maximum under a total order -- value, then the smaller API id -- so the shape of
+// the reduction tree does not matter: same winners as k_mmr_argmax1's strided partials.)  Two launches per step instead of
+// three, and no cosine pass behind the last pick.
+__global__ __launch_bounds__(256) void k_mmr_update_argmax(const float* Y, int32_t ld, int32_t D, const float* q, int32_t N, int first,
+                                                           double* maxsim, const double* base, const unsigned char* alive,
+                                                           const int32_t* api_id, double lambda, double* pval, int32_t* pid,
+                                                           int32_t* prow) {
+  __shared__ double sv[4];
+  __shared__ int sid[4], srow[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v = MMR_DEAD;  // (lane 0: the best offer of this wave's rows)
+  int id = 0x7fffffff, rr = -1;
+  for (int row = blockIdx.x * 4 + wave; row < N; row += (int)gridDim.x * 4) {  // (at most MMR_PARTS workgroups: a few rows per wave)
+    const float* y = Y + (size_t)row * ld;
+    float s = 0.f, n2 = 0.f;
+    const int d4 = D & ~3;
+    for (int c = lane * 4; c < d4; c += 256) {
+      const float4 a = ld4(y + c), w = ld4(q + c);
+      s = fmaf(a.x, w.x, fmaf(a.y, w.y, fmaf(a.z, w.z, fmaf(a.w, w.w, s))));
+      n2 = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, n2))));
+    }
+    for (int c = d4 + lane; c < D; c += 64) {
+      const float a = y[c];
+      s = fmaf(a, q[c], s);
+      n2 = fmaf(a, a, n2);
+    }
+    s = wave_sum(s);
+    n2 = wave_sum(n2);
+    if (lane == 0) {
+      const double cs = (double)(s / (sqrtf(n2) + 1e-12f));
+      const double ms = first ? cs : fmax(maxsim[row], cs);
+      maxsim[row] = ms;
+      if (alive[row]) {
+        const double cand = base[row] - lambda * ms;
+        const int cid = api_id ? api_id[row] : row;
+        if (rr < 0 || mmr_better(cand, cid, v, id)) {
+          v = cand;
+          id = cid;
+          rr = row;
+        }
+      }
+    }
   }
-  for (int c = d4 + lane; c < D; c += 64) {
-    const float v = y[c];
-    s = fmaf(v, q[c], s);
-    n2 = fmaf(v, v, n2);
-  }
-  s = wave_sum(s);
-  n2 = wave_sum(n2);
   if (lane == 0) {
-    const double cs = (double)(s / (sqrtf(n2) + 1e-12f));
-    maxsim[row] = first ? cs : fmax(maxsim[row], cs);
+    sv[wave] = v;
+    sid[wave] = id;
+    srow[wave] = rr;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double bv = MMR_DEAD;
+    int bid = 0x7fffffff, brow = -1;
+    for (int w = 0; w < 4; ++w)
+      if (srow[w] >= 0 && (brow < 0 || mmr_better(sv[w], sid[w], bv, bid))) {
+        bv = sv[w];
+        bid = sid[w];
+        brow = srow[w];
+      }
+    pval[blockIdx.x] = bv;
+    pid[blockIdx.x] = bid;
+    prow[blockIdx.x] = brow;
   }
 }
 
@@ -521,14 +560,21 @@ void launch_receipt_rows(const ReceiptArgs& a, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+// step 0: strided first stage (no running maximum yet); step s > 0: the cosine pass to the item picked in step s - 1 fused with
+// the first stage (one partial per workgroup: pval / pid / prow hold max(nblocks, mmr_parts(N)) entries)
+int mmr_parts(int32_t N) { return (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)N + 3) / 4, 2048)); }
 void launch_mmr_step(const MmrArgs& a, int step, hipStream_t s) {
-  const int nb = a.nblocks;
-  hipLaunchKernelGGL(k_mmr_argmax1, dim3(nb), dim3(256), 0, s, a.base, a.maxsim, a.alive, a.api_id, a.N, a.lambda,
-                     step == 0 ? 1 : 0, a.pval, a.pid, a.prow);
+  int nb = a.nblocks;
+  if (step == 0) {
+    hipLaunchKernelGGL(k_mmr_argmax1, dim3(nb), dim3(256), 0, s, a.base, a.maxsim, a.alive, a.api_id, a.N, a.lambda, 1, a.pval,
+                       a.pid, a.prow);
+  } else {
+    nb = mmr_parts(a.N);
+    hipLaunchKernelGGL(k_mmr_update_argmax, dim3((unsigned)nb), dim3(256), 0, s, a.Y, a.ld, a.D, a.q, a.N, step == 1 ? 1 : 0,
+                       a.maxsim, a.base, a.alive, a.api_id, a.lambda, a.pval, a.pid, a.prow);
+  }
   hipLaunchKernelGGL(k_mmr_argmax2, dim3(1), dim3(256), 0, s, a.pval, a.pid, a.prow, nb, a.alive, a.chosen_api, step, a.Y,
                      a.ld, a.D, a.q);
-  hipLaunchKernelGGL(k_mmr_update, dim3((unsigned)((a.N + 3) / 4)), dim3(256), 0, s, a.Y, a.ld, a.D, a.q, a.N,
-                     step == 0 ? 1 : 0, a.maxsim);
   HIP_CHECK(hipGetLastError());
 }
 

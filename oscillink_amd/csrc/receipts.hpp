@@ -52,5 +52,6 @@ struct MmrArgs {
   double lambda;
 };
 void launch_mmr_step(const MmrArgs& a, int step, hipStream_t s);
+int mmr_parts(int32_t N);  // partials of the fused cosine + argmax pass (pval / pid / prow must hold max(nblocks, this))
 
 }  // namespace osc
