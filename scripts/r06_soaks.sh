@@ -19,6 +19,6 @@ run soak_sharded_build python tests/soak/soak_sharded_build.py $((4+S)) 12
 run soak_streamed_create python tests/soak/soak_streamed_create.py $((42+S)) 16
 run soak_cg_loop python tests/soak/soak_cg_loop.py $((7+S)) 30
 run soak_blocked_apply python tests/soak/soak_blocked_apply.py $((4+S)) 16
-run soak_sequences python tests/soak/soak_sequences.py $((6+S)) 20
+run soak_sequences python tests/soak/soak_sequences.py $((6+S)) $((20+S))  # (first seed, one past the last)
 run soak_multirank python tests/soak/soak_multirank.py $((11+S)) 20
 grep -c "rc=0" $O

@@ -46,8 +46,9 @@ for t in range(count):
             srow = Yn @ Yn[r]
             srow[r] = -np.inf
             kth = np.partition(srow, -k)[-k]
-            near = near or abs(srow[c] - kth) < 2e-6
+            near = near or abs(srow[c] - kth) < 2e-6 * max(1.0, D / 1024.0)  # (fp32 summation noise grows with D: soak_panel.py)
         ok = ok and near
     bad += not ok
     print(f"N={N} D={D} k={k} clustered={clustered} edges={len(eb)} symmetric-difference={diff}(near-ties only: {ok}) fallback_rows={info['prefilter']['fallback_rows']} {'ok' if ok else 'MISMATCH'}", flush=True)
 print("mismatches:", bad)
+sys.exit(1 if bad else 0)

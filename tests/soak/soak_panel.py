@@ -55,6 +55,9 @@ for t in range(count):
     eb = set(zip(np.repeat(np.arange(N), np.diff(b[0])).tolist(), b[1].tolist()))
     diff = ea ^ eb
     ok = True
+    # two fp32 summation orders of a D-term dot product of near-unit scores differ by up to ~D x 2e-9 (clustered anchors, scores
+    # ~ 0.99: seed 333's case 7, N = 30000, D = 1536, one edge at a float64 gap of 2.10e-6 under OSC_KNN_PANEL_T=6)
+    tol = 2e-6 * max(1.0, D / 1024.0)
     Yn = None
     for (i, j) in list(diff)[:48]:
         if Yn is None:
@@ -65,9 +68,10 @@ for t in range(count):
             srow = Yn @ Yn[r]
             srow[r] = -np.inf
             kth = np.partition(srow, -k)[-k]
-            near = near or abs(srow[c] - kth) < 2e-6
+            near = near or abs(srow[c] - kth) < tol
         ok = ok and near
     bad += not ok
     print(f"N={N} D={D} k={k} {kind}: route {info['panel']['prefilter']} edges={len(eb)} symmetric-difference={len(diff)} "
           f"(near-ties only: {ok}) fallback_rows={info['panel']['fallback_rows']} {'ok' if ok else 'MISMATCH'}", flush=True)
 print("mismatches:", bad)
+sys.exit(1 if bad else 0)

@@ -22,3 +22,4 @@ for seed in range(lo, hi):
         print("seed", seed, "FAILED")
         traceback.print_exc(limit=3)
 print(f"seeds {lo}..{hi - 1}: {len(bad)} failed {bad}  (OSC_SMALL_PATH={os.environ.get('OSC_SMALL_PATH', 'default')})")
+sys.exit(1 if bad else 0)
