@@ -1152,55 +1152,62 @@ __global__ __launch_bounds__(256) void k_panel_select(const uint2* hit_list, con
       for (int e = lane; e < keep; e += 64) oi[e] = -1;
       continue;
     }
-    const uint2* ent = sorted + start[rl];
-    constexpr int M = SEL_CAP / 64;
-    unsigned key[M], col[M], bits[M];
+    // (round 6: the registers a row's candidates take are a template constant of this part -- 4, 8 or 16 -- instead of sixteen
+    // predicated rounds for every row: a config-3 row has ~190 candidates, three registers)
+    auto select_row = [&](auto MC) {
+      constexpr int M = decltype(MC)::value;
+      const uint2* ent = sorted + start[rl];
+      unsigned key[M], col[M], bits[M];
 #pragma unroll
-    for (int q = 0; q < M; ++q) {
-      const int e = lane + 64 * q;
-      key[q] = 0u;  // below every real key (scores here are > tau; order_key never yields 0 for them)
-      col[q] = 0u;
-      bits[q] = 0u;
-      if (e < m) {
-        const uint2 v = ent[e];
-        col[q] = mapped ? (unsigned)knn_map_lattice_row(map, N, (int)v.x) : v.x;  // image column -> lattice column
-        bits[q] = v.y;
-        key[q] = order_key(v.y);
+      for (int q = 0; q < M; ++q) {
+        const int e = lane + 64 * q;
+        key[q] = 0u;  // below every real key (scores here are > tau; order_key never yields 0 for them)
+        col[q] = 0u;
+        bits[q] = 0u;
+        if (e < m) {
+          const uint2 v = ent[e];
+          col[q] = mapped ? (unsigned)knn_map_lattice_row(map, N, (int)v.x) : v.x;  // image column -> lattice column
+          bits[q] = v.y;
+          key[q] = order_key(v.y);
+        }
       }
-    }
-    const int mq = (m + 63) / 64;  // registers in use (wave-uniform)
-    unsigned T = 0u;
-    for (int b = 31; b >= 0; --b) {
-      const unsigned cand = T | (1u << b);
-      int ge = 0;
+      const int mq = (m + 63) / 64;  // registers in use (wave-uniform)
+      unsigned T = 0u;
+      for (int b = 31; b >= 0; --b) {
+        const unsigned cand = T | (1u << b);
+        int ge = 0;
+#pragma unroll
+        for (int q = 0; q < M; ++q)
+          if (q < mq) ge += __popcll(__ballot(key[q] >= cand));
+        if (ge >= keep) T = cand;
+      }
+      int n_gt = 0;
 #pragma unroll
       for (int q = 0; q < M; ++q)
-        if (q < mq) ge += __popcll(__ballot(key[q] >= cand));
-      if (ge >= keep) T = cand;
-    }
-    int n_gt = 0;
+        if (q < mq) n_gt += __popcll(__ballot(key[q] > T));
+      int base_gt = 0, base_eq = n_gt;
 #pragma unroll
-    for (int q = 0; q < M; ++q)
-      if (q < mq) n_gt += __popcll(__ballot(key[q] > T));
-    int base_gt = 0, base_eq = n_gt;
-#pragma unroll
-    for (int q = 0; q < M; ++q) {
-      if (q >= mq) continue;
-      const bool gt = key[q] > T, eq = key[q] == T && key[q] != 0u;
-      const unsigned long long bg = __ballot(gt), be = __ballot(eq);
-      const int pg = base_gt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bg, 0u));
-      const int pe = base_eq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(be >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)be, 0u));
-      if (gt) {
-        ov[pg] = __uint_as_float(bits[q]);
-        oi[pg] = (int32_t)col[q];
+      for (int q = 0; q < M; ++q) {
+        if (q >= mq) continue;
+        const bool gt = key[q] > T, eq = key[q] == T && key[q] != 0u;
+        const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+        const int pg = base_gt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bg, 0u));
+        const int pe = base_eq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(be >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)be, 0u));
+        if (gt) {
+          ov[pg] = __uint_as_float(bits[q]);
+          oi[pg] = (int32_t)col[q];
+        }
+        if (eq && pe < keep) {
+          ov[pe] = __uint_as_float(bits[q]);
+          oi[pe] = (int32_t)col[q];
+        }
+        base_gt += __popcll(bg);
+        base_eq += __popcll(be);
       }
-      if (eq && pe < keep) {
-        ov[pe] = __uint_as_float(bits[q]);
-        oi[pe] = (int32_t)col[q];
-      }
-      base_gt += __popcll(bg);
-      base_eq += __popcll(be);
-    }
+    };
+    if (m <= 256) select_row(std::integral_constant<int, 4>{});
+    else if (m <= 512) select_row(std::integral_constant<int, 8>{});
+    else select_row(std::integral_constant<int, SEL_CAP / 64>{});
   }
 }
 
