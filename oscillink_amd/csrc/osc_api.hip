@@ -67,7 +67,7 @@ void read_env_build(L& h) {
   h.create_piece_mb_set = num("OSC_CREATE_PIECE_MB", v);
   h.create_piece_mb = h.create_piece_mb_set ? std::max(1, std::min(v, 1024)) : 24;
   h.knn_tune = KnnPanelTune{};
-  h.knn_rescore_pair = !(num("OSC_KNN_RESCORE_PAIR", v) && v == 0);
+  h.knn_rescore_pair = num("OSC_KNN_RESCORE_PAIR", v) ? std::max(0, std::min(v, 2)) : 1;
   if (num("OSC_KNN_PANEL_NRG", v)) h.knn_tune.nrg = v;
   if (const char* e = getenv("OSC_KNN_PANEL_RHO")) h.knn_tune.rho = atof(e);
   if (num("OSC_KNN_PANEL_T", v)) h.knn_tune.T = v;

@@ -807,11 +807,12 @@ static bool build_graph_once(L& h, const float* host_Y) {
       launch_panel_select(pp, rb_begin, rb_count, N, p_hits.p, p_hcnt.p, cval.p, cidx.p, fail_rows.p, fail_count.p,
                           h.stream, pp.sym ? &sym_dev : nullptr);
       if (knn_debug) fprintf(stderr, "[knn] after the select: %d rows without a candidate list\n", failed_so_far());
-      // (single-process builds of rows of >= 640 columns: every undirected candidate pair is scored once -- two launches and two
+      // (single-process builds of rows of >= 384 columns: every undirected candidate pair is scored once -- two launches and two
       // N x keep scratch arrays.  A lookup in the partner's list costs keep x 4 bytes and a dependent round trip per candidate,
       // which short rows do not repay: build with / without, profiles/r06_rescore_ab.txt: config 3 12.07 / 12.54 ms, config 5
-      // 91.7 / 96.1, config 4 (384 columns) 413.9 / 413.2, 40 000 x 256 3.68 / 3.20)
-      if (h.knn_rescore_pair && h.D >= 640 && parts == 1 && !exchange && h.comm == nullptr && (int64_t)N * keep_f < ((int64_t)1 << 31)) {
+      // 91.7 / 96.1; with the cheaper selection tail of the round's last pass also 140 000 x 576 18.24 / 18.80, 200 000 x 512
+      // 30.74 / 31.05, config 4 (384 columns) 390.8 / 393.6, 100 000 x 384 6.56 / 6.61; 40 000 x 256 a tie, 2.03 / 2.00)
+      if ((h.knn_rescore_pair == 2 || (h.knn_rescore_pair == 1 && h.D >= 384)) && parts == 1 && !exchange && h.comm == nullptr && (int64_t)N * keep_f < ((int64_t)1 << 31)) {
         pair_sc.alloc((size_t)N * keep_f);
         pair_pos.alloc((size_t)N * keep_f);
       }

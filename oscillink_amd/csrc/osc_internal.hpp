@@ -145,7 +145,7 @@ struct osc_lattice {
   int32_t create_two_mb = 256;  // OSC_CREATE_TWO_PIECE_MB: anchors from this size on may travel in TWO pieces (three below it)
   bool create_force_retry = false;  // OSC_CREATE_FORCE_RETRY (test hook): a streamed build always hands over to the whole-array one
   int32_t create_pieces = 0;   // pieces the last build received its anchors in (0: they were on the device before it started)
-  bool knn_rescore_pair = true;  // OSC_KNN_RESCORE_PAIR: the exact re-scoring scores every undirected candidate pair once (single-process builds)
+  int knn_rescore_pair = 1;  // OSC_KNN_RESCORE_PAIR: 0 = every candidate pair scored from both ends, 1 = once where rows have >= 384 columns, 2 = once at any width (experiments)
   int32_t knn_sweep = 0;       // main sweep of the last build's thresholds-and-hits prefilter: 0 none (another route), 1 every column tile per row block, 2 the half sweep (ONE per build, shared by the ranks of a sharded build)
   bool knn_force_exchange = false;  // OSC_KNN_FORCE_EXCHANGE=1 (test hook): run the sharded half sweep's collectives under a ONE-rank communicator too
   KnnPanelTune knn_tune{};     // OSC_KNN_PANEL_NRG / _RHO / _T / _RANK

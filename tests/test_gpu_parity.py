@@ -1734,10 +1734,10 @@ def test_non_finite_anchor_rows_on_the_wide_tile_core(amd, monkeypatch):
 
 
 @pytest.mark.parametrize("N,D,k,kind,mode", [(20000, 700, 32, "clustered", "panel"), (16400, 768, 16, "dups", "panel"),
-                                              (20000, 1000, 40, "iid", "panel"), (12000, 640, 24, "iid", "prefilter"),
+                                              (20000, 1000, 40, "iid", "panel"), (12000, 640, 24, "iid", "prefilter"), (24000, 384, 16, "clustered", "panel"),
                                               (33000, 768, 8, "grouped", "panel")])
 def test_rescoring_every_candidate_pair_once_gives_the_same_lists(amd, N, D, k, kind, mode, monkeypatch):
-    """Round 6: in single-process builds of rows of >= 640 columns the exact re-scoring scores every undirected candidate pair
+    """Round 6: in single-process builds of rows of >= 384 columns the exact re-scoring scores every undirected candidate pair
     once -- row i leaves the pairs (i, j), j < i, in which it stands in j's list to row j and fetches j's result
     (k_knn_rescore_pair + k_knn_rescore_finish) -- instead of from both ends (k_knn_rescore, OSC_KNN_RESCORE_PAIR=0).  The exact
     dot product is symmetric bit for bit, so lists (indices AND similarities), proofs, fallback rows and lattices are identical:
