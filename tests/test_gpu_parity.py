@@ -1773,7 +1773,8 @@ def test_rescoring_every_candidate_pair_once_gives_the_same_lists(amd, N, D, k, 
 
 
 @pytest.mark.parametrize("N,D,k,kind,extra", [(20000, 768, 32, "iid", ""), (9000, 128, 16, "clustered", "gates"), (12000, 1536, 48, "iid", "chain"),
-                                                (6000, 300, 8, "dups", ""), (30000, 64, 6, "clustered", "reorder"), (5000, 1600, 12, "iid", "")])
+                                                (6000, 300, 8, "dups", ""), (30000, 64, 6, "clustered", "reorder"), (5000, 1600, 12, "iid", ""),
+                                                (5000, 128, 100, "clustered", "")])  # (rows of more than 64 edges: the finish walks them in chunks)
 def test_receipt_pass_that_computes_every_edge_once_gives_the_same_receipt(amd, N, D, k, kind, extra, monkeypatch):
     """Round 6: the receipt's per-edge pass computes the two squared distances of every undirected edge ONCE (row i its edges to
     j >= i: k_receipt_pairs; k_receipt_finish fetches the mirror slots and accumulates in edge order) instead of from both ends
