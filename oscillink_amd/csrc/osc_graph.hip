@@ -559,8 +559,9 @@ static bool build_graph_once(L& h, const float* host_Y) {
   const int keep_f = std::min(96, k + std::max(12, k / 2));
   constexpr bool dense_small = true;
   constexpr int dense_max = 8192;
-  // small lattices go through the dense similarity matrix (below); beyond that the fp16 prefilter pays
-  bool prefilter = (keep_f >= k + 8) && N >= 4096 && !(dense_small && parts == 1 && N <= dense_max);
+  // small lattices go through the dense similarity matrix (below) unless the panel route takes them; beyond that the fp16
+  // prefilter pays
+  bool prefilter = (keep_f >= k + 8) && N >= 4096;
   // OSC_KNN_MODE = exact | prefilter | panel: force one route (tests, A/B)
   if (h.knn_mode == 1) prefilter = false;
   if (h.knn_mode == 2) prefilter = (keep_f >= k + 8);
@@ -568,7 +569,13 @@ static bool build_graph_once(L& h, const float* host_Y) {
   // The prefilter's GEMM has two shapes: "panel" (knn_gemm.hip: query panel in registers, thresholds from a column
   // sample, hits appended -- D <= 768 and enough row blocks for the sample) and the older 128 x 128 tile with
   // register-resident sorted lists (k_knn_pref), which serves everything else.
-  constexpr int panel_min = 8193;  // (up to 8192 rows: the dense route)
+  // Where the panel route starts.  Until round 6: behind the dense route, at 8193 rows.  With that round's lighter small kernels
+  // (threshold kernel, select, re-scoring tail, row kernels) it is ahead of the dense route from its own lower limit of 6144
+  // rows on wide rows (scripts/exp/r06/route_crossover.py, build in ms, dense / panel: 6144 x 768 k 32 0.83 / 0.63, 8192 x 768
+  // 1.45 / 0.77, 6144 x 1536 1.33 / 0.73, 8192 x 1536 2.34 / 0.83; 7000 x 384 k 16 0.61 / 0.55, 8192 x 384 0.82 / 0.69, but 6144 x
+  // 384 0.48 / 0.55 and 8192 x 128 0.53 / 0.62): from 6144 rows at >= 512 columns, 7168 at >= 320, 8193 below.  (Sharded builds
+  // have no dense route and keep their tile prefilter up to 8192 rows.)
+  const int panel_min = parts == 1 && h.knn_mode == 0 ? (h.D >= 512 ? 6144 : h.D >= 320 ? 7168 : 8193) : 8193;
   // (a hit entry packs the column index into 25 bits, next to its two side flags)
   // (D > 768: the same route on the tile core, k_tile_thr -- half sweep only, so single-process builds only)
   // (round 5: the half sweep also under sharding -- the ranks split the work ITEMS of the one sweep and exchange the hits of
@@ -590,6 +597,7 @@ static bool build_graph_once(L& h, const float* host_Y) {
   const bool depth_ok = knn_panel_nkt(h.D) != 0 || (sym_ok && knn_tile_nkt(h.D) != 0);
   bool panel = prefilter && depth_ok && N >= panel_min && N < (1 << 25) &&
                knn_panel_plan(N, h.D, keep_f, prop.multiProcessorCount, false, sym_ok, h.knn_tune).ok;
+  if (h.knn_mode == 0 && dense_small && parts == 1 && N <= dense_max && !panel) prefilter = false;  // the dense route (below)
   if (h.knn_mode == 3) panel = prefilter = (keep_f >= k + 8) && !any_k && depth_ok && N >= 6144 && N < (1 << 25);
   if (h.knn_mode == 2) panel = false;
   h.knn_panel = panel;

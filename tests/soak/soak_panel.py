@@ -14,6 +14,7 @@ import oscillink_amd as amd  # noqa: E402
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 wide = len(sys.argv) > 3 and sys.argv[3] == "wide"  # only shapes whose main sweep runs with 64 x 128 wave tiles (k_tile_thr2): D > 768, N >= ~49k
+small = len(sys.argv) > 3 and sys.argv[3] == "small"  # round 6: 6144-8192 rows of 320-1600 columns -- the panel route's new lower end (the PLANNER's route against the exact one)
 rng = np.random.default_rng(seed)
 bad = 0
 special = [(16384, 384, 16), (16385, 385, 8), (32768, 64, 1), (20000, 8, 5), (16400, 768, 64), (50000, 200, 33), (16384, 769, 12),
@@ -21,6 +22,10 @@ special = [(16384, 384, 16), (16385, 385, 8), (32768, 64, 1), (20000, 8, 5), (16
 for t in range(count):
     if wide:
         N, D, k = int(rng.integers(49200, 90000)), int(rng.integers(769, 1601)), int(rng.integers(1, 33))
+    elif small:
+        N, D, k = int(rng.integers(6144, 8193)), int(rng.integers(320, 1601)), int(rng.integers(1, 65))
+        if t % 4 == 0:
+            N = int(rng.choice([6144, 7168, 8192, 6145, 7167]))
     elif t < len(special):
         N, D, k = special[t]
     else:
@@ -46,6 +51,8 @@ for t in range(count):
     g, info = {}, {}
     for mode in ("panel", "exact"):
         os.environ["OSC_KNN_MODE"] = mode
+        if small and mode == "panel":
+            os.environ.pop("OSC_KNN_MODE")  # the planner's own choice
         lat = amd.Oscillink(Y, kneighbors=k, deterministic_k=True)
         g[mode] = lat.graph_csr()
         info[mode] = lat.build_info()
