@@ -187,13 +187,15 @@ void maybe_reorder(L& l) {
   if (l.reorder == 0 || (l.comm != nullptr && l.shard_mode != 1) || l.N < 2) return;
   if (l.reorder < 0) {
     if (l.N < 8192 || l.nnz == 0) return;  // small lattices run out of LDS / L2 anyway
+    constexpr int kSample = 1024;
     DevBuf<unsigned long long> cnt;
-    cnt.alloc(2);
-    HIP_CHECK(hipMemsetAsync(cnt.p, 0, 16, l.stream));
-    launch_clustering_sample(l.ell_col.p, l.deg.p, l.width, l.N, 1024, cnt.p, l.stream);
-    unsigned long long hc[2] = {0, 0};
-    HIP_CHECK(hipMemcpyAsync(hc, cnt.p, 16, hipMemcpyDeviceToHost, l.stream));
+    cnt.alloc(2 * kSample);  // (every sampled row writes its own two words: perm_kernels.hip)
+    launch_clustering_sample(l.ell_col.p, l.deg.p, l.width, l.N, kSample, cnt.p, l.stream);
+    std::vector<unsigned long long> per_row((size_t)2 * kSample, 0ull);
+    HIP_CHECK(hipMemcpyAsync(per_row.data(), cnt.p, per_row.size() * 8, hipMemcpyDeviceToHost, l.stream));
     sync(l);
+    unsigned long long hc[2] = {0, 0};
+    for (int s2 = 0; s2 < kSample; ++s2) hc[0] += per_row[(size_t)2 * s2], hc[1] += per_row[(size_t)2 * s2 + 1];
     l.clustering = hc[1] ? (double)hc[0] / (double)hc[1] : 0.0;
     if (l.clustering < 0.05) return;
   }

@@ -20,6 +20,7 @@ bool device_bfs_order(const int32_t* col, const int32_t* deg, int32_t width, int
 size_t scan_blocks(int64_t n);
 void exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* sums, hipStream_t s);
 
+// counts: 2 * nsample words, written (not added to): [2 s] adjacent neighbour pairs of sampled row s, [2 s + 1] its pairs
 void launch_clustering_sample(const int32_t* col, const int32_t* deg, int32_t width, int64_t N, int32_t nsample,
                               unsigned long long* counts, hipStream_t s);
 
